@@ -1,0 +1,126 @@
+"""ctypes binding of include/adafocus.h.
+
+PyTorch is plumbing here: it owns device memory and streams; every compute call goes through
+the C ABI with raw ``data_ptr()`` values and the current HIP stream.  There is NO fallback: if
+``libadafocus_hip.so`` is missing or the device is not a gfx950 part, calls raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadafocus_hip.so")
+
+LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+CONV_TILES = 4
+
+# every symbol include/adafocus.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "adaf_version", "adaf_create", "adaf_destroy", "adaf_last_error", "adaf_device_cus",
+    "adaf_crop_gather_f32", "adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32", "adaf_pack_conv_weight_f32",
+    "adaf_fold_bn_f32", "adaf_maxpool3x3s2_f32", "adaf_global_avgpool_f32", "adaf_temporal_shift_f32",
+    "adaf_resnet50_create", "adaf_resnet50_destroy", "adaf_resnet50_set_param", "adaf_resnet50_finalize",
+    "adaf_resnet50_workspace_bytes", "adaf_resnet50_forward", "adaf_resnet50_launch_count",
+    "adaf_resnet50_forward_profiled", "adaf_resnet50_set_tiles", "adaf_gru_cls_workspace_bytes",
+    "adaf_gru_cls_forward_f32", "adaf_fc_meanpool_forward_f32", "adaf_copy2d_f32",
+)
+
+
+class ConvParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n", "h", "w", "cin", "cout", "kh", "kw", "stride", "pad", "act",
+                                       "tsm_segments", "tsm_div", "ldx", "ldo", "ldr", "tile")]
+
+
+class AdafError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree shared library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdafError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` or `make -C adafocus_amd/csrc`)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.c_int, C.c_float
+    lib.adaf_last_error.restype = C.c_char_p
+    lib.adaf_last_error.argtypes = [vp]
+    lib.adaf_create.argtypes = [ip, C.POINTER(vp)]
+    lib.adaf_destroy.argtypes = [vp]
+    lib.adaf_device_cus.argtypes = [vp]
+    lib.adaf_crop_gather_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, ip, vp, vp]
+    for name in ("adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(ConvParams), vp, vp, vp, vp, vp, vp, vp]
+    lib.adaf_pack_conv_weight_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp]
+    lib.adaf_fold_bn_f32.argtypes = [vp, vp, vp, vp, vp, fp, ip, vp, vp, vp]
+    lib.adaf_maxpool3x3s2_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp]
+    lib.adaf_global_avgpool_f32.argtypes = [vp, vp, ip, ip, ip, vp, ip, vp]
+    lib.adaf_temporal_shift_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp, vp]
+    lib.adaf_resnet50_create.argtypes = [vp, C.POINTER(vp)]
+    lib.adaf_resnet50_destroy.argtypes = [vp]
+    lib.adaf_resnet50_set_param.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    lib.adaf_resnet50_finalize.argtypes = [vp, vp]
+    lib.adaf_resnet50_workspace_bytes.restype = C.c_size_t
+    lib.adaf_resnet50_workspace_bytes.argtypes = [vp, ip, ip]
+    lib.adaf_resnet50_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, vp, C.c_size_t, vp]
+    lib.adaf_resnet50_launch_count.argtypes = [vp]
+    lib.adaf_resnet50_forward_profiled.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, vp, C.c_size_t, vp, vp, vp, vp, vp]
+    lib.adaf_resnet50_set_tiles.argtypes = [vp, vp, ip]
+    lib.adaf_gru_cls_workspace_bytes.restype = C.c_size_t
+    lib.adaf_gru_cls_workspace_bytes.argtypes = [ip, ip, ip]
+    lib.adaf_gru_cls_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                             C.c_size_t, vp]
+    lib.adaf_fc_meanpool_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp, C.c_size_t, vp]
+    lib.adaf_copy2d_f32.argtypes = [vp, vp, ip, vp, ip, ip, ip, vp]
+    _lib = lib
+    return lib
+
+
+_handles = {}
+
+
+def handle(device):
+    """One library handle per device per process."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _handles:
+        lib = load_library()
+        h = C.c_void_p()
+        rc = lib.adaf_create(idx, C.byref(h))
+        if rc != 0:
+            raise AdafError("adaf_create(device=%d) failed with %d: no gfx950 (MI355X) device -- this package "
+                            "has no CPU or non-gfx950 path" % (idx, rc))
+        _handles[idx] = h
+    return _handles[idx]
+
+
+def check(rc, h):
+    if rc != 0:
+        raise AdafError("adafocus HIP call failed (%d): %s" % (rc, load_library().adaf_last_error(h).decode()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def need_gpu_f32(*tensors):
+    """Product-path guard: the HIP path is the only path."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AdafError("adafocus_amd runs on MI355X only: got a %s tensor (no CPU fallback exists)" % t.device)
+        if t.dtype != torch.float32:
+            raise AdafError("adafocus_amd computes in fp32: got %s" % t.dtype)

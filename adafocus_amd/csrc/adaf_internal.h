@@ -1,0 +1,53 @@
+// Internal declarations shared by the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "../../include/adafocus.h"
+
+struct adaf_handle {
+    int device = 0;
+    int cus = 256;
+    std::string err;
+};
+
+// Flattened description of one implicit-GEMM convolution launch.
+struct ConvArgs {
+    const float* x;
+    const float* w;      // [N][K] with K ordered (kh, kw, cin)
+    const float* scale;  // may be null (= 1)
+    const float* bias;   // may be null (= 0)
+    const float* res;    // may be null
+    float* out;
+    int M, N, K;         // GEMM extents: pixels out, channels out, kh*kw*cin
+    int cin, H, W, OH, OW, KH, KW, stride, pad;
+    int ldx, ldo, ldr;
+    int act;
+    int tsm_T, tsm_fold, tsm_hw;
+    int tiles_n;         // ceil(N / BN) for the chosen tile
+    int nblocks;
+};
+
+// conv_gemm.hip
+int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0
+int adaf_pick_conv_tile(int M, int N, int K, int cus);
+void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
+
+// crop.hip
+hipError_t adaf_launch_crop(const float* frames, int nf, int C, int H, int W, const float* act, int fpa, int P,
+                            float* out, int layout, int32_t* coords, hipStream_t s);
+
+// misc_ops.hip
+void adaf_launch_pack_weight(const float* w, int cout, int cin, int kh, int kw, int cin_pad, float* o, hipStream_t s);
+void adaf_launch_fold_bn(const float* g, const float* b, const float* m, const float* v, float eps, int c,
+                         float* scale, float* bias, hipStream_t s);
+void adaf_launch_maxpool(const float* x, int n, int h, int w, int c, float* o, hipStream_t s);
+void adaf_launch_avgpool(const float* x, int n, int hw, int c, float* o, int ldo, hipStream_t s);
+void adaf_launch_tshift(const float* x, int nt, int c, int hw, int T, int div, int layout, float* o, hipStream_t s);
+void adaf_launch_gru_gates(const float* gi, int ldgi_t, const float* gh, const float* bhh, const float* hprev,
+                           int ldh, float* hout, int ldo, int B, int Hd, hipStream_t s);
+void adaf_launch_segment_mean(const float* logit, int B, int T, int C, const float* glog, int Tg, float* out,
+                              hipStream_t s);
+void adaf_launch_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);

@@ -1,0 +1,541 @@
+// C-ABI layer (include/adafocus.h): argument validation, launch planning, the ResNet-50 trunk
+// object and the GRU classifier driver.  No PyTorch types, no allocation in forward calls.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "adaf_internal.h"
+
+namespace {
+
+int fail(adaf_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+int hip_fail(adaf_handle* h, hipError_t e, const char* what) {
+    return fail(h, ADAF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int conv_out(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+// Validates a conv description and flattens it; returns ADAF_OK or an error code.
+int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, const float* w, const float* scale,
+                   const float* bias, const float* res, float* out, ConvArgs* a) {
+    if (!p || !x || !w || !out) return fail(h, ADAF_E_BADARG, "conv: null pointer");
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->cin <= 0 || p->cout <= 0 || p->kh <= 0 || p->kw <= 0 ||
+        p->stride <= 0 || p->pad < 0)
+        return fail(h, ADAF_E_BADARG, "conv: non-positive extent");
+    if (p->cin % 4) return fail(h, ADAF_E_LAYOUT, "conv: cin=%d must be a multiple of 4 (pad the channel axis)", p->cin);
+    const int ldx = p->ldx ? p->ldx : p->cin, ldo = p->ldo ? p->ldo : p->cout, ldr = p->ldr ? p->ldr : p->cout;
+    if (ldx < p->cin || ldo < p->cout || ldr < p->cout) return fail(h, ADAF_E_BADARG, "conv: pixel stride smaller than channels");
+    if (ldx % 4 || !aligned16(x) || !aligned16(w)) return fail(h, ADAF_E_LAYOUT, "conv: x/w must be 16-byte aligned, ldx % 4 == 0");
+    if (p->act < ADAF_ACT_NONE || p->act > ADAF_ACT_RELU6) return fail(h, ADAF_E_BADARG, "conv: unknown activation %d", p->act);
+    const int oh = conv_out(p->h, p->kh, p->stride, p->pad), ow = conv_out(p->w, p->kw, p->stride, p->pad);
+    if (oh <= 0 || ow <= 0) return fail(h, ADAF_E_BADARG, "conv: empty output");
+    const long long M = (long long)p->n * oh * ow;
+    if (M > 0x7fffffffLL || (long long)p->n * p->h * p->w > 0x7fffffffLL) return fail(h, ADAF_E_BADARG, "conv: too many pixels");
+    int fold = 0;
+    if (p->tsm_segments > 0) {
+        if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0)
+            return fail(h, ADAF_E_BADARG, "conv: fused temporal shift needs a 1x1 stride-1 conv");
+        if (p->tsm_div <= 0 || p->n % p->tsm_segments) return fail(h, ADAF_E_BADARG, "conv: n %% tsm_segments != 0");
+        fold = p->cin / p->tsm_div;
+        if (fold % 4) return fail(h, ADAF_E_LAYOUT, "conv: temporal-shift fold=%d must be a multiple of 4", fold);
+    }
+    a->x = x; a->w = w; a->scale = scale; a->bias = bias; a->res = res; a->out = out;
+    a->M = (int)M; a->N = p->cout; a->K = p->kh * p->kw * p->cin;
+    a->cin = p->cin; a->H = p->h; a->W = p->w; a->OH = oh; a->OW = ow; a->KH = p->kh; a->KW = p->kw;
+    a->stride = p->stride; a->pad = p->pad; a->ldx = ldx; a->ldo = ldo; a->ldr = ldr; a->act = p->act;
+    a->tsm_T = p->tsm_segments > 0 ? p->tsm_segments : 0; a->tsm_fold = fold; a->tsm_hw = p->h * p->w;
+    a->tiles_n = 0; a->nblocks = 0;
+    return ADAF_OK;
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+int adaf_version(void) { return ADAF_VERSION; }
+
+int adaf_create(int device, adaf_handle** out) {
+    if (!out) return ADAF_E_BADARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ADAF_E_ARCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ADAF_E_ARCH;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ADAF_E_ARCH;  // the kernels are gfx950 code objects
+    adaf_handle* h = new adaf_handle();
+    h->device = device;
+    h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = h;
+    return ADAF_OK;
+}
+
+int adaf_destroy(adaf_handle* h) {
+    delete h;
+    return ADAF_OK;
+}
+
+const char* adaf_last_error(const adaf_handle* h) { return h ? h->err.c_str() : "null handle"; }
+int adaf_device_cus(const adaf_handle* h) { return h ? h->cus : 0; }
+
+// ---- crop ------------------------------------------------------------------------------
+int adaf_crop_gather_f32(adaf_handle* h, const float* frames, int n_frames, int channels, int height, int width,
+                         const float* action_yx, int n_actions, int frames_per_action, int patch, float* out,
+                         int out_layout, int32_t* coords_out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (n_frames == 0) return ADAF_OK;  // empty batch: nothing to gather
+    if (!frames || !action_yx || !out) return fail(h, ADAF_E_BADARG, "crop: null pointer");
+    if (n_frames < 0 || channels <= 0 || height <= 0 || width <= 0 || patch <= 0 || frames_per_action <= 0)
+        return fail(h, ADAF_E_BADARG, "crop: non-positive extent");
+    if (patch > height) return fail(h, ADAF_E_BADARG, "crop: patch %d larger than frame height %d", patch, height);
+    if (width < height) return fail(h, ADAF_E_BADARG, "crop: width < height (the reference scales both axes by H-P)");
+    if ((long long)n_actions * frames_per_action != n_frames)
+        return fail(h, ADAF_E_BADARG, "crop: n_actions*frames_per_action=%lld != n_frames=%d",
+                    (long long)n_actions * frames_per_action, n_frames);
+    if (out_layout == ADAF_LAYOUT_NHWC4 && channels != 3) return fail(h, ADAF_E_LAYOUT, "crop: NHWC4 needs 3 channels");
+    if (out_layout == ADAF_LAYOUT_NHWC && channels > 16) return fail(h, ADAF_E_LAYOUT, "crop: NHWC output supports <= 16 channels");
+    if (out_layout < ADAF_LAYOUT_NCHW || out_layout > ADAF_LAYOUT_NHWC4) return fail(h, ADAF_E_LAYOUT, "crop: unknown layout");
+    const int co = out_layout == ADAF_LAYOUT_NCHW ? 1 : (out_layout == ADAF_LAYOUT_NHWC4 ? 4 : channels);
+    if ((size_t)8 * patch * co * sizeof(float) > 160 * 1024) return fail(h, ADAF_E_BADARG, "crop: patch too wide for the LDS tile");
+    hipError_t e = adaf_launch_crop(frames, n_frames, channels, height, width, action_yx, frames_per_action, patch, out,
+                                    out_layout, coords_out, (hipStream_t)stream);
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "crop launch");
+}
+
+// ---- conv ------------------------------------------------------------------------------
+int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const float* x, const float* w_ohwi,
+                           const float* scale, const float* bias, const float* residual, float* out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    ConvArgs a;
+    int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
+    if (rc) return rc;
+    if (p->tile < 0 || p->tile > ADAF_CONV_TILES) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");
+}
+
+int adaf_conv2d_naive_f32(adaf_handle* h, const adaf_conv_params* p, const float* x, const float* w_ohwi,
+                          const float* scale, const float* bias, const float* residual, float* out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    ConvArgs a;
+    int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
+    if (rc) return rc;
+    adaf_launch_conv_naive(a, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "naive conv launch");
+}
+
+int adaf_pack_conv_weight_f32(adaf_handle* h, const float* w_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                              float* w_ohwi, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!w_oihw || !w_ohwi || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cin_pad < cin || cin_pad % 4)
+        return fail(h, ADAF_E_BADARG, "pack: bad arguments");
+    adaf_launch_pack_weight(w_oihw, cout, cin, kh, kw, cin_pad, w_ohwi, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "pack launch");
+}
+
+int adaf_fold_bn_f32(adaf_handle* h, const float* gamma, const float* beta, const float* mean, const float* var,
+                     float eps, int channels, float* scale, float* bias, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!gamma || !beta || !mean || !var || !scale || !bias || channels <= 0) return fail(h, ADAF_E_BADARG, "fold_bn: bad arguments");
+    adaf_launch_fold_bn(gamma, beta, mean, var, eps, channels, scale, bias, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "fold_bn launch");
+}
+
+// ---- pooling / shift / glue ------------------------------------------------------------
+int adaf_maxpool3x3s2_f32(adaf_handle* h, const float* x, int n, int hh, int ww, int c, float* out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!x || !out || n <= 0 || hh <= 0 || ww <= 0 || c <= 0) return fail(h, ADAF_E_BADARG, "maxpool: bad arguments");
+    if (c % 4 || !aligned16(x) || !aligned16(out)) return fail(h, ADAF_E_LAYOUT, "maxpool: c %% 4 and 16-byte alignment required");
+    adaf_launch_maxpool(x, n, hh, ww, c, out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "maxpool launch");
+}
+
+int adaf_global_avgpool_f32(adaf_handle* h, const float* x, int n, int hw, int c, float* out, int ldo, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!x || !out || n <= 0 || hw <= 0 || c <= 0) return fail(h, ADAF_E_BADARG, "avgpool: bad arguments");
+    if (ldo == 0) ldo = c;
+    if (c % 4 || ldo % 4 || ldo < c || !aligned16(x) || !aligned16(out)) return fail(h, ADAF_E_LAYOUT, "avgpool: c,ldo %% 4 and 16-byte alignment required");
+    adaf_launch_avgpool(x, n, hw, c, out, ldo, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "avgpool launch");
+}
+
+int adaf_temporal_shift_f32(adaf_handle* h, const float* x, int nt, int c, int hw, int n_segment, int fold_div,
+                            int layout, float* out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (nt == 0) return ADAF_OK;
+    if (!x || !out || nt < 0 || c <= 0 || hw <= 0 || n_segment <= 0 || fold_div <= 0) return fail(h, ADAF_E_BADARG, "tshift: bad arguments");
+    if (nt % n_segment) return fail(h, ADAF_E_BADARG, "tshift: nt=%d not a multiple of n_segment=%d", nt, n_segment);
+    if (layout != ADAF_LAYOUT_NCHW && layout != ADAF_LAYOUT_NHWC) return fail(h, ADAF_E_LAYOUT, "tshift: layout");
+    if (x == out) return fail(h, ADAF_E_BADARG, "tshift: in-place shift is not supported (as in the reference, temporal_shift.py:36-38)");
+    adaf_launch_tshift(x, nt, c, hw, n_segment, fold_div, layout, out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "tshift launch");
+}
+
+int adaf_copy2d_f32(adaf_handle* h, const float* src, int lds, float* dst, int ldd, int rows, int cols, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (rows == 0 || cols == 0) return ADAF_OK;
+    if (!src || !dst || rows < 0 || cols < 0 || lds < cols || ldd < cols) return fail(h, ADAF_E_BADARG, "copy2d: bad arguments");
+    adaf_launch_copy2d(src, lds, dst, ldd, rows, cols, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "copy2d launch");
+}
+
+}  // extern "C"
+
+// ======================================================================================
+// ResNet-50 trunk
+// ======================================================================================
+struct ConvLayer {
+    std::string name;      // e.g. "layer1.0.conv1"
+    std::string bn;        // e.g. "layer1.0.bn1"
+    int cin, cout, k, stride, pad;
+    int cin_pad;
+    float* w = nullptr;    // packed OHWI
+    float* scale = nullptr;
+    float* bias = nullptr;
+};
+
+struct adaf_resnet50 {
+    adaf_handle* h = nullptr;
+    std::map<std::string, std::pair<const float*, size_t>> params;
+    std::vector<ConvLayer> convs;  // [0] = stem, then per block conv1, conv2, conv3, (downsample)
+    std::vector<int> tiles;        // per conv launch override
+    bool finalized = false;
+};
+
+namespace {
+
+const int kStageBlocks[4] = {3, 4, 6, 3};
+const int kStagePlanes[4] = {64, 128, 256, 512};
+
+void build_layers(adaf_resnet50* net) {
+    net->convs.clear();
+    net->convs.push_back({"conv1", "bn1", 3, 64, 7, 2, 3, 4});
+    int inplanes = 64;
+    for (int s = 0; s < 4; ++s) {
+        const int planes = kStagePlanes[s];
+        for (int b = 0; b < kStageBlocks[s]; ++b) {
+            char pre[32];
+            snprintf(pre, sizeof(pre), "layer%d.%d.", s + 1, b);
+            const int stride = (b == 0 && s > 0) ? 2 : 1;
+            const std::string p(pre);
+            net->convs.push_back({p + "conv1", p + "bn1", inplanes, planes, 1, 1, 0, inplanes});
+            net->convs.push_back({p + "conv2", p + "bn2", planes, planes, 3, stride, 1, planes});
+            net->convs.push_back({p + "conv3", p + "bn3", planes, planes * 4, 1, 1, 0, planes});
+            if (b == 0) net->convs.push_back({p + "downsample.0", p + "downsample.1", inplanes, planes * 4, 1, stride, 0, inplanes});
+            inplanes = planes * 4;
+        }
+    }
+    net->tiles.assign(net->convs.size(), 0);
+}
+
+struct Launch {   // one enqueued kernel of the forward pass, for the profiler
+    double flops, bytes;
+    int tile;
+};
+
+// Walks the trunk; `rec` (optional) gets one hipEvent before each launch plus one at the end.
+int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int tsm_div, float* feat, int ldfeat,
+              void* ws, size_t ws_bytes, hipStream_t st, std::vector<hipEvent_t>* rec, std::vector<Launch>* info) {
+    adaf_handle* h = net->h;
+    if (!net->finalized) return fail(h, ADAF_E_STATE, "resnet50: finalize() has not been called");
+    if (!x4 || !feat || !ws) return fail(h, ADAF_E_BADARG, "resnet50: null pointer");
+    if (n <= 0 || P < 32) return fail(h, ADAF_E_BADARG, "resnet50: need n > 0 and patch >= 32");
+    if (ldfeat == 0) ldfeat = 2048;
+    if (ldfeat < 2048 || ldfeat % 4 || !aligned16(feat) || !aligned16(x4) || !aligned16(ws))
+        return fail(h, ADAF_E_LAYOUT, "resnet50: ldfeat >= 2048, %% 4 == 0 and 16-byte aligned buffers required");
+    if (tsm_T > 0 && n % tsm_T) return fail(h, ADAF_E_BADARG, "resnet50: n=%d not a multiple of tsm_segments=%d", n, tsm_T);
+    const size_t need = adaf_resnet50_workspace_bytes(net, n, P);
+    if (ws_bytes < need) return fail(h, ADAF_E_NOMEM, "resnet50: workspace %zu < %zu bytes", ws_bytes, need);
+
+    const size_t slab = adaf_resnet50_workspace_bytes(net, n, P) / (5 * sizeof(float));  // largest activation, floats
+    float* buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = static_cast<float*>(ws) + i * slab;
+
+    auto mark = [&](double flops, double bytes, int tile) {
+        if (rec) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            hipEventRecord(e, st);
+            rec->push_back(e);
+            info->push_back({flops, bytes, tile});
+        }
+    };
+    int li = 0;
+    auto conv = [&](const float* in, int hh, int ww, int act, const float* res, float* out, int tsm, int* oh, int* ow,
+                    int ldo) -> int {
+        const ConvLayer& L = net->convs[li];
+        adaf_conv_params p;
+        memset(&p, 0, sizeof(p));
+        p.n = n; p.h = hh; p.w = ww; p.cin = L.cin_pad; p.cout = L.cout; p.kh = p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
+        p.act = act; p.tsm_segments = tsm ? tsm_T : 0; p.tsm_div = tsm_div; p.ldo = ldo; p.tile = net->tiles[li];
+        ConvArgs a;
+        int rc = make_conv_args(h, &p, in, L.w, L.scale, L.bias, res, out, &a);
+        if (rc) return rc;
+        const int tile = p.tile ? p.tile : adaf_pick_conv_tile(a.M, a.N, a.K, h->cus);
+        const double macs = (double)a.M * L.cout * L.k * L.k * L.cin;   // algorithmic: un-padded cin
+        const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
+        mark(2.0 * macs, bytes, tile);
+        adaf_launch_conv_gemm(a, tile, h->cus, st);
+        *oh = a.OH; *ow = a.OW;
+        ++li;
+        return ADAF_OK;
+    };
+
+    int hh, ww, rc;
+    // stem: conv7x7 s2 + BN + ReLU -> maxpool 3x3 s2
+    if ((rc = conv(x4, P, P, ADAF_ACT_RELU, nullptr, buf[0], 0, &hh, &ww, 0))) return rc;
+    const int ph = conv_out(hh, 3, 2, 1), pw = conv_out(ww, 3, 2, 1);
+    mark(0.0, 4.0 * ((double)n * hh * ww * 64 + (double)n * ph * pw * 64), 0);
+    adaf_launch_maxpool(buf[0], n, hh, ww, 64, buf[1], st);
+    hh = ph; ww = pw;
+    float* cur = buf[1];
+    float* nxt = buf[0];
+    for (int s = 0; s < 4; ++s) {
+        for (int b = 0; b < kStageBlocks[s]; ++b) {
+            int h1, w1, h2, w2, h3, w3;
+            // conv1 (1x1, optional fused temporal shift) -> conv2 (3x3, stride) -> conv3 (1x1) + identity
+            if ((rc = conv(cur, hh, ww, ADAF_ACT_RELU, nullptr, buf[2], tsm_T > 0, &h1, &w1, 0))) return rc;
+            if ((rc = conv(buf[2], h1, w1, ADAF_ACT_RELU, nullptr, buf[3], 0, &h2, &w2, 0))) return rc;
+            const float* identity = cur;
+            if (b == 0) {
+                // launch order: conv3's layer index precedes the downsample's in `convs`
+                const int keep = li;
+                li = keep + 1;
+                int hd, wd;
+                if ((rc = conv(cur, hh, ww, ADAF_ACT_NONE, nullptr, buf[4], 0, &hd, &wd, 0))) return rc;
+                li = keep;
+                identity = buf[4];
+            }
+            if ((rc = conv(buf[3], h2, w2, ADAF_ACT_RELU, identity, nxt, 0, &h3, &w3, 0))) return rc;
+            if (b == 0) ++li;  // skip the downsample slot
+            hh = h3; ww = w3;
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    mark(0.0, 4.0 * ((double)n * hh * ww * 2048 + (double)n * 2048), 0);
+    adaf_launch_avgpool(cur, n, hh * ww, 2048, feat, ldfeat, st);
+    if (rec) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        hipEventRecord(e, st);
+        rec->push_back(e);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "resnet50 forward");
+}
+
+}  // namespace
+
+extern "C" {
+
+int adaf_resnet50_create(adaf_handle* h, adaf_resnet50** out) {
+    if (!h || !out) return ADAF_E_BADARG;
+    adaf_resnet50* net = new adaf_resnet50();
+    net->h = h;
+    build_layers(net);
+    *out = net;
+    return ADAF_OK;
+}
+
+int adaf_resnet50_destroy(adaf_resnet50* net) {
+    if (!net) return ADAF_OK;
+    for (auto& L : net->convs) {
+        if (L.w) hipFree(L.w);
+        if (L.scale) hipFree(L.scale);
+        if (L.bias) hipFree(L.bias);
+    }
+    delete net;
+    return ADAF_OK;
+}
+
+int adaf_resnet50_set_param(adaf_resnet50* net, const char* name, const float* dev_ptr, size_t numel) {
+    if (!net || !name || !dev_ptr) return ADAF_E_BADARG;
+    net->params[name] = std::make_pair(dev_ptr, numel);
+    net->finalized = false;
+    return ADAF_OK;
+}
+
+int adaf_resnet50_finalize(adaf_resnet50* net, void* stream) {
+    if (!net) return ADAF_E_BADARG;
+    adaf_handle* h = net->h;
+    hipStream_t st = (hipStream_t)stream;
+    auto get = [&](const std::string& key, size_t numel, const float** p) -> int {
+        auto it = net->params.find(key);
+        if (it == net->params.end()) return fail(h, ADAF_E_STATE, "resnet50: missing parameter '%s'", key.c_str());
+        if (it->second.second != numel)
+            return fail(h, ADAF_E_BADARG, "resnet50: '%s' has %zu elements, expected %zu", key.c_str(), it->second.second, numel);
+        *p = it->second.first;
+        return ADAF_OK;
+    };
+    for (auto& L : net->convs) {
+        const float *w, *g, *b, *m, *v;
+        int rc;
+        if ((rc = get(L.name + ".weight", (size_t)L.cout * L.cin * L.k * L.k, &w))) return rc;
+        if ((rc = get(L.bn + ".weight", L.cout, &g))) return rc;
+        if ((rc = get(L.bn + ".bias", L.cout, &b))) return rc;
+        if ((rc = get(L.bn + ".running_mean", L.cout, &m))) return rc;
+        if ((rc = get(L.bn + ".running_var", L.cout, &v))) return rc;
+        const size_t wn = (size_t)L.cout * L.k * L.k * L.cin_pad;
+        if (!L.w && hipMalloc(reinterpret_cast<void**>(&L.w), wn * sizeof(float)) != hipSuccess) return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc weights");
+        if (!L.scale && hipMalloc(reinterpret_cast<void**>(&L.scale), L.cout * sizeof(float)) != hipSuccess) return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc scale");
+        if (!L.bias && hipMalloc(reinterpret_cast<void**>(&L.bias), L.cout * sizeof(float)) != hipSuccess) return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc bias");
+        adaf_launch_pack_weight(w, L.cout, L.cin, L.k, L.k, L.cin_pad, L.w, st);
+        adaf_launch_fold_bn(g, b, m, v, 1e-5f, L.cout, L.scale, L.bias, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(h, e, "resnet50 finalize");
+    net->finalized = true;
+    return ADAF_OK;
+}
+
+size_t adaf_resnet50_workspace_bytes(const adaf_resnet50* net, int n, int patch) {
+    (void)net;
+    if (n <= 0 || patch <= 0) return 0;
+    // five slabs (block input, block output, two bottleneck temporaries, downsample branch), each as
+    // large as the biggest activation: the stem output or the first stage's 256-channel map
+    const int s1 = conv_out(patch, 7, 2, 3), s2 = conv_out(s1, 3, 2, 1);
+    const size_t a = (size_t)s1 * s1 * 64, b = (size_t)s2 * s2 * 256;
+    return (size_t)5 * n * (a > b ? a : b) * sizeof(float);
+}
+
+int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
+                          int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream) {
+    if (!net) return ADAF_E_BADARG;
+    return run_trunk(net, patches_nhwc4, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream,
+                     nullptr, nullptr);
+}
+
+int adaf_resnet50_launch_count(const adaf_resnet50* net) { return net ? (int)net->convs.size() + 2 : 0; }
+
+int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
+                                   int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream,
+                                   float* launch_ms, double* launch_flops, double* launch_bytes, int* launch_tile) {
+    if (!net || !launch_ms || !launch_flops || !launch_bytes || !launch_tile) return ADAF_E_BADARG;
+    std::vector<hipEvent_t> ev;
+    std::vector<Launch> info;
+    int rc = run_trunk(net, patches_nhwc4, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream,
+                       &ev, &info);
+    if (rc == ADAF_OK) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) rc = hip_fail(net->h, e, "resnet50 profiled forward");
+    }
+    if (rc == ADAF_OK && ev.size() == info.size() + 1) {
+        for (size_t i = 0; i < info.size(); ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            launch_ms[i] = ms;
+            launch_flops[i] = info[i].flops;
+            launch_bytes[i] = info[i].bytes;
+            launch_tile[i] = info[i].tile;
+        }
+    }
+    for (auto e : ev) hipEventDestroy(e);
+    return rc;
+}
+
+int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
+    if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
+    for (int i = 0; i < count; ++i) {
+        if (tile[i] < 0 || tile[i] > ADAF_CONV_TILES) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        net->tiles[i] = tile[i];
+    }
+    return ADAF_OK;
+}
+
+// ======================================================================================
+// GRU classifier / linear + temporal mean
+// ======================================================================================
+size_t adaf_gru_cls_workspace_bytes(int batch, int steps, int hidden) {
+    if (batch <= 0 || steps <= 0 || hidden <= 0) return 0;
+    // gi [B*T, 3H] + gh [B, 3H] + hidden states [B, T, H]
+    return ((size_t)batch * steps * 3 * hidden + (size_t)batch * 3 * hidden + (size_t)batch * steps * hidden) * sizeof(float);
+}
+
+static int linear_launch(adaf_handle* h, const float* x, int rows, int ldx, int in, int out_dim, const float* w,
+                         const float* bias, float* out, int ldo, hipStream_t st) {
+    adaf_conv_params p;
+    memset(&p, 0, sizeof(p));
+    p.n = rows; p.h = 1; p.w = 1; p.cin = in; p.cout = out_dim; p.kh = p.kw = 1; p.stride = 1; p.pad = 0;
+    p.act = ADAF_ACT_NONE; p.ldx = ldx; p.ldo = ldo;
+    ConvArgs a;
+    int rc = make_conv_args(h, &p, x, w, nullptr, bias, nullptr, out, &a);
+    if (rc) return rc;
+    adaf_launch_conv_gemm(a, 0, h->cus, st);
+    return ADAF_OK;
+}
+
+int adaf_gru_cls_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
+                             int classes, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                             const float* fc_w, const float* fc_b, float* logits_all, float* last, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (batch == 0) return ADAF_OK;
+    if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !fc_w || !fc_b || !logits_all || !last || !ws)
+        return fail(h, ADAF_E_BADARG, "gru_cls: null pointer");
+    if (batch < 0 || steps <= 0 || feat <= 0 || hidden <= 0 || classes <= 0) return fail(h, ADAF_E_BADARG, "gru_cls: non-positive extent");
+    if (ldx == 0) ldx = feat;
+    if (feat % 4 || hidden % 4 || ldx % 4) return fail(h, ADAF_E_LAYOUT, "gru_cls: feat, hidden, ldx must be multiples of 4");
+    if (ws_bytes < adaf_gru_cls_workspace_bytes(batch, steps, hidden)) return fail(h, ADAF_E_NOMEM, "gru_cls: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* gi = static_cast<float*>(ws);
+    float* gh = gi + (size_t)batch * steps * 3 * hidden;
+    float* hs = gh + (size_t)batch * 3 * hidden;  // [B, T, H]
+    int rc;
+    // all input projections at once: gi[b*T+t, :] = W_ih x[b,t] + b_ih
+    if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
+    for (int t = 0; t < steps; ++t) {
+        const float* hprev = t ? hs + (size_t)(t - 1) * hidden : nullptr;
+        if (t) {  // gh = W_hh h_{t-1}; rows are strided views into hs
+            if ((rc = linear_launch(h, hprev, batch, steps * hidden, hidden, 3 * hidden, w_hh, nullptr, gh, 0, st))) return rc;
+        }
+        adaf_launch_gru_gates(gi + (size_t)t * 3 * hidden, steps * 3 * hidden, t ? gh : nullptr, b_hh, hprev, steps * hidden,
+                              hs + (size_t)t * hidden, steps * hidden, batch, hidden, st);
+    }
+    // logits for every step, then the last step's rows
+    if ((rc = linear_launch(h, hs, batch * steps, hidden, hidden, classes, fc_w, fc_b, logits_all, 0, st))) return rc;
+    adaf_launch_copy2d(logits_all + (size_t)(steps - 1) * classes, steps * classes, last, classes, batch, classes, st);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "gru_cls forward");
+}
+
+int adaf_fc_meanpool_forward_f32(adaf_handle* h, const float* feat, int batch, int steps, int feat_dim, int classes,
+                                 const float* fc_w, const float* fc_b, const float* global_logit, int global_steps,
+                                 float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (batch == 0) return ADAF_OK;
+    if (!feat || !fc_w || !fc_b || !out || !ws) return fail(h, ADAF_E_BADARG, "fc_meanpool: null pointer");
+    if (batch < 0 || steps <= 0 || feat_dim <= 0 || classes <= 0 || (global_logit && global_steps <= 0))
+        return fail(h, ADAF_E_BADARG, "fc_meanpool: non-positive extent");
+    if (feat_dim % 4) return fail(h, ADAF_E_LAYOUT, "fc_meanpool: feat_dim %% 4");
+    if (ws_bytes < (size_t)batch * steps * classes * sizeof(float)) return fail(h, ADAF_E_NOMEM, "fc_meanpool: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* logit = static_cast<float*>(ws);
+    int rc = linear_launch(h, feat, batch * steps, feat_dim, feat_dim, classes, fc_w, fc_b, logit, 0, st);
+    if (rc) return rc;
+    adaf_launch_segment_mean(logit, batch, steps, classes, global_logit, global_steps, out, st);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "fc_meanpool forward");
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+// Implicit-GEMM convolution + folded-BN + residual + activation on the gfx950 fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32).  One kernel family serves every dense contraction on the
+// AdaFocus hot path: the ResNet-50 1x1 / 3x3 / strided convs (ACT/models/resnet.py:94-114),
+// the 7x7 stem (cin padded 3 -> 4), the GRU input/recurrent projections and the classifiers.
+//
+// GEMM view:  out[M = n*OH*OW pixels, N = cout] = A[M, K = kh*kw*cin] * W[N, K]^T
+//   A is never materialised: each 16-byte operand chunk is gathered straight from the NHWC
+//   activation tensor (zero for padding / clip-boundary TSM rows), staged in LDS and consumed
+//   as MFMA fragments.  Activations are pixel-major, so an output row's `cout` values are
+//   contiguous and the MFMA C layout (col = lane & 31) stores 128-byte segments.
+//
+// Block = 256 threads = 4 waves (64 lanes).  K is walked in BK = 32 slices, double-buffered
+// in LDS (row pitch 36 floats: conflict-free for the 16-lane ds_read_b128 groups and for the
+// 8-lane ds_write_b128 groups), with the next slice's global loads in flight while the current
+// one is multiplied.  A lane's ds_read_b128 brings four k-values for its row; MFMA sub-step s
+// consumes element s, so lanes 0-31 cover k = 8kk+s and lanes 32-63 cover k = 8kk+4+s -- the
+// same permutation on A and W, hence an exact (re-ordered) fp32 fma chain.
+#include "adaf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct defeats SROA)
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDP = 36;  // LDS row pitch in floats
+
+template <int BM, int BN, int WGM, int WGN, bool DENSE>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int STAGE = (BM + BN) * LDP;
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware, bijective block remap: hardware places block b on XCD b % 8; give every XCD a
+    // contiguous range of tiles so the blocks that share an A row-panel hit the same L2.
+    int bid = blockIdx.x;
+    {
+        const int q = a.nblocks >> 3, r = a.nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / a.tiles_n;
+    const int tile_n = bid - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int lrow = tid >> 3;  // 0..31: row inside a 32-row pass
+    const int lq = tid & 7;     // which float4 of the 32-wide k slice
+
+    // ---- per-thread row bookkeeping for the operand gather --------------------------------
+    bool a_ok[AP];
+    size_t a_off[AP];   // DENSE: row offset in floats
+    int a_pix[AP];      // generic: image base pixel; DENSE+TSM: bit0 = has previous frame, bit1 = has next frame
+    int a_iy[AP], a_ix[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int m = m0 + lrow + 32 * p;
+        a_ok[p] = m < a.M;
+        const int mm = a_ok[p] ? m : 0;
+        if (DENSE) {
+            a_off[p] = (size_t)mm * a.ldx;
+            a_pix[p] = 3;
+            if (a.tsm_T > 0) {
+                const int t = (mm / a.tsm_hw) % a.tsm_T;
+                a_pix[p] = (t > 0 ? 1 : 0) | (t < a.tsm_T - 1 ? 2 : 0);
+            }
+            a_iy[p] = a_ix[p] = 0;
+        } else {
+            const int ohw = a.OH * a.OW;
+            const int img = mm / ohw;
+            const int rem = mm - img * ohw;
+            const int oy = rem / a.OW;
+            const int ox = rem - oy * a.OW;
+            a_pix[p] = img * a.H * a.W;
+            a_iy[p] = oy * a.stride - a.pad;
+            a_ix[p] = ox * a.stride - a.pad;
+            a_off[p] = 0;
+        }
+    }
+    const float* wrow[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+        const int n = n0 + lrow + 32 * p;
+        b_ok[p] = n < a.N;
+        wrow[p] = a.w + (size_t)(b_ok[p] ? n : 0) * a.K;
+    }
+    const size_t tsm_stride = (size_t)a.tsm_hw * a.ldx;
+
+    f32x4 ra[AP], rb[BP];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](int kt) {
+        const int kidx = kt * BK + lq * 4;
+        const bool k_ok = kidx < a.K;
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+        {
+            const bool ok = b_ok[p] && k_ok;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? wrow[p] + kidx : a.w);
+            rb[p] = ok ? v : zero4;
+        }
+        if (DENSE) {
+            int need = 0;           // which neighbour frame this channel chunk reads (TSM)
+            long long shift = 0;
+            if (a.tsm_T > 0) {
+                if (kidx < a.tsm_fold) { need = 2; shift = (long long)tsm_stride; }
+                else if (kidx < 2 * a.tsm_fold) { need = 1; shift = -(long long)tsm_stride; }
+            }
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                const bool ok = a_ok[p] && k_ok && (need == 0 || (a_pix[p] & need));
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? a.x + (long long)a_off[p] + shift + kidx : a.x);
+                ra[p] = ok ? v : zero4;
+            }
+        } else {
+            const int tap = kidx / a.cin;
+            const int c = kidx - tap * a.cin;
+            const int kh = tap / a.KW;
+            const int kw = tap - kh * a.KW;
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                const int iy = a_iy[p] + kh, ix = a_ix[p] + kw;
+                const bool ok = a_ok[p] && k_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const size_t off = (size_t)(a_pix[p] + iy * a.W + ix) * a.ldx + c;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? a.x + off : a.x);
+                ra[p] = ok ? v : zero4;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + BM * LDP;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDP + lq * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDP + lq * 4]) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (a.K + BK - 1) / BK;
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const float* As = smem + (kt & 1) * STAGE + (wm * TM * 32 + frag_row) * LDP + frag_k;
+        const float* Bs = smem + (kt & 1) * STAGE + BM * LDP + (wn * TN * 32 + frag_row) * LDP + frag_k;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDP + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDP + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: BN affine, residual, activation; C layout col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
+    const int crow = 4 * (lane >> 5);
+    const bool has_res = a.res != nullptr;
+    const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool n_ok = n < a.N;
+        const int nn = n_ok ? n : 0;
+        const float sc = a.scale ? a.scale[nn] : 1.f;
+        const float bi = a.bias ? a.bias[nn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + crow;
+            float rv[16];
+            if (has_res) {  // issue all residual loads of the tile before the first use
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    const bool ok = n_ok && m < a.M;
+                    rv[r] = a.res[ok ? (size_t)m * a.ldr + n : 0];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const float v = fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi);
+                if (n_ok && m < a.M) a.out[(size_t)m * a.ldo + n] = v;
+            }
+        }
+    }
+}
+
+// One thread per output element: the plain statement of the same contract.
+__global__ void conv_naive_kernel(const ConvArgs a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)a.M * a.N) return;
+    const int m = (int)(idx / a.N), n = (int)(idx - (long long)m * a.N);
+    const int ohw = a.OH * a.OW;
+    const int img = m / ohw, rem = m - img * ohw, oy = rem / a.OW, ox = rem - oy * a.OW;
+    float s = 0.f;
+    for (int kh = 0; kh < a.KH; ++kh)
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int iy = oy * a.stride - a.pad + kh, ix = ox * a.stride - a.pad + kw;
+            if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
+            const int pix = img * a.H * a.W + iy * a.W + ix;
+            const float* wr = a.w + (size_t)n * a.K + (kh * a.KW + kw) * a.cin;
+            for (int c = 0; c < a.cin; ++c) {
+                int src = pix;
+                bool ok = true;
+                if (a.tsm_T > 0) {
+                    const int t = (pix / a.tsm_hw) % a.tsm_T;
+                    if (c < a.tsm_fold) { ok = t < a.tsm_T - 1; src = pix + a.tsm_hw; }
+                    else if (c < 2 * a.tsm_fold) { ok = t > 0; src = pix - a.tsm_hw; }
+                }
+                if (ok) s = fmaf(a.x[(size_t)src * a.ldx + c], wr[c], s);
+            }
+        }
+    float v = fmaf(s, a.scale ? a.scale[n] : 1.f, a.bias ? a.bias[n] : 0.f);
+    if (a.res) v += a.res[(size_t)m * a.ldr + n];
+    if (a.act == ADAF_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (a.act == ADAF_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    a.out[(size_t)m * a.ldo + n] = v;
+}
+
+struct TileShape { int bm, bn; float eff; };
+// eff: relative MFMA efficiency of the main loop (bigger tiles amortise staging better);
+// refined from profiles/ measurements.
+const TileShape kTiles[ADAF_CONV_TILES + 1] = {
+    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 0.93f}, {64, 64, 0.82f}, {64, 128, 0.90f}};
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if (dense)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+int adaf_pick_conv_tile(int M, int N, int K, int cus) {
+    (void)K;
+    int best = 1;
+    double best_t = 1e300;
+    for (int t = 1; t <= ADAF_CONV_TILES; ++t) {
+        const long long blocks = (long long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn);
+        const long long rounds = (blocks + cus - 1) / cus;
+        const double cost = (double)rounds * kTiles[t].bm * kTiles[t].bn / kTiles[t].eff;
+        if (cost < best_t * 0.999) { best_t = cost; best = t; }
+    }
+    return best;
+}
+
+int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
+    if (tile <= 0 || tile > ADAF_CONV_TILES) tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
+    const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    switch (tile) {
+        case 1: launch_cfg<128, 128, 2, 2>(a, dense, s); break;
+        case 2: launch_cfg<128, 64, 2, 2>(a, dense, s); break;
+        case 3: launch_cfg<64, 64, 2, 2>(a, dense, s); break;
+        case 4: launch_cfg<64, 128, 2, 2>(a, dense, s); break;
+        default: return -1;
+    }
+    return tile;
+}
+
+void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s) {
+    const long long total = (long long)a.M * a.N;
+    hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}

@@ -1,0 +1,195 @@
+// Bandwidth-bound companions of the conv engine: weight packing, BN folding, pooling,
+// the stand-alone temporal shift, the GRU gate math and small glue copies.  All NHWC fp32,
+// 16-byte accesses wherever the channel count allows.
+#include "adaf_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+// OIHW -> OHWI (+ zero pad of the I axis): w_ohwi[((o*KH+kh)*KW+kw)*cin_pad + i]
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw, int cin_pad,
+                                   float* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)cout * kh * kw * cin_pad;
+    if (idx >= total) return;
+    const int i = (int)(idx % cin_pad);
+    long long t = idx / cin_pad;
+    const int x = (int)(t % kw);
+    t /= kw;
+    const int y = (int)(t % kh);
+    const int oc = (int)(t / kh);
+    o[idx] = i < cin ? w[(((long long)oc * cin + i) * kh + y) * kw + x] : 0.f;
+}
+
+// scale = gamma / sqrt(var + eps); bias = beta - mean * scale  (eval-mode BatchNorm)
+__global__ void fold_bn_kernel(const float* g, const float* b, const float* m, const float* v, float eps, int c,
+                               float* scale, float* bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float s = g[i] / sqrtf(v[i] + eps);
+    scale[i] = s;
+    bias[i] = b[i] - m[i] * s;
+}
+
+// MaxPool2d(3, stride 2, pad 1), NHWC, 4 channels per thread; padding never wins (PyTorch pads
+// with -inf), matching ACT/models/resnet.py:141.
+__global__ void maxpool_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow,
+                               float* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)n * oh * ow * c4;
+    if (idx >= total) return;
+    const int cq = (int)(idx % c4);
+    long long t = idx / c4;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int img = (int)(t / oh);
+    const float ninf = -__builtin_inff();
+    f32x4 best = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - 1 + ky;
+        if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if ((unsigned)ix >= (unsigned)w) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + iy) * w + ix) * (size_t)(4 * c4) + 4 * cq);
+            best.x = fmaxf(best.x, v.x);
+            best.y = fmaxf(best.y, v.y);
+            best.z = fmaxf(best.z, v.z);
+            best.w = fmaxf(best.w, v.w);
+        }
+    }
+    *reinterpret_cast<f32x4*>(o + (size_t)idx * 4) = best;
+}
+
+// AdaptiveAvgPool2d(1): mean over hw pixels, NHWC, 4 channels per thread.
+__global__ void avgpool_kernel(const float* __restrict__ x, int n, int hw, int c4, float* __restrict__ o, int ldo) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c4) return;
+    const int cq = idx % c4, img = idx / c4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* p = x + (size_t)img * hw * (4 * c4) + 4 * cq;
+    for (int i = 0; i < hw; ++i) s += *reinterpret_cast<const f32x4*>(p + (size_t)i * (4 * c4));
+    const float inv = (float)hw;
+    f32x4 r = {s.x / inv, s.y / inv, s.z / inv, s.w / inv};
+    *reinterpret_cast<f32x4*>(o + (size_t)img * ldo + 4 * cq) = r;
+}
+
+// TemporalShift.shift -- STH/ops/temporal_shift.py:28-46.  One thread per element.
+__global__ void tshift_kernel(const float* __restrict__ x, long long total, int c, int hw, int T, int fold, int nhwc,
+                              float* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long frame_elems = (long long)c * hw;
+    const long long f = idx / frame_elems;
+    const int within = (int)(idx - f * frame_elems);
+    const int ch = nhwc ? within % c : within / hw;
+    const int t = (int)(f % T);
+    float v;
+    if (ch < fold) v = (t < T - 1) ? x[idx + frame_elems] : 0.f;          // from t+1
+    else if (ch < 2 * fold) v = (t > 0) ? x[idx - frame_elems] : 0.f;     // from t-1
+    else v = x[idx];
+    o[idx] = v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// One GRU step's gate math (PyTorch order r,z,n):  gi = W_ih x_t + b_ih (precomputed for all t),
+// gh = W_hh h_{t-1} (without bias; null at t = 0 where h = 0), bhh = b_hh.
+//   r = s(gi_r + gh_r + bhh_r); z = s(gi_z + gh_z + bhh_z); n = tanh(gi_n + r*(gh_n + bhh_n)); h' = (1-z)n + z h
+__global__ void gru_gates_kernel(const float* __restrict__ gi, int ldgi, const float* __restrict__ gh,
+                                 const float* __restrict__ bhh, const float* __restrict__ hprev, int ldh,
+                                 float* __restrict__ hout, int ldo, int B, int Hd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Hd) return;
+    const int b = idx / Hd, j = idx - b * Hd;
+    const float* gir = gi + (size_t)b * ldgi;
+    float hr = bhh[j], hz = bhh[Hd + j], hn = bhh[2 * Hd + j];
+    float hp = 0.f;
+    if (gh) {
+        const float* ghr = gh + (size_t)b * 3 * Hd;
+        hr += ghr[j];
+        hz += ghr[Hd + j];
+        hn += ghr[2 * Hd + j];
+        hp = hprev[(size_t)b * ldh + j];
+    }
+    const float r = sigmoidf_(gir[j] + hr);
+    const float z = sigmoidf_(gir[Hd + j] + hz);
+    const float nn = tanhf(gir[2 * Hd + j] + r * hn);
+    hout[(size_t)b * ldo + j] = (1.f - z) * nn + z * hp;
+}
+
+// out[b,c] = mean_t logit[b,t,c] (+ mean_t glog[b,t,c])  -- ConsensusModule('avg'), STH/ops/basic_ops.py:17-26
+__global__ void segment_mean_kernel(const float* __restrict__ logit, int B, int T, int C,
+                                    const float* __restrict__ glog, int Tg, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += logit[((size_t)b * T + t) * C + c];
+    float r = s / (float)T;
+    if (glog) {
+        float g = 0.f;
+        for (int t = 0; t < Tg; ++t) g += glog[((size_t)b * Tg + t) * C + c];
+        r = g / (float)Tg + r;
+    }
+    out[idx] = r;
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,
+                              int cols) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * cols) return;
+    const int r = (int)(idx / cols), c = (int)(idx - (long long)r * cols);
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
+}
+
+}  // namespace
+
+void adaf_launch_pack_weight(const float* w, int cout, int cin, int kh, int kw, int cin_pad, float* o, hipStream_t s) {
+    const long long total = (long long)cout * kh * kw * cin_pad;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks_for(total)), dim3(256), 0, s, w, cout, cin, kh, kw, cin_pad, o);
+}
+
+void adaf_launch_fold_bn(const float* g, const float* b, const float* m, const float* v, float eps, int c,
+                         float* scale, float* bias, hipStream_t s) {
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(blocks_for(c)), dim3(256), 0, s, g, b, m, v, eps, c, scale, bias);
+}
+
+void adaf_launch_maxpool(const float* x, int n, int h, int w, int c, float* o, hipStream_t s) {
+    const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * oh * ow * (c / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, o);
+}
+
+void adaf_launch_avgpool(const float* x, int n, int hw, int c, float* o, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3(blocks_for((long long)n * (c / 4))), dim3(256), 0, s, x, n, hw, c / 4, o, ldo);
+}
+
+void adaf_launch_tshift(const float* x, int nt, int c, int hw, int T, int div, int layout, float* o, hipStream_t s) {
+    const long long total = (long long)nt * c * hw;
+    hipLaunchKernelGGL(tshift_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, total, c, hw, T, c / div,
+                       layout == ADAF_LAYOUT_NHWC ? 1 : 0, o);
+}
+
+void adaf_launch_gru_gates(const float* gi, int ldgi, const float* gh, const float* bhh, const float* hprev, int ldh,
+                           float* hout, int ldo, int B, int Hd, hipStream_t s) {
+    hipLaunchKernelGGL(gru_gates_kernel, dim3(blocks_for((long long)B * Hd)), dim3(256), 0, s, gi, ldgi, gh, bhh, hprev,
+                       ldh, hout, ldo, B, Hd);
+}
+
+void adaf_launch_segment_mean(const float* logit, int B, int T, int C, const float* glog, int Tg, float* out,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(segment_mean_kernel, dim3(blocks_for((long long)B * C)), dim3(256), 0, s, logit, B, T, C, glog, Tg,
+                       out);
+}
+
+void adaf_launch_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for((long long)rows * cols)), dim3(256), 0, s, src, lds, dst, ldd, rows,
+                       cols);
+}

@@ -1,0 +1,257 @@
+"""ActivityNet / FCVID / Mini-Kinetics model composition -- host-side mirror of
+ACT/models/gfv_net.py for offline inference (`evaluate=true`, stage-3 branch of
+ACT/main_dist.py:367-371).
+
+Same class names, constructor arguments (`args` fields of ACT/conf/default.yaml), attributes
+(``glancer``, ``focuser``, ``focuser.net``, ``focuser.policy.policy/policy_old``, ``classifier``) and
+state-dict keys as the reference, so its checkpoints load unchanged.  What differs is the
+execution plan of ``GFV.forward(one_step=True)`` (gfv_net.py:95-133):
+
+  reference: for t in range(T): policy step -> python-loop crop (4 .item() syncs per sample) ->
+             ResNet-50 on B patches -> cat;  then GRU
+  here:      policy over all T (its input never depends on local features in eval mode) ->
+             ONE batched HIP gather of B*T patches (NHWC4) -> ONE ResNet-50 trunk pass over B*T
+             patches whose avgpool writes straight into the GRU input matrix -> HIP GRU + FC
+
+which reproduces the reference logits.  Training branches (stage 0-2 forward
+modes, reward baselines, PPO update) are out of scope and raise.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import hip_ops
+from .mobilenet import mobilenet_v2
+from .ppo import PPO, Memory
+from .resnet import resnet50
+from .synth import grid_table
+from .utils import get_patch, get_patch_nhwc4
+
+__all__ = ["GFV", "Glancer", "Focuser", "PatchSampler", "RecurrentClassifier", "LinearCLassifier"]
+
+
+class GFV(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.num_segments = args.num_segments
+        self.num_class = args.num_classes
+        self.rew = getattr(args, "reward", "random")
+        if getattr(args, "dataset", None) == "fcvid":
+            assert args.num_classes == 239
+        self.input_size = args.input_size
+        self.batch_size = args.batch_size
+        self.patch_size = args.patch_size
+        self.input_mean = [0.485, 0.456, 0.406]
+        self.input_std = [0.229, 0.224, 0.225]
+        self.with_glancer = args.with_glancer
+        self.glancer = Glancer(num_classes=self.num_class)
+        cells = math.ceil(args.glance_size / 32)
+        policy_params = dict(feature_dim=args.feature_map_channels, state_dim=args.feature_map_channels * cells * cells,
+                             action_dim=args.action_dim, hidden_state_dim=args.hidden_state_dim,
+                             policy_conv=args.policy_conv, gpu=args.gpu, continuous=getattr(args, "continuous", False),
+                             gamma=getattr(args, "gamma", 0.7), policy_lr=getattr(args, "policy_lr", 0.0003))
+        self.focuser = Focuser(args.patch_size, args.random_patch, policy_params, self.num_class)
+        self.dropout = nn.Dropout(p=args.dropout)
+        feat_dim = self.focuser.feature_dim + (self.glancer.feature_dim if self.with_glancer else 0)
+        if args.consensus == "gru":
+            self.classifier = RecurrentClassifier(seq_len=args.num_segments, input_dim=feat_dim,
+                                                  batch_size=self.batch_size, hidden_dim=args.hidden_dim,
+                                                  num_classes=args.num_classes, dropout=args.dropout)
+        elif args.consensus == "fc":
+            self.classifier = LinearCLassifier(seq_len=args.num_segments, input_dim=feat_dim,
+                                               batch_size=self.batch_size, hidden_dim=args.hidden_dim,
+                                               num_classes=args.num_classes, dropout=args.dropout)
+        else:
+            raise ValueError("consensus must be 'gru' or 'fc'")
+
+    # ---- reference surface --------------------------------------------------------------
+    def forward(self, *argv, **kwargs):
+        if kwargs.get("backbone_pred"):
+            x = kwargs["input"]
+            b, tc, hh, ww = x.shape
+            x2 = x.view(b * (tc // 3), 3, hh, ww)
+            net = self.glancer if kwargs.get("glancer") else self.focuser
+            return net.predict(x2).view(b, tc // 3, -1)
+        if not kwargs.get("one_step"):
+            raise NotImplementedError("stage-1 training forward is out of scope (SURVEY.md §2 row 2)")
+        if kwargs.get("training"):
+            raise NotImplementedError("only training=False (offline inference) is implemented")
+        if self.focuser.random:
+            raise NotImplementedError("random_patch=True is the stage-1 training configuration")
+        return self.offline_forward(kwargs["input"], kwargs["scan"])[:2]
+
+    @torch.no_grad()
+    def offline_forward(self, images, scan, forced_action_idx=None):
+        """images, scan: (B, T*3, H, W) fp32 on the GPU.  Returns (logits (B*T,C), last (B,C),
+        action indices (B,T), feature matrix (B,T,F))."""
+        b, tc, hh, ww = images.shape
+        t = tc // 3
+        global_feat_map, global_feat = self.glance(scan)
+        idx = self.focuser.policy.policy_old.act_sequence(global_feat_map)
+        if forced_action_idx is not None:
+            idx = forced_action_idx.to(idx.device)
+        actions = self.focuser._get_standard_action(idx.reshape(-1))[0]
+        return self.hot_path(images.view(b * t, 3, hh, ww), global_feat if self.with_glancer else None, actions, b, t) \
+            + (idx,)
+
+    def hot_path(self, frames, global_feat, actions, b, t):
+        """Batched crop -> local CNN -> concat -> classifier: the benchmarked slice.
+        frames (B*T,3,H,W), global_feat (B,T,1280) or None, actions (B*T,2)."""
+        gdim = global_feat.shape[2] if global_feat is not None else 0
+        feature = torch.empty((b, t, gdim + self.focuser.feature_dim), device=frames.device, dtype=torch.float32)
+        flat = feature.view(b * t, -1)
+        patches = get_patch_nhwc4(frames, actions, self.patch_size)
+        self.focuser.net.features_nhwc4(patches, out=flat[:, gdim:])
+        if gdim:
+            hip_ops.copy2d(global_feat.reshape(b * t, gdim), flat[:, :gdim])
+        logits, last = self.classifier(feature)
+        return logits, last, feature
+
+    def glance(self, input_prime):
+        b, tc, hh, ww = input_prime.shape
+        t = tc // 3
+        fm, fv = self.glancer(input_prime.view(b * t, 3, hh, ww))
+        return fm.view(b, t, *fm.shape[1:]), fv.view(b, t, -1)
+
+    def one_step_act(self, *a, **k):
+        raise NotImplementedError("one_step_act is the stage-2 (PPO) training loop body: out of scope")
+
+    def train_mode(self, args):
+        raise NotImplementedError("training modes are out of scope; use .eval()")
+
+    @property
+    def scale_size(self):
+        return self.input_size * 256 // 224
+
+    @property
+    def crop_size(self):
+        return self.input_size
+
+
+class Glancer(nn.Module):
+    def __init__(self, skip=False, num_classes=200):
+        super().__init__()
+        self.net = mobilenet_v2(pretrained=False)
+        self.net.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(self.net.last_channel, num_classes))
+        self.skip = skip
+
+    def forward(self, input):
+        return self.net.get_featmap(input)
+
+    def predict(self, input):
+        return self.net(input)
+
+    @property
+    def feature_dim(self):
+        return self.net.feature_dim
+
+
+class Focuser(nn.Module):
+    def __init__(self, size=96, random=True, policy_params=None, num_classes=200):
+        super().__init__()
+        self.net = resnet50(pretrained=False)
+        self.net.fc = nn.Linear(self.net.fc.in_features, num_classes)
+        self.patch_size = size
+        self.random = random
+        self.patch_sampler = PatchSampler(self.patch_size, self.random)
+        self.policy = None
+        self.memory = Memory()
+        if not self.random:
+            assert policy_params is not None
+            # s x s grids of [row/(s-1), col/(s-1)], python doubles -> fp32 (gfv_net.py:272-307)
+            self._tables = {s * s: torch.from_numpy(grid_table(s)) for s in (5, 6, 7, 8)}
+            self.policy_feature_dim = policy_params["feature_dim"]
+            self.policy_state_dim = policy_params["state_dim"]
+            self.policy_action_dim = policy_params["action_dim"]
+            self.policy_hidden_state_dim = policy_params["hidden_state_dim"]
+            self.policy_conv = policy_params["policy_conv"]
+            self.gpu = policy_params["gpu"]
+            self.policy = PPO(self.policy_feature_dim, self.policy_state_dim, self.policy_action_dim,
+                              self.policy_hidden_state_dim, self.policy_conv, self.gpu, gamma=policy_params["gamma"],
+                              lr=policy_params["policy_lr"])
+
+    @property
+    def standard_actions_set(self):
+        return self._tables
+
+    def _get_standard_action(self, action):
+        table = self._tables[self.policy_action_dim]
+        if table.device != action.device:
+            table = table.to(action.device)
+            self._tables[self.policy_action_dim] = table
+        return table[action], None
+
+    def forward(self, *argv, **kwargs):
+        """One focuser step with the reference's contract (gfv_net.py:316-331): returns
+        (local feature (B,2048,1,1), (None, standard_action))."""
+        if self.random:
+            raise NotImplementedError("random patch sampling is a training-stage path")
+        action = self.policy.select_action(kwargs["state"], self.memory, kwargs["restart_batch"], kwargs["training"])
+        standard_action, _ = self._get_standard_action(action)
+        imgs = kwargs["input"]
+        feat = self.net.features_nhwc4(get_patch_nhwc4(imgs, standard_action, self.patch_size))
+        return feat.view(imgs.shape[0], -1, 1, 1), (None, standard_action)
+
+    def predict(self, input):
+        return self.net(input)
+
+    def update(self):
+        raise NotImplementedError("policy update is training code")
+
+    @property
+    def feature_dim(self):
+        return self.net.feature_dim
+
+
+class PatchSampler(nn.Module):
+    def __init__(self, size=96, random=True):
+        super().__init__()
+        self.random = random
+        self.size = size
+
+    def sample(self, imgs, action=None):
+        if self.random:
+            raise NotImplementedError("random cropping is a training-stage path")
+        assert action is not None
+        return get_patch(imgs, action, self.size)
+
+    def forward(self, *argv, **kwargs):
+        raise NotImplementedError
+
+
+class LinearCLassifier(nn.Module):
+    """softmax-mean classifier (gfv_net.py:388-407); FC on the HIP engine, softmax/mean in torch."""
+
+    def __init__(self, seq_len, input_dim, batch_size, hidden_dim, num_classes, dropout):
+        super().__init__()
+        self.seq_len, self.input_dim, self.hidden_dim, self.num_classes, self.batch_size = \
+            seq_len, input_dim, hidden_dim, num_classes, batch_size
+        self.fc = nn.Linear(input_dim, num_classes)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, feature):
+        b, t, _ = feature.shape
+        logits = hip_ops.linear(feature.reshape(b * t, -1), self.fc.weight.detach(), self.fc.bias.detach())
+        avg = torch.softmax(logits, dim=1).reshape(b, t, -1).mean(dim=1)
+        return torch.log(avg), avg
+
+
+class RecurrentClassifier(nn.Module):
+    """GRU + FC classifier (gfv_net.py:409-435).  ``self.gru`` / ``self.fc`` hold the parameters under
+    the reference's names; the arithmetic is adaf_gru_cls_forward_f32."""
+
+    def __init__(self, seq_len, input_dim, batch_size, hidden_dim, num_classes, dropout, bias=True):
+        super().__init__()
+        self.seq_len, self.input_dim, self.hidden_dim, self.num_classes, self.batch_size = \
+            seq_len, input_dim, hidden_dim, num_classes, batch_size
+        self.gru = nn.GRU(input_size=input_dim, hidden_size=hidden_dim, bias=bias, batch_first=True)
+        self.fc = nn.Linear(hidden_dim, num_classes)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, feature):
+        if self.training:
+            raise RuntimeError("RecurrentClassifier: eval mode only (dropout must be the identity)")
+        g = self.gru
+        return hip_ops.gru_cls_forward(feature, g.weight_ih_l0.detach(), g.weight_hh_l0.detach(), g.bias_ih_l0.detach(),
+                                       g.bias_hh_l0.detach(), self.fc.weight.detach(), self.fc.bias.detach())

@@ -1,0 +1,266 @@
+"""Tensor-level wrappers over the C ABI (include/adafocus.h).  Everything here enqueues
+hand-written gfx950 kernels on the current HIP stream; nothing falls back to ATen.
+
+Activation tensors are fp32 NHWC (``(N, H, W, C)`` contiguous) unless a function says otherwise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
+
+
+def _h(t):
+    return L.handle(t.device)
+
+
+def crop_gather(frames, actions, patch, frames_per_action=1, layout=LAYOUT_NCHW, return_coords=False):
+    """Batched get_patch (ACT/models/utils.py:37-51).  frames (N,C,H,W) fp32, actions (M,2) fp32 in
+    [0,1] with M*frames_per_action == N.  Returns (N,C,P,P) [NCHW], (N,P,P,C) [NHWC] or
+    (N,P,P,4) [NHWC4]; optionally also the int32 (M,2) window origins."""
+    L.need_gpu_f32(frames, actions)
+    if frames.dim() != 4 or actions.dim() != 2 or actions.shape[1] != 2:
+        raise ValueError("crop_gather: frames (N,C,H,W) and actions (M,2) expected")
+    frames = frames.contiguous()
+    actions = actions.contiguous()
+    n, c, hh, ww = frames.shape
+    p = int(patch)
+    if layout == LAYOUT_NCHW:
+        out = torch.empty((n, c, p, p), device=frames.device, dtype=torch.float32)
+    elif layout == LAYOUT_NHWC:
+        out = torch.empty((n, p, p, c), device=frames.device, dtype=torch.float32)
+    else:
+        out = torch.empty((n, p, p, 4), device=frames.device, dtype=torch.float32)
+    coords = torch.empty((actions.shape[0], 2), device=frames.device, dtype=torch.int32) if return_coords else None
+    h = _h(frames)
+    L.check(L.load_library().adaf_crop_gather_f32(h, L.ptr(frames), n, c, hh, ww, L.ptr(actions), actions.shape[0],
+                                                  int(frames_per_action), p, L.ptr(out), layout, L.ptr(coords),
+                                                  L.stream_ptr()), h)
+    return (out, coords) if return_coords else out
+
+
+def pack_conv_weight(w_oihw, cin_pad=None):
+    """OIHW -> OHWI (input channels zero-padded to a multiple of 4)."""
+    L.need_gpu_f32(w_oihw)
+    w = w_oihw.contiguous()
+    co, ci, kh, kw = w.shape
+    cp = cin_pad or ((ci + 3) // 4 * 4)
+    out = torch.empty((co, kh, kw, cp), device=w.device, dtype=torch.float32)
+    h = _h(w)
+    L.check(L.load_library().adaf_pack_conv_weight_f32(h, L.ptr(w), co, ci, kh, kw, cp, L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def fold_bn(gamma, beta, mean, var, eps=1e-5):
+    L.need_gpu_f32(gamma, beta, mean, var)
+    c = gamma.numel()
+    scale = torch.empty(c, device=gamma.device, dtype=torch.float32)
+    bias = torch.empty(c, device=gamma.device, dtype=torch.float32)
+    h = _h(gamma)
+    L.check(L.load_library().adaf_fold_bn_f32(h, L.ptr(gamma.contiguous()), L.ptr(beta.contiguous()),
+                                              L.ptr(mean.contiguous()), L.ptr(var.contiguous()), C.c_float(eps), c,
+                                              L.ptr(scale), L.ptr(bias), L.stream_ptr()), h)
+    return scale, bias
+
+
+def conv2d_bn_act(x, w_ohwi, scale=None, bias=None, residual=None, stride=1, pad=0, act=ACT_NONE, tsm_segments=0,
+                  tsm_div=8, tile=0, naive=False, out=None):
+    """x (N,H,W,Cin) NHWC, w (Cout,KH,KW,Cin) -> (N,OH,OW,Cout).  `naive=True` runs the
+    one-thread-per-output cross-check kernel instead of the MFMA engine (tests only)."""
+    L.need_gpu_f32(x, w_ohwi, scale, bias, residual)
+    x = x.contiguous()
+    w_ohwi = w_ohwi.contiguous()
+    n, hh, ww, cin = x.shape
+    cout, kh, kw, cin_w = w_ohwi.shape
+    if cin_w != cin:
+        raise ValueError("conv2d_bn_act: x has %d channels, weight expects %d" % (cin, cin_w))
+    oh = (hh + 2 * pad - kh) // stride + 1
+    ow = (ww + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n, oh, ow, cout), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = residual.contiguous()
+    p = L.ConvParams(n=n, h=hh, w=ww, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad=pad, act=act,
+                     tsm_segments=tsm_segments, tsm_div=tsm_div, ldx=0, ldo=0, ldr=0, tile=tile)
+    h = _h(x)
+    lib = L.load_library()
+    fn = lib.adaf_conv2d_naive_f32 if naive else lib.adaf_conv2d_bn_act_f32
+    L.check(fn(h, C.byref(p), L.ptr(x), L.ptr(w_ohwi), L.ptr(scale), L.ptr(bias), L.ptr(residual), L.ptr(out),
+               L.stream_ptr()), h)
+    return out
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, tile=0):
+    """nn.Linear on the MFMA engine: x (rows, in) row-major, weight (out, in)."""
+    rows, fin = x.shape
+    y = conv2d_bn_act(x.reshape(rows, 1, 1, fin), weight.reshape(weight.shape[0], 1, 1, fin), None, bias, act=act,
+                      tile=tile)
+    return y.reshape(rows, weight.shape[0])
+
+
+def maxpool3x3s2(x):
+    L.need_gpu_f32(x)
+    x = x.contiguous()
+    n, hh, ww, c = x.shape
+    out = torch.empty((n, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    h = _h(x)
+    L.check(L.load_library().adaf_maxpool3x3s2_f32(h, L.ptr(x), n, hh, ww, c, L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def global_avgpool(x):
+    L.need_gpu_f32(x)
+    x = x.contiguous()
+    n, hh, ww, c = x.shape
+    out = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    h = _h(x)
+    L.check(L.load_library().adaf_global_avgpool_f32(h, L.ptr(x), n, hh * ww, c, L.ptr(out), c, L.stream_ptr()), h)
+    return out
+
+
+def temporal_shift(x, n_segment, fold_div, layout=LAYOUT_NCHW):
+    """TemporalShift.shift (STH/ops/temporal_shift.py:28-46).  x (NT,C,H,W) [NCHW] or (NT,H,W,C)."""
+    L.need_gpu_f32(x)
+    x = x.contiguous()
+    if layout == LAYOUT_NCHW:
+        nt, c, hh, ww = x.shape
+    else:
+        nt, hh, ww, c = x.shape
+    out = torch.empty_like(x)
+    h = _h(x)
+    L.check(L.load_library().adaf_temporal_shift_f32(h, L.ptr(x), nt, c, hh * ww, int(n_segment), int(fold_div), layout,
+                                                     L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def gru_cls_forward(x, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b):
+    """RecurrentClassifier.forward (ACT/models/gfv_net.py:427-435).  x (B,T,F) (last dim may be a
+    strided view with stride 1) -> (logits (B*T,C), last (B,C))."""
+    L.need_gpu_f32(x, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b)
+    b, t, f = x.shape
+    if x.stride(2) != 1 or x.stride(0) != t * x.stride(1):
+        x = x.contiguous()
+    hid, ncls = w_hh.shape[1], fc_w.shape[0]
+    lib = L.load_library()
+    ws_bytes = lib.adaf_gru_cls_workspace_bytes(b, t, hid)
+    ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
+    logits = torch.empty((b * t, ncls), device=x.device, dtype=torch.float32)
+    last = torch.empty((b, ncls), device=x.device, dtype=torch.float32)
+    h = _h(x)
+    L.check(lib.adaf_gru_cls_forward_f32(h, L.ptr(x), x.stride(1), b, t, f, hid, ncls, L.ptr(w_ih.contiguous()),
+                                         L.ptr(w_hh.contiguous()), L.ptr(b_ih.contiguous()), L.ptr(b_hh.contiguous()),
+                                         L.ptr(fc_w.contiguous()), L.ptr(fc_b.contiguous()), L.ptr(logits), L.ptr(last),
+                                         L.ptr(ws), ws_bytes, L.stream_ptr()), h)
+    return logits, last
+
+
+def fc_meanpool_forward(feat, batch, fc_w, fc_b, global_logit=None):
+    """mean_t FC(f_t) (+ mean_t glancer logits) -- STH/models/gfv_net.py:164-174.
+    feat (B*T,F); global_logit (B,Tg,C) or None -> (B,C)."""
+    L.need_gpu_f32(feat, fc_w, fc_b, global_logit)
+    feat = feat.contiguous()
+    rows, f = feat.shape
+    t = rows // batch
+    ncls = fc_w.shape[0]
+    ws = torch.empty(max(rows * ncls, 1), device=feat.device, dtype=torch.float32)
+    out = torch.empty((batch, ncls), device=feat.device, dtype=torch.float32)
+    tg = 0
+    if global_logit is not None:
+        global_logit = global_logit.contiguous()
+        tg = global_logit.shape[1]
+    h = _h(feat)
+    L.check(L.load_library().adaf_fc_meanpool_forward_f32(h, L.ptr(feat), batch, t, f, ncls, L.ptr(fc_w.contiguous()),
+                                                          L.ptr(fc_b.contiguous()), L.ptr(global_logit), tg, L.ptr(out),
+                                                          L.ptr(ws), ws.numel() * 4, L.stream_ptr()), h)
+    return out
+
+
+def copy2d(src, dst_view):
+    """dst_view[:, :] = src for a row-strided destination (torch.cat on dim=1 without a new tensor)."""
+    L.need_gpu_f32(src, dst_view)
+    rows, cols = src.shape
+    if src.stride(1) != 1 or dst_view.stride(1) != 1:
+        raise ValueError("copy2d: unit inner stride required")
+    h = _h(src)
+    L.check(L.load_library().adaf_copy2d_f32(h, L.ptr(src), src.stride(0), L.ptr(dst_view), dst_view.stride(0), rows, cols,
+                                             L.stream_ptr()), h)
+    return dst_view
+
+
+class ResNet50Trunk:
+    """adaf_resnet50: the whole local CNN (stem ... layer4, avgpool) as ~55 back-to-back launches on
+    one stream, weights packed / BN folded once.  Replaces ResNet.get_featmap(x, pooled=True)
+    (ACT/models/resnet.py:211-225) and TSN.forward(no_reshape=True) (STH/models/tsn.py:215-241)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._h = L.handle(self.device)
+        self._lib = L.load_library()
+        net = C.c_void_p()
+        L.check(self._lib.adaf_resnet50_create(self._h, C.byref(net)), self._h)
+        self._net = net
+        self._ws = None
+        self.n_launches = self._lib.adaf_resnet50_launch_count(net)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_net", None):
+                self._lib.adaf_resnet50_destroy(self._net)
+                self._net = None
+        except Exception:
+            pass
+
+    def load(self, params):
+        """params: mapping torchvision-style name -> tensor (on this device).  Non-trunk entries
+        (fc.*, num_batches_tracked) are ignored."""
+        keep = []
+        for name, t in params.items():
+            if name.startswith("fc.") or name.endswith("num_batches_tracked"):
+                continue
+            L.need_gpu_f32(t)
+            t = t.detach().contiguous()
+            keep.append(t)
+            L.check(self._lib.adaf_resnet50_set_param(self._net, name.encode(), L.ptr(t), t.numel()), self._h)
+        L.check(self._lib.adaf_resnet50_finalize(self._net, L.stream_ptr()), self._h)
+        del keep
+
+    def _workspace(self, n, patch):
+        need = self._lib.adaf_resnet50_workspace_bytes(self._net, n, patch)
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty(need // 4, device=self.device, dtype=torch.float32)
+        return self._ws, need
+
+    def forward(self, patches_nhwc4, tsm_segments=0, tsm_div=8, out=None):
+        """patches (N,P,P,4) -> (N,2048); `out` may be a (N,2048) row-strided view (e.g. the tail of
+        the GRU input matrix)."""
+        L.need_gpu_f32(patches_nhwc4, out)
+        x = patches_nhwc4.contiguous()
+        n, p = x.shape[0], x.shape[1]
+        if out is None:
+            out = torch.empty((n, 2048), device=x.device, dtype=torch.float32)
+        ws, need = self._workspace(n, p)
+        L.check(self._lib.adaf_resnet50_forward(self._net, L.ptr(x), n, p, int(tsm_segments), int(tsm_div), L.ptr(out),
+                                                out.stride(0), L.ptr(ws), need, L.stream_ptr()), self._h)
+        return out
+
+    def profile(self, patches_nhwc4, tsm_segments=0, tsm_div=8):
+        """One forward bracketed by HIP events per launch.  Returns a list of dicts
+        {ms, flops, bytes, tile} (flops = 0 for the pooling launches)."""
+        x = patches_nhwc4.contiguous()
+        n, p = x.shape[0], x.shape[1]
+        out = torch.empty((n, 2048), device=x.device, dtype=torch.float32)
+        ws, need = self._workspace(n, p)
+        k = self.n_launches
+        ms = (C.c_float * k)()
+        fl = (C.c_double * k)()
+        by = (C.c_double * k)()
+        tl = (C.c_int * k)()
+        L.check(self._lib.adaf_resnet50_forward_profiled(self._net, L.ptr(x), n, p, int(tsm_segments), int(tsm_div),
+                                                         L.ptr(out), 2048, L.ptr(ws), need, L.stream_ptr(), ms, fl, by,
+                                                         tl), self._h)
+        return [dict(ms=ms[i], flops=fl[i], bytes=by[i], tile=tl[i]) for i in range(k)]
+
+    def set_tiles(self, tiles):
+        arr = (C.c_int * len(tiles))(*tiles)
+        L.check(self._lib.adaf_resnet50_set_tiles(self._net, arr, len(tiles)), self._h)

@@ -1,0 +1,82 @@
+"""Patch-location policy, inference branch only (ACT/models/ppo.py:27-96,125-145).
+
+The policy is the PRODUCER of the crop coordinates, so bit-exactness of the gather is defined
+relative to its output tensor; it stays a few small PyTorch-ROCm ops and its
+result is handed to the HIP gather without a host round trip.  The PPO update / Memory replay
+logic is training code and out of scope.
+
+``ActorCritic.act_sequence`` is the offline-inference form: in eval mode the policy input is only
+the glancer feature map and its own hidden state (ppo.py:67-96), so all T actions are computed
+before any patch is cropped.
+"""
+import torch
+from torch import nn
+
+__all__ = ["Memory", "ActorCritic", "PPO"]
+
+
+class Memory:
+    def __init__(self):
+        self.actions, self.states, self.logprobs, self.rewards, self.is_terminals, self.hidden = [], [], [], [], [], []
+
+    def clear_memory(self):
+        for lst in (self.actions, self.states, self.logprobs, self.rewards, self.is_terminals, self.hidden):
+            del lst[:]
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, feature_dim, state_dim, action_dim, hidden_state_dim=1024, policy_conv=True):
+        super().__init__()
+        if policy_conv:
+            self.state_encoder = nn.Sequential(
+                nn.Conv2d(feature_dim, 32, 1, bias=False), nn.ReLU(), nn.Flatten(),
+                nn.Linear(int(state_dim * 32 / feature_dim), hidden_state_dim), nn.ReLU())
+        else:
+            self.state_encoder = nn.Sequential(nn.Linear(state_dim, 2048), nn.ReLU(),
+                                               nn.Linear(2048, hidden_state_dim), nn.ReLU())
+        self.gru = nn.GRU(hidden_state_dim, hidden_state_dim, batch_first=False)
+        self.actor = nn.Sequential(nn.Linear(hidden_state_dim, action_dim), nn.Softmax(dim=-1))
+        self.critic = nn.Sequential(nn.Linear(hidden_state_dim, 1))
+        self.hidden_state_dim, self.action_dim, self.policy_conv, self.feature_dim = \
+            hidden_state_dim, action_dim, policy_conv, feature_dim
+
+    def act(self, state_ini, memory, restart_batch=False, training=True):
+        """One step, eval branch of ppo.py:67-96 (argmax of the actor's softmax)."""
+        if training:
+            raise NotImplementedError("adafocus_amd implements the inference branch of the policy only")
+        if restart_batch:
+            del memory.hidden[:]
+            memory.hidden.append(torch.zeros(1, state_ini.size(0), self.hidden_state_dim, device=state_ini.device))
+        state = state_ini if self.policy_conv else state_ini.flatten(1)
+        state = self.state_encoder(state)
+        state, hidden = self.gru(state.view(1, state.size(0), state.size(1)), memory.hidden[-1])
+        memory.hidden.append(hidden)
+        return self.actor(state[0]).max(1)[1]
+
+    @torch.no_grad()
+    def act_sequence(self, states):
+        """states (B,T,C,h,w) -> action indices (B,T): encoder over all B*T frames at once, one GRU
+        scan, one actor call.  Same arithmetic as T calls of act()."""
+        b, t = states.shape[:2]
+        flat = states.reshape(b * t, *states.shape[2:])
+        enc = self.state_encoder(flat if self.policy_conv else flat.flatten(1)).view(b, t, -1).transpose(0, 1)
+        out, _ = self.gru(enc.contiguous(), torch.zeros(1, b, self.hidden_state_dim, device=states.device))
+        return self.actor(out).max(2)[1].transpose(0, 1).contiguous()
+
+
+class PPO(nn.Module):
+    """Holder of policy / policy_old with the reference's attribute and state-dict names."""
+
+    def __init__(self, feature_dim, state_dim, action_dim, hidden_state_dim, policy_conv, gpu=0, lr=0.0003,
+                 betas=(0.9, 0.999), gamma=0.7, K_epochs=1, eps_clip=0.2):
+        super().__init__()
+        self.lr, self.betas, self.gamma, self.eps_clip, self.K_epochs = lr, betas, gamma, eps_clip, K_epochs
+        self.policy = ActorCritic(feature_dim, state_dim, action_dim, hidden_state_dim, policy_conv)
+        self.policy_old = ActorCritic(feature_dim, state_dim, action_dim, hidden_state_dim, policy_conv)
+        self.policy_old.load_state_dict(self.policy.state_dict())
+
+    def select_action(self, state, memory, restart_batch=False, training=True):
+        return self.policy_old.act(state, memory, restart_batch, training)
+
+    def update(self, memory):
+        raise NotImplementedError("PPO.update is training code (out of scope, SURVEY.md §2 row 5)")

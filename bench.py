@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s of the AdaFocus offline-inference hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of B clips per GPU, inputs resident in HBM:
+batched patch gather of B*T windows from (B*T,3,224,224) frames -> ResNet-50 local CNN over the
+B*T patches -> concat with the glancer's 1280-d vectors -> GRU + FC classifier (+ for N > 1 one RCCL
+all-gather of the (B,C) logits).  Workload = BASELINE.json's metric configuration: T=16 frames,
+96x96 patches, ResNet-50 local CNN, B=64 clips per GPU (weak scaling: clips shard across ranks).
+Glancer features and policy actions are producers upstream of the path and are generated once
+before the timed region (the actions are a forced uniform-random 7x7 grid sequence so the gather
+addresses scatter).
+
+Prints ONE JSON line (rank 0) with the contract fields plus:
+  roofline     -- dominant kernel (implicit-GEMM conv on fp32 MFMA): algorithmic FLOP / HIP-event time
+  cpu_baseline -- the oracle (torch-CPU restatement of the reference) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def act_args(t, p, b):
+    return Args(num_segments=t, num_classes=200, reward="random", dataset="actnet", input_size=224, batch_size=b,
+                patch_size=p, with_glancer=True, feature_map_channels=1280, glance_size=224, action_dim=49,
+                hidden_state_dim=1024, policy_conv=True, gpu=0, continuous=False, gamma=0.7, policy_lr=0.0003,
+                random_patch=False, dropout=0.5, consensus="gru", hidden_dim=1024)
+
+
+def synth_model_state(model, seed):
+    from adafocus_amd import synth
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    return {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed).items()}
+
+
+def cpu_baseline(sd, t, p, clips, threads):
+    """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host."""
+    from adafocus_amd import synth
+    from oracle import ref_model as O
+    if threads:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    frames = torch.from_numpy(synth.synth_frames(clips, t, 224, seed=1)).view(clips * t, 3, 224, 224)
+    _, actions = synth.synth_actions(clips * t, 7, seed=2)
+    gvec = torch.randn(clips, t, 1280)
+    times = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.perf_counter()
+            O.act_hot_path(sd, frames, gvec, torch.from_numpy(actions), p)
+            times.append(time.perf_counter() - t0)
+    best = float(np.median(times[1:]))
+    return {"value": round(clips / best, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "oracle.act_hot_path (batched crop -> ResNet-50 -> GRU), %d clips x T=%d, P=%d, fp32, "
+                      "median of 3 after 1 warm-up, %.2f s/iter" % (clips, t, p, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--patch", type=int, default=96)
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra per-launch HIP-event passes for the roofline")
+    ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy producers)")
+    ap.add_argument("--tiles", type=str, default="", help="comma list of per-conv tile overrides (tuning)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from adafocus_amd import synth
+    from adafocus_amd.gfv_net import GFV
+    from adafocus_amd.parallel import gather_logits
+
+    b, t, p = a.batch, a.frames, a.patch
+    model = GFV(act_args(t, p, b)).eval()
+    sd = synth_model_state(model, 1007)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+
+    # synthetic inputs, resident in HBM before the timed region (per-rank shard of the clip set)
+    frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=100 + rank)).to(dev).view(b * t, 3, 224, 224)
+    _, act_np = synth.synth_actions(b * t, 7, seed=2 + rank)
+    actions = torch.from_numpy(act_np).to(dev)
+    gvec = torch.randn((b, t, 1280), device=dev)
+    trunk = model.focuser.net._sync()
+    if a.tiles:
+        trunk.set_tiles([int(v) for v in a.tiles.split(",")])
+
+    def step():
+        with torch.no_grad():
+            logits, last, _ = model.hot_path(frames, gvec, actions, b, t)
+            if world > 1:
+                last = gather_logits(last)
+        return last
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    clips_total = b * world * a.steps
+    value = clips_total / elapsed
+    res = {
+        "metric": "clips/sec (T=%d, patch=%d^2, ResNet-50 local)" % (t, p), "value": round(value, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ActivityNet AdaFocus hot path: gather + ResNet-50 local CNN + GRU classifier, "
+                               "T=%d, P=%d, B=%d clips/GPU (%d patches/GPU/step), random-init weights seed 1007"
+                               % (t, p, b, b * t),
+                   "global_batch": b * world, "frames": t, "patch": p, "parallelism": "dp%d" % world},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -------------
+        conv_ms = conv_fl = tot_ms = 0.0
+        nconv = 0
+        patches = model.focuser.net  # noqa: F841
+        from adafocus_amd.utils import get_patch_nhwc4
+        x4 = get_patch_nhwc4(frames, actions, p)
+        per_launch = None
+        for _ in range(max(a.profile_steps, 1)):
+            prof = trunk.profile(x4)
+            per_launch = prof
+            for e in prof:
+                tot_ms += e["ms"]
+                if e["flops"] > 0:
+                    conv_ms += e["ms"]
+                    conv_fl += e["flops"]
+                    nconv += 1
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": "conv_gemm_kernel (implicit-GEMM conv+BN+ReLU, v_mfma_f32_32x32x2_f32), %d launches/step"
+                                     % (nconv // max(a.profile_steps, 1)),
+                           "avg_launch_ms": round(conv_ms / max(nconv, 1), 4),
+                           "flop_per_launch": round(conv_fl / max(nconv, 1), 1),
+                           "trunk_ms_per_step": round(tot_ms / max(a.profile_steps, 1), 3)}
+        # the gather, priced against HBM
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            get_patch_nhwc4(frames, actions, p)
+        ev1.record()
+        torch.cuda.synchronize()
+        crop_ms = ev0.elapsed_time(ev1) / 20
+        crop_bytes = 2.0 * 3 * p * p * 4 * b * t
+        res["gather"] = {"bound": "hbm", "achieved": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(crop_bytes / (crop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "ms": round(crop_ms, 4), "bytes_per_patch": 2 * 3 * p * p * 4}
+        if os.environ.get("ADAF_BENCH_LAUNCHES"):
+            res["launches"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()} for e in per_launch]
+        if a.full:
+            try:
+                scan = frames.view(b, t * 3, 224, 224)
+                with torch.no_grad():
+                    for _ in range(2):
+                        model.offline_forward(scan, scan)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        model.offline_forward(scan, scan)
+                    torch.cuda.synchronize()
+                res["full_forward"] = {"value": round(3 * b / (time.perf_counter() - t1), 2), "unit": "clips/s",
+                                       "note": "glancer (MobileNetV2) + policy as PyTorch-ROCm producers + hot path"}
+            except Exception as exc:  # producers are outside the path; never fail the bench on them
+                res["full_forward"] = {"error": repr(exc)[:200]}
+        if world == 1 and a.cpu_clips > 0:
+            res["cpu_baseline"] = cpu_baseline(sd, t, p, a.cpu_clips, a.cpu_threads)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

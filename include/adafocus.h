@@ -1,0 +1,185 @@
+/*
+ * adafocus.h -- C ABI of the MI355X-native AdaFocus offline-inference hot path.
+ *
+ * The reference (blackfeather-wang/AdaFocus) is 100 % Python on PyTorch and exposes no
+ * FFI/plugin registry; its boundary for this path is the Python
+ * surface of models/utils.py, models/gfv_net.py, models/resnet.py, ops/temporal_shift.py.
+ * This header is the flat C layer that surface is re-implemented on.  Each entry point cites
+ * the reference interface it replaces.  Path aliases:
+ *   ACT/ = "Experiments on ActivityNet, FCVID and Mini-Kinetics/"
+ *   STH/ = "Experiments on Something-Something V1&V2/"
+ *
+ * Conventions
+ *   - every pointer named in a compute call is a DEVICE pointer owned by the caller
+ *     (PyTorch tensors' data_ptr()); the library allocates only its handle and the packed
+ *     weight copies made by adaf_resnet50_finalize();
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls enqueue work
+ *     and return, they never synchronise the device;
+ *   - all functions return ADAF_OK (0) or a negative ADAF_E_* code; the message is available
+ *     from adaf_last_error(); a handle is not thread-safe (one per device per process, like the
+ *     reference's one Python thread per rank);
+ *   - activations are fp32 NHWC ("pixel-major"): element (n,y,x,c) at ((n*H+y)*W+x)*ld + c.
+ */
+#ifndef ADAFOCUS_H
+#define ADAFOCUS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADAF_VERSION 100
+
+enum {
+    ADAF_OK = 0,
+    ADAF_E_BADARG = -1, /* argument out of the documented domain */
+    ADAF_E_LAYOUT = -2, /* unsupported layout / alignment */
+    ADAF_E_ARCH = -3,   /* device is not gfx950 or no device */
+    ADAF_E_LAUNCH = -4, /* HIP runtime error while enqueueing */
+    ADAF_E_STATE = -5,  /* object not finalized / missing parameter */
+    ADAF_E_NOMEM = -6   /* workspace too small or allocation failure */
+};
+
+enum { ADAF_LAYOUT_NCHW = 0, ADAF_LAYOUT_NHWC = 1, ADAF_LAYOUT_NHWC4 = 2 /* C=3 padded to 4 with a zero lane */ };
+enum { ADAF_ACT_NONE = 0, ADAF_ACT_RELU = 1, ADAF_ACT_RELU6 = 2 };
+
+typedef struct adaf_handle adaf_handle;
+typedef struct adaf_resnet50 adaf_resnet50;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int adaf_version(void);
+/* Binds to HIP device `device`; fails with ADAF_E_ARCH unless it is a gfx950 part. */
+int adaf_create(int device, adaf_handle** out);
+int adaf_destroy(adaf_handle* h);
+const char* adaf_last_error(const adaf_handle* h);
+/* Number of compute units of the bound device (256 on MI355X). */
+int adaf_device_cus(const adaf_handle* h);
+
+/* ---- a1: patch gather -------------------------------------------------------------------
+ * Replaces get_patch(images, action_sequence, patch_size) -- ACT/models/utils.py:37-51
+ * (= STH/models/utils.py:44-58) and PatchSampler.sample -- ACT/models/gfv_net.py:363-374.
+ *   frames      [n_frames, channels, height, width] fp32, NCHW (the loader's layout)
+ *   action_yx   [n_actions, 2] fp32 in [0,1]; column 0 = row (y) fraction, column 1 = x fraction
+ *   frames_per_action  frame f uses action f / frames_per_action (1 = ActivityNet per-frame
+ *               coords; T = Something-Something one (y,x) per clip applied to T frames);
+ *               n_actions * frames_per_action must equal n_frames
+ *   coords: y0 = (int)floorf(a_y * (float)(height - patch)), x0 likewise with the SAME
+ *               (height - patch) factor (utils.py:40 uses images.size(2) for both axes);
+ *               bit-exact with the reference for a in [0,1]; clamped to the frame for memory
+ *               safety outside that range.  Requires width >= height.
+ *   out         out_layout NCHW  -> [n_frames, channels, patch, patch]  (reference layout)
+ *               out_layout NHWC  -> [n_frames, patch, patch, channels]
+ *               out_layout NHWC4 -> [n_frames, patch, patch, 4], channels must be 3, lane 3 = 0
+ *   coords_out  optional [n_actions, 2] int32 (y0, x0) for parity checks; may be NULL
+ */
+int adaf_crop_gather_f32(adaf_handle* h, const float* frames, int n_frames, int channels, int height, int width,
+                         const float* action_yx, int n_actions, int frames_per_action, int patch, float* out,
+                         int out_layout, int32_t* coords_out, void* stream);
+
+/* ---- a4: fused conv + BN(eval) + residual + activation, implicit GEMM on fp32 MFMA ------
+ * Replaces the nn.Conv2d -> nn.BatchNorm2d -> (+identity) -> ReLU sequences of
+ * Bottleneck.forward -- ACT/models/resnet.py:94-114, the stem (:212-214), the pointwise
+ * convs of InvertedResidual -- ACT/models/mobilenet.py:42-68, and nn.Linear (h = w = 1).
+ * out[m, co] = act( dot(x_window[m,:], w[co,:]) * scale[co] + bias[co] + residual[m, co] )
+ */
+typedef struct adaf_conv_params {
+    int n, h, w, cin;   /* input: n images of h x w pixels, cin channels (cin % 4 == 0) */
+    int cout, kh, kw;   /* filter bank [cout][kh][kw][cin] (see adaf_pack_conv_weight_f32) */
+    int stride, pad;
+    int act;            /* ADAF_ACT_* */
+    int tsm_segments;   /* > 0: temporal shift (STH/ops/temporal_shift.py:28-46) of the INPUT, fused into the
+                           operand load; images are (clip, t) with t fastest, n % tsm_segments == 0;
+                           only for kh = kw = 1, stride 1, pad 0 */
+    int tsm_div;        /* fold = cin / tsm_div, must be a multiple of 4 */
+    int ldx, ldo, ldr;  /* pixel strides in floats of x / out / residual; 0 = dense (cin / cout / cout) */
+    int tile;           /* 0 = choose automatically; 1..ADAF_CONV_TILES = force a tile shape (tuning) */
+} adaf_conv_params;
+
+#define ADAF_CONV_TILES 4
+
+int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const float* x, const float* w_ohwi,
+                           const float* scale, const float* bias, const float* residual, float* out,
+                           void* stream);
+/* Same contract, one thread per output element, no MFMA: the on-device cross-check used by
+ * the tests (never by the model path). */
+int adaf_conv2d_naive_f32(adaf_handle* h, const adaf_conv_params* p, const float* x, const float* w_ohwi,
+                          const float* scale, const float* bias, const float* residual, float* out,
+                          void* stream);
+/* OIHW (PyTorch) -> OHWI with the input-channel axis zero-padded to cin_pad (>= cin, % 4 == 0). */
+int adaf_pack_conv_weight_f32(adaf_handle* h, const float* w_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                              float* w_ohwi, void* stream);
+/* Eval-mode BatchNorm as an affine map: scale = gamma / sqrt(var + eps), bias = beta - mean * scale
+ * (nn.BatchNorm2d in eval mode, ACT/models/resnet.py:85-91). */
+int adaf_fold_bn_f32(adaf_handle* h, const float* gamma, const float* beta, const float* mean, const float* var,
+                     float eps, int channels, float* scale, float* bias, void* stream);
+
+/* ---- pooling ---------------------------------------------------------------------------
+ * nn.MaxPool2d(3, 2, 1) -- ACT/models/resnet.py:141,215; nn.AdaptiveAvgPool2d((1,1)) -- :150,222. */
+int adaf_maxpool3x3s2_f32(adaf_handle* h, const float* x, int n, int hh, int ww, int c, float* out, void* stream);
+int adaf_global_avgpool_f32(adaf_handle* h, const float* x, int n, int hw, int c, float* out, int ldo, void* stream);
+
+/* ---- a6: stand-alone temporal shift ----------------------------------------------------
+ * TemporalShift.shift(x, n_segment, fold_div) -- STH/ops/temporal_shift.py:28-46.
+ * x, out: [n_clips * n_segment, c, hw] (layout NCHW) or [n_clips * n_segment, hw, c] (NHWC). */
+int adaf_temporal_shift_f32(adaf_handle* h, const float* x, int nt, int c, int hw, int n_segment, int fold_div,
+                            int layout, float* out, void* stream);
+
+/* ---- a4/a5: ResNet-50 trunk as one object ----------------------------------------------
+ * Replaces ResNet.get_featmap(x, pooled=True) -- ACT/models/resnet.py:211-225 -- and
+ * TSN.forward(input, no_reshape=True) -- STH/models/tsn.py:215-241 (TSM on every Bottleneck
+ * conv1, STH/ops/temporal_shift.py:123-140).  Parameter names are torchvision's
+ * ("conv1.weight", "bn1.running_var", "layer3.4.conv2.weight", "layer2.0.downsample.1.bias").
+ */
+int adaf_resnet50_create(adaf_handle* h, adaf_resnet50** out);
+int adaf_resnet50_destroy(adaf_resnet50* net);
+/* Registers a device pointer to a parameter / buffer in PyTorch layout; the data is read by
+ * adaf_resnet50_finalize() and not needed afterwards. */
+int adaf_resnet50_set_param(adaf_resnet50* net, const char* name, const float* dev_ptr, size_t numel);
+/* Packs weights (OIHW -> OHWI, stem cin 3 -> 4), folds BN, on `stream`; synchronises that stream. */
+int adaf_resnet50_finalize(adaf_resnet50* net, void* stream);
+size_t adaf_resnet50_workspace_bytes(const adaf_resnet50* net, int n, int patch);
+/* patches_nhwc4 [n, patch, patch, 4] (adaf_crop_gather_f32 with ADAF_LAYOUT_NHWC4);
+ * feat[i * ldfeat + c], c < 2048: the pooled feature (get_featmap(..., pooled=True).view(n,-1)).
+ * tsm_segments = 0 for the ActivityNet model. */
+int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
+                          int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream);
+/* Same as forward, but brackets every launch with HIP events on `stream` and reports per-launch
+ * milliseconds, algorithmic FLOPs (2*MAC, 0 for non-conv launches) and algorithmic bytes.
+ * Arrays must hold adaf_resnet50_launch_count() entries.  Synchronises the stream. */
+int adaf_resnet50_launch_count(const adaf_resnet50* net);
+int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch,
+                                   int tsm_segments, int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes,
+                                   void* stream, float* launch_ms, double* launch_flops, double* launch_bytes,
+                                   int* launch_tile);
+/* Tile-shape override table for tuning: tile[i] in 0..ADAF_CONV_TILES for conv launch i (0 = auto). */
+int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
+
+/* ---- a7: GRU classifier ----------------------------------------------------------------
+ * RecurrentClassifier.forward -- ACT/models/gfv_net.py:427-435 (nn.GRU batch_first, gate order
+ * r,z,n; h0 = 0; dropout = identity in eval; nn.Linear on every step).
+ *   x [B, T, F] with row stride ldx (0 = F); logits_all [B*T, C]; last [B, C] */
+size_t adaf_gru_cls_workspace_bytes(int batch, int steps, int hidden);
+int adaf_gru_cls_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
+                             int classes, const float* w_ih, const float* w_hh, const float* b_ih,
+                             const float* b_hh, const float* fc_w, const float* fc_b, float* logits_all,
+                             float* last, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a8: linear classifier + temporal mean ---------------------------------------------
+ * nn.Linear + ConsensusModule('avg') (+ glancer mean logits) -- STH/models/gfv_net.py:164-174,
+ * STH/ops/basic_ops.py:17-26.  feat [B*T, F]; global_logit [B, Tg, C] or NULL; out [B, C];
+ * ws holds B*T*C floats. */
+int adaf_fc_meanpool_forward_f32(adaf_handle* h, const float* feat, int batch, int steps, int feat_dim, int classes,
+                                 const float* fc_w, const float* fc_b, const float* global_logit, int global_steps,
+                                 float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- glue ------------------------------------------------------------------------------
+ * dst[r*ldd + c] = src[r*lds + c]: torch.cat([global_feat, local_feat], dim=1) of
+ * ACT/models/gfv_net.py:121 done as a strided copy into the GRU input. */
+int adaf_copy2d_f32(adaf_handle* h, const float* src, int lds, float* dst, int ldd, int rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAFOCUS_H */

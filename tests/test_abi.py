@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the
+header declares, and the product path refuses to run without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from adafocus_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure_built():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_header_symbols_exported():
+    _ensure_built()
+    header = open(os.path.join(ROOT, "include", "adafocus.h")).read()
+    declared = set(re.findall(r"\b(adaf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.adaf_version.restype = ctypes.c_int
+    assert lib.adaf_version() == 100
+
+
+def test_loader_declares_prototypes():
+    _ensure_built()
+    lib = _lib.load_library()
+    assert lib.adaf_resnet50_workspace_bytes.restype is ctypes.c_size_t
+    # pure host helpers are callable without a device
+    assert lib.adaf_gru_cls_workspace_bytes(2, 8, 1024) == (2 * 8 * 3072 + 2 * 3072 + 2 * 8 * 1024) * 4
+    assert lib.adaf_resnet50_workspace_bytes(None, 4, 96) == 5 * 4 * 48 * 48 * 64 * 4
+    assert lib.adaf_resnet50_workspace_bytes(None, 1, 98) == 5 * 25 * 25 * 256 * 4   # odd stem size: stage-1 map is larger
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_fails_loudly():
+    _ensure_built()
+    from adafocus_amd import hip_ops, utils
+    with pytest.raises(_lib.AdafError):
+        utils.get_patch(torch.zeros(1, 3, 224, 224), torch.zeros(1, 2), 96)
+    with pytest.raises(_lib.AdafError):
+        hip_ops.maxpool3x3s2(torch.zeros(1, 8, 8, 64))
+    h = ctypes.c_void_p()
+    assert _lib.load_library().adaf_create(0, ctypes.byref(h)) == -3   # ADAF_E_ARCH: no gfx950 device
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "adafocus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -133,3 +133,45 @@ def test_g7_sth_end_to_end():
     np.testing.assert_allclose(logit.numpy(), g["logits"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(logit_f.numpy(), g["logits_forced"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(logit_f.numpy(), g["logits_stage3_forced"], rtol=1e-4, atol=2e-5)
+
+
+# ---- the plain-C restatement (oracle/crop_ref.c) against the same reference vectors ----------
+def _c_oracle():
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "libcrop_ref.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True)
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_c_oracle_coords_and_payload():
+    lib = _c_oracle()
+    g = golden("g1_crop_indices")
+    a = np.ascontiguousarray(g["cont_actions"])
+    for p in SIZES:
+        out = np.empty((a.shape[0], 2), dtype=np.int32)
+        lib.ref_patch_coords(_p(a), a.shape[0], 224, p, _p(out))
+        assert np.array_equal(out, g["cont_coords_%d" % p])
+    g2 = golden("g2_crop_payload")
+    fr = np.ascontiguousarray(rnd((2, 24, 224, 224), 22).numpy())
+    act = np.ascontiguousarray(g2["a2"])
+    out = np.empty((2, 24, 128, 128), dtype=np.float32)
+    lib.ref_get_patch(_p(fr), 2, 24, 224, 224, _p(act), 128, _p(out))
+    assert np.array_equal(_sha(out), g2["sha2_128"])
+
+
+def test_c_oracle_temporal_shift():
+    lib = _c_oracle()
+    g = golden("g3_temporal_shift")
+    x = np.arange(2 * 8 * 16 * 3 * 3, dtype=np.float32)
+    out = np.empty_like(x)
+    lib.ref_temporal_shift(_p(x), 16, 16, 9, 8, 8, _p(out))
+    assert np.array_equal(out.reshape(16, 16, 3, 3), g["out_arange"])
