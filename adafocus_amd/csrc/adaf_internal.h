@@ -10,6 +10,7 @@
 struct adaf_handle {
     int device = 0;
     int cus = 256;
+    float* zeros = nullptr;  // device, 256 bytes of zeros
     std::string err;
 };
 
@@ -26,6 +27,8 @@ struct ConvArgs {
     int ldx, ldo, ldr;
     int act;
     int tsm_T, tsm_fold, tsm_hw;
+    const float* zeros;  // >= 64 bytes of zeros (handle-owned): target of predicated-off loads
+    int vec_epi;         // 1: 16-byte epilogue is legal (aligned out/res/scale/bias, strides % 4 == 0)
     int tiles_n;         // ceil(N / BN) for the chosen tile
     int nblocks;
 };

@@ -58,6 +58,9 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
     a->stride = p->stride; a->pad = p->pad; a->ldx = ldx; a->ldo = ldo; a->ldr = ldr; a->act = p->act;
     a->tsm_T = p->tsm_segments > 0 ? p->tsm_segments : 0; a->tsm_fold = fold; a->tsm_hw = p->h * p->w;
     a->tiles_n = 0; a->nblocks = 0;
+    a->zeros = h->zeros;
+    a->vec_epi = (p->cout % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0 && aligned16(out) && (!res || aligned16(res)) &&
+                  (!scale || aligned16(scale)) && (!bias || aligned16(bias))) ? 1 : 0;
     return ADAF_OK;
 }
 
@@ -79,11 +82,19 @@ int adaf_create(int device, adaf_handle** out) {
     adaf_handle* h = new adaf_handle();
     h->device = device;
     h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->zeros), 256);
+    if (e == hipSuccess) e = hipMemset(h->zeros, 0, 256);
+    (void)hipSetDevice(cur);
+    if (e != hipSuccess) { delete h; return ADAF_E_NOMEM; }
     *out = h;
     return ADAF_OK;
 }
 
 int adaf_destroy(adaf_handle* h) {
+    if (h && h->zeros) (void)hipFree(h->zeros);
     delete h;
     return ADAF_OK;
 }
@@ -275,8 +286,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     auto mark = [&](double flops, double bytes, int tile) {
         if (rec) {
             hipEvent_t e;
-            hipEventCreate(&e);
-            hipEventRecord(e, st);
+            (void)hipEventCreate(&e);
+            (void)hipEventRecord(e, st);
             rec->push_back(e);
             info->push_back({flops, bytes, tile});
         }
@@ -337,8 +348,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     adaf_launch_avgpool(cur, n, hh * ww, 2048, feat, ldfeat, st);
     if (rec) {
         hipEvent_t e;
-        hipEventCreate(&e);
-        hipEventRecord(e, st);
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, st);
         rec->push_back(e);
     }
     hipError_t e = hipGetLastError();
@@ -361,9 +372,9 @@ int adaf_resnet50_create(adaf_handle* h, adaf_resnet50** out) {
 int adaf_resnet50_destroy(adaf_resnet50* net) {
     if (!net) return ADAF_OK;
     for (auto& L : net->convs) {
-        if (L.w) hipFree(L.w);
-        if (L.scale) hipFree(L.scale);
-        if (L.bias) hipFree(L.bias);
+        if (L.w) (void)hipFree(L.w);
+        if (L.scale) (void)hipFree(L.scale);
+        if (L.bias) (void)hipFree(L.bias);
     }
     delete net;
     return ADAF_OK;
@@ -443,14 +454,14 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
     if (rc == ADAF_OK && ev.size() == info.size() + 1) {
         for (size_t i = 0; i < info.size(); ++i) {
             float ms = 0.f;
-            hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             launch_ms[i] = ms;
             launch_flops[i] = info[i].flops;
             launch_bytes[i] = info[i].bytes;
             launch_tile[i] = info[i].tile;
         }
     }
-    for (auto e : ev) hipEventDestroy(e);
+    for (auto e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 

@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     const size_t tsm_stride = (size_t)a.tsm_hw * a.ldx;
 
     f32x4 ra[AP], rb[BP];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto gload = [&](int kt) {
         const int kidx = kt * BK + lq * 4;
@@ -102,9 +101,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < BP; ++p)
         {
-            const bool ok = b_ok[p] && k_ok;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? wrow[p] + kidx : a.w);
-            rb[p] = ok ? v : zero4;
+            // out-of-range chunks read a handle-owned block of zeros: no select on the loaded value,
+            // so nothing forces the load to complete before the multiply phase
+            rb[p] = *reinterpret_cast<const f32x4*>((b_ok[p] && k_ok) ? wrow[p] + kidx : a.zeros);
         }
         if (DENSE) {
             int need = 0;           // which neighbour frame this channel chunk reads (TSM)
@@ -116,8 +115,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
                 const bool ok = a_ok[p] && k_ok && (need == 0 || (a_pix[p] & need));
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? a.x + (long long)a_off[p] + shift + kidx : a.x);
-                ra[p] = ok ? v : zero4;
+                ra[p] = *reinterpret_cast<const f32x4*>(ok ? a.x + (long long)a_off[p] + shift + kidx : a.zeros);
             }
         } else {
             const int tap = kidx / a.cin;
@@ -129,8 +127,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
                 const int iy = a_iy[p] + kh, ix = a_ix[p] + kw;
                 const bool ok = a_ok[p] && k_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const size_t off = (size_t)(a_pix[p] + iy * a.W + ix) * a.ldx + c;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? a.x + off : a.x);
-                ra[p] = ok ? v : zero4;
+                ra[p] = *reinterpret_cast<const f32x4*>(ok ? a.x + off : a.zeros);
             }
         }
     };
@@ -161,6 +158,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads issued above, their use (ds_write) below the MFMAs
         const float* As = smem + (kt & 1) * STAGE + (wm * TM * 32 + frag_row) * LDP + frag_k;
         const float* Bs = smem + (kt & 1) * STAGE + BM * LDP + (wn * TN * 32 + frag_row) * LDP + frag_k;
 #pragma unroll
@@ -187,15 +185,66 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) lstore((kt + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: BN affine, residual, activation; C layout col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
-    const int crow = 4 * (lane >> 5);
-    const bool has_res = a.res != nullptr;
+    // ---- epilogue: BN affine, residual, activation.
+    // C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
     const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
+    const int crow = 4 * (lane >> 5);
+    if (a.vec_epi) {
+        // Transpose the wave's WM x WN tile through its private LDS slab (the K-loop buffers are
+        // free after the final barrier) so every lane owns 4 consecutive channels of a row:
+        // residual loads and output stores become 16-byte accesses, 4x fewer memory instructions.
+        constexpr int WM = TM * 32, WN = TN * 32, SP = WN + 4;
+        static_assert(4 * WM * SP <= 2 * STAGE, "epilogue slab must fit in the K-loop buffers");
+        float* st = smem + wave * WM * SP;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[(i * 32 + crow + (r & 3) + 8 * (r >> 2)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order; just pin the order
+        constexpr int C4 = WN / 4, RPI = 64 / C4;
+        const int c4 = lane % C4, rsub = lane / C4;
+        const int n = n0 + wn * WN + 4 * c4;
+        const bool n_ok = n < a.N;
+        const int nn = n_ok ? n : 0;
+        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nn) : one4;
+        const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nn) : zero4;
+        const bool has_res = a.res != nullptr;
+#pragma unroll
+        for (int it = 0; it < WM / RPI; it += 4) {
+            f32x4 rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + wm * WM + (it + u) * RPI + rsub;
+                const bool ok = n_ok && m < a.M && has_res;
+                rv[u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (it + u) * RPI + rsub;
+                const int m = m0 + wm * WM + row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
+                f32x4 o;
+                o.x = fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, act_lo), act_hi);
+                o.y = fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi);
+                o.z = fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi);
+                o.w = fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi);
+                if (n_ok && m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+            }
+        }
+        return;
+    }
+    // scalar fallback (unaligned strides / channel counts that are not multiples of 4)
+    const bool has_res = a.res != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -207,16 +256,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + crow;
             float rv[16];
-            if (has_res) {  // issue all residual loads of the tile before the first use
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    const bool ok = n_ok && m < a.M;
-                    rv[r] = a.res[ok ? (size_t)m * a.ldr + n : 0];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const bool ok = has_res && n_ok && m < a.M;
+                rv[r] = *(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

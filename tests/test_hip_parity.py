@@ -343,7 +343,8 @@ def test_act_full_forward_golden(dev):
         logits, last, feat, idx = m.offline_forward(frames, frames, torch.from_numpy(g["forced_idx"]))
         lg2, last2 = m(input=frames, scan=frames, training=False, backbone_pred=False, one_step=True, gpu=0)
         _, _, _, pol_idx = m.offline_forward(frames, frames)
-    assert np.abs(feat[:, :, :1280].cpu().numpy() - g["glancer_vec"]).max() < 1e-4
+    # glancer = PyTorch-ROCm (MIOpen) producer vs oneDNN on the reference side: loose, it is not a HIP kernel of ours
+    assert np.abs(feat[:, :, :1280].cpu().numpy() - g["glancer_vec"]).max() < 1e-3
     assert np.abs(logits.cpu().numpy() - g["logits_forced"]).max() < TOL
     assert np.abs(last.cpu().numpy() - g["last_forced"]).max() < TOL
     if np.array_equal(pol_idx.cpu().numpy(), g["policy_idx"]):       # argmax ties may flip across backends
