@@ -133,7 +133,7 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > ADAF_CONV_TILES) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (p->tile < 0 || p->tile > 32) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");

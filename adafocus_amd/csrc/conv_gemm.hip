@@ -22,16 +22,106 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDP = 36;  // LDS row pitch in floats
+// ---- epilogue shared by both kernel families: BN affine, residual, activation ---------------
+// C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int lane, int wave) {
+    const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
+    const int crow = 4 * (lane >> 5);
+    if (a.vec_epi) {
+        // Transpose the wave's WM x WN tile through its private LDS slab (the K-loop buffers are
+        // free after the final barrier) so every lane owns 4 consecutive channels of a row:
+        // residual loads and output stores become 16-byte accesses, 4x fewer memory instructions.
+        constexpr int WM = TM * 32, WN = TN * 32, SP = WN + 4;
+        float* st = smem + wave * 32 * SP;
+        constexpr int C4 = WN / 4, RPI = 64 / C4;   // 16-byte chunks per row, rows per wave instruction
+        const int c4 = lane % C4, rsub = lane / C4;
+        const int n = n0 + wn * WN + 4 * c4;
+        const bool n_ok = n < a.N;
+        const int nn = n_ok ? n : 0;
+        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nn) : one4;
+        const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nn) : zero4;
+        const bool has_res = a.res != nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {   // one 32-row band at a time
+            __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order; just pin the order
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[(crow + (r & 3) + 8 * (r >> 2)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it += 4) {
+                f32x4 rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int m = m0 + wm * WM + i * 32 + (it + u) * RPI + rsub;
+                    const bool ok = n_ok && m < a.M && has_res;
+                    rv[u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (it + u) * RPI + rsub;
+                    const int m = m0 + wm * WM + i * 32 + row;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
+                    f32x4 o;
+                    o.x = fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, act_lo), act_hi);
+                    o.y = fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi);
+                    o.z = fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi);
+                    o.w = fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi);
+                    if (n_ok && m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                }
+            }
+        }
+        return;
+    }
+    // scalar fallback (unaligned strides / channel counts that are not multiples of 4)
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool n_ok = n < a.N;
+        const int nn = n_ok ? n : 0;
+        const float sc = a.scale ? a.scale[nn] : 1.f;
+        const float bi = a.bias ? a.bias[nn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + crow;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const bool ok = has_res && n_ok && m < a.M;
+                rv[r] = *(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const float v = fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi);
+                if (n_ok && m < a.M) a.out[(size_t)m * a.ldo + n] = v;
+            }
+        }
+    }
+}
 
-template <int BM, int BN, int WGM, int WGN, bool DENSE>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+// FLAGS bit 0: raise wave priority around the MFMA cluster (s_setprio)
+template <int BM, int BN, int WGM, int WGN, int BK, bool DENSE, int FLAGS>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int NT = 64 * WGM * WGN;      // threads per block
+    constexpr int LDP = BK + 4;             // LDS row pitch in floats (conflict-free b128 access)
+    constexpr int QK = BK / 4;              // 16-byte chunks per k slice
+    constexpr int RPP = NT / QK;            // rows staged per pass
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int AP = BM / RPP, BP = BN / RPP;
     constexpr int STAGE = (BM + BN) * LDP;
-    static_assert(WGM * WGN == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && AP >= 1 && BP >= 1, "staging shape");
+    constexpr int SLAB = WGM * WGN * 32 * (TN * 32 + 4);   // epilogue transpose slabs (one 32-row band per wave)
+    constexpr int SMEM = 2 * STAGE > SLAB ? 2 * STAGE : SLAB;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -50,8 +140,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     const int tile_n = bid - tile_m * a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int lrow = tid >> 3;  // 0..31: row inside a 32-row pass
-    const int lq = tid & 7;     // which float4 of the 32-wide k slice
+    const int lrow = tid / QK;  // row inside a staging pass
+    const int lq = tid % QK;    // which 16-byte chunk of the k slice
 
     // ---- per-thread row bookkeeping for the operand gather --------------------------------
     bool a_ok[AP];
@@ -60,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     int a_iy[AP], a_ix[AP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-        const int m = m0 + lrow + 32 * p;
+        const int m = m0 + lrow + RPP * p;
         a_ok[p] = m < a.M;
         const int mm = a_ok[p] ? m : 0;
         if (DENSE) {
@@ -87,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     bool b_ok[BP];
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
-        const int n = n0 + lrow + 32 * p;
+        const int n = n0 + lrow + RPP * p;
         b_ok[p] = n < a.N;
         wrow[p] = a.w + (size_t)(b_ok[p] ? n : 0) * a.K;
     }
@@ -135,9 +225,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         float* As = smem + buf * STAGE;
         float* Bs = As + BM * LDP;
 #pragma unroll
-        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDP + lq * 4]) = ra[p];
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * p) * LDP + lq * 4]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDP + lq * 4]) = rb[p];
+        for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * p) * LDP + lq * 4]) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -161,6 +251,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);  // keep the loads issued above, their use (ds_write) below the MFMAs
         const float* As = smem + (kt & 1) * STAGE + (wm * TM * 32 + frag_row) * LDP + frag_k;
         const float* Bs = smem + (kt & 1) * STAGE + BM * LDP + (wn * TN * 32 + frag_row) * LDP + frag_k;
+        if (FLAGS & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 af[TM], bf[TN];
@@ -185,91 +276,196 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
+        if (FLAGS & 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) lstore((kt + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: BN affine, residual, activation.
-    // C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
-    const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
-    const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
-    const int crow = 4 * (lane >> 5);
-    if (a.vec_epi) {
-        // Transpose the wave's WM x WN tile through its private LDS slab (the K-loop buffers are
-        // free after the final barrier) so every lane owns 4 consecutive channels of a row:
-        // residual loads and output stores become 16-byte accesses, 4x fewer memory instructions.
-        constexpr int WM = TM * 32, WN = TN * 32, SP = WN + 4;
-        static_assert(4 * WM * SP <= 2 * STAGE, "epilogue slab must fit in the K-loop buffers");
-        float* st = smem + wave * WM * SP;
+    conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+}
+
+
+// =============================================================================================
+// Direct-to-LDS variant (global_load_lds_dwordx4).  Measured on gfx950 (profiles/r1_conv_ablation.md):
+// with VGPR staging the 8 global_load_dwordx4 + 8 ds_write_b128 a thread issues per k slice cost
+// ~17 % of the MFMA time and are NOT hidden by the co-resident wave; the LDS-DMA form has no
+// register round trip, no ds_write pass and (pointers advanced by a constant per slice) almost no
+// address arithmetic.
+//   - LDS image per operand: [rows][32 floats], NO padding (the DMA writes base + lane*16 B).
+//     Bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index with (row>>1)&7,
+//     applied on the per-lane GLOBAL source address and again on the fragment read.
+//   - a wave instruction fills 8 consecutive rows x 128 B; lane -> (row = 8*g + lane/8, slot = lane%8).
+//   - requirements (checked by the launcher): K % 32 == 0; for non-1x1: cin % 32 == 0, KH*KW <= 32.
+//   - 2 LDS stages; per slice: s_waitcnt vmcnt(0) ; s_barrier ; issue DMA for the next slice ; multiply.
+template <int BM, int BN, int WGM, int WGN, bool DENSE>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
+    constexpr int NW = WGM * WGN;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);   // DMA instructions per wave per slice
+    constexpr int STAGE = (BM + BN) * 32;
+    constexpr int SLAB = NW * 32 * (TN * 32 + 4);
+    constexpr int SMEM = 2 * STAGE > SLAB ? 2 * STAGE : SLAB;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "staging shape");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    int bid = blockIdx.x;
+    {
+        const int q = a.nblocks >> 3, r = a.nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / a.tiles_n;
+    const int tile_n = bid - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-lane source bookkeeping ------------------------------------------------------
+    const int lr = lane >> 3;   // row within the 8-row group
+    const int ls = lane & 7;    // LDS chunk slot
+    const float* pa[AI];        // DENSE: running source pointer (or the zero block)
+    int step_a[AI];             // DENSE: pointer advance per slice (0 for the zero block)
+    long long boff[AI];         // generic: element offset of (image, oy*s-pad, ox*s-pad, chunk)
+    unsigned amask[AI];         // generic: bit t set <=> filter tap t is inside the image for this row
+    int tflag[AI];              // DENSE+TSM: bit0 has previous frame, bit1 has next frame, bit2 row valid
+    int qa[AI];                 // source chunk (swizzled) in floats
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    st[(i * 32 + crow + (r & 3) + 8 * (r >> 2)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
-        __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order; just pin the order
-        constexpr int C4 = WN / 4, RPI = 64 / C4;
-        const int c4 = lane % C4, rsub = lane / C4;
-        const int n = n0 + wn * WN + 4 * c4;
-        const bool n_ok = n < a.N;
-        const int nn = n_ok ? n : 0;
-        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nn) : one4;
-        const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nn) : zero4;
-        const bool has_res = a.res != nullptr;
-#pragma unroll
-        for (int it = 0; it < WM / RPI; it += 4) {
-            f32x4 rv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int m = m0 + wm * WM + (it + u) * RPI + rsub;
-                const bool ok = n_ok && m < a.M && has_res;
-                rv[u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+    for (int j = 0; j < AI; ++j) {
+        const int row = (j * NW + wave) * 8 + lr;
+        const int m = m0 + row;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        qa[j] = (ls ^ ((row >> 1) & 7)) * 4;
+        pa[j] = a.zeros; step_a[j] = 0; boff[j] = 0; amask[j] = 0; tflag[j] = 0;
+        if (DENSE) {
+            if (ok) { pa[j] = a.x + (size_t)mm * a.ldx + qa[j]; step_a[j] = 32; }
+            if (a.tsm_T > 0) {
+                const int t = (mm / a.tsm_hw) % a.tsm_T;
+                tflag[j] = (ok ? 4 : 0) | (t > 0 ? 1 : 0) | (t < a.tsm_T - 1 ? 2 : 0);
             }
+        } else {
+            const int ohw = a.OH * a.OW;
+            const int img = mm / ohw;
+            const int rem = mm - img * ohw;
+            const int oy = rem / a.OW;
+            const int ox = rem - oy * a.OW;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            boff[j] = ((long long)img * a.H * a.W + (long long)iy0 * a.W + ix0) * a.ldx + qa[j];
+            unsigned mk = 0;
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw)
+                    if (ok && (unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W)
+                        mk |= 1u << (kh * a.KW + kw);
+            amask[j] = mk;
+        }
+    }
+    const float* pb[BI];
+    int step_b[BI];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = (it + u) * RPI + rsub;
-                const int m = m0 + wm * WM + row;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
-                f32x4 o;
-                o.x = fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, act_lo), act_hi);
-                o.y = fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi);
-                o.z = fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi);
-                o.w = fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi);
-                if (n_ok && m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+    for (int j = 0; j < BI; ++j) {
+        const int row = (j * NW + wave) * 8 + lr;
+        const int n = n0 + row;
+        const int q = (ls ^ ((row >> 1) & 7)) * 4;
+        if (n < a.N) { pb[j] = a.w + (size_t)n * a.K + q; step_b[j] = 32; }
+        else { pb[j] = a.zeros; step_b[j] = 0; }
+    }
+    const long long tsm_stride = (long long)a.tsm_hw * a.ldx;
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    auto issue = [&](int kt, int buf) {
+        float* As = smem + buf * STAGE + wave * 8 * 32;   // + j*NW*8*32 per instruction
+        float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[j], (lptr_t)(Bs + j * NW * 8 * 32), 16, 0, 0);
+            pb[j] += step_b[j];
+        }
+        if (DENSE) {
+            const bool tsm_slice = a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < AI; ++j) {
+                const float* src = pa[j];
+                if (tsm_slice) {   // this slice holds shifted channels: pick the neighbour frame per chunk
+                    const int c = kt * 32 + qa[j];
+                    if (c < a.tsm_fold) src = (tflag[j] & 2) ? src + tsm_stride : a.zeros;
+                    else if (c < 2 * a.tsm_fold) src = (tflag[j] & 1) ? src - tsm_stride : a.zeros;
+                    if (!(tflag[j] & 4)) src = a.zeros;
+                }
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
+                pa[j] += step_a[j];
+            }
+        } else {
+            const int k0 = kt * 32;
+            const int tap = k0 / a.cin;               // wave-uniform: one tap per slice (cin % 32 == 0)
+            const int c0 = k0 - tap * a.cin;
+            const int kh = tap / a.KW;
+            const int kw = tap - kh * a.KW;
+            const long long toff = ((long long)kh * a.W + kw) * a.ldx + c0;
+#pragma unroll
+            for (int j = 0; j < AI; ++j) {
+                const float* src = ((amask[j] >> tap) & 1u) ? a.x + boff[j] + toff : a.zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
             }
         }
-        return;
-    }
-    // scalar fallback (unaligned strides / channel counts that are not multiples of 4)
-    const bool has_res = a.res != nullptr;
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        const bool n_ok = n < a.N;
-        const int nn = n_ok ? n : 0;
-        const float sc = a.scale ? a.scale[nn] : 1.f;
-        const float bi = a.bias ? a.bias[nn] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + crow;
-            float rv[16];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const bool ok = has_res && n_ok && m < a.M;
-                rv[r] = *(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: row (lane&31) of a 32-row band, chunk (2kk + lane>>5) ^ swizzle(row)
+    const int sw = (lane >> 1) & 7;
+    const int hb = ((lane >> 5) ^ sw) & 1;
+    int foff[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const float v = fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi);
-                if (n_ok && m < a.M) a.out[(size_t)m * a.ldo + n] = v;
-            }
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 32 + ((((2 * kk) ^ (sw & 6)) | hb) << 2);
+    const int a_base = wm * TM * 32 * 32;
+    const int b_base = BM * 32 + wn * TN * 32 * 32;
+
+    const int nk = a.K / 32;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for slice kt has landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's has, and slice kt-1 is consumed
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const float* St = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foff[kk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
+    conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
 
 // One thread per output element: the plain statement of the same contract.
@@ -305,19 +501,30 @@ __global__ void conv_naive_kernel(const ConvArgs a) {
 }
 
 struct TileShape { int bm, bn; float eff; };
-// eff: relative MFMA efficiency of the main loop (bigger tiles amortise staging better);
-// refined from profiles/ measurements.
+// eff: relative MFMA efficiency of the main loop; refined from profiles/ measurements.
+// Tiles 1..4 are the production shapes; higher ids are variants reachable only through the
+// explicit `tile` override (tools/conv_probe.py).  Ids 21.. use the direct-to-LDS kernel.
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
-    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 0.93f}, {64, 64, 0.82f}, {64, 128, 0.90f}};
+    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 0.97f}, {64, 64, 0.95f}, {64, 128, 0.97f}};
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (dense)
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, true, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, false, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if (dense)
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
 }  // namespace
@@ -335,14 +542,30 @@ int adaf_pick_conv_tile(int M, int N, int K, int cus) {
     return best;
 }
 
-int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
-    if (tile <= 0 || tile > ADAF_CONV_TILES) tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
+bool adaf_conv_glds_ok(const ConvArgs& a) {
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (a.K % 32) return false;
+    if (!dense && (a.cin % 32 || a.KH * a.KW > 32)) return false;
+    return true;
+}
+
+int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
+    if (tile <= 0) tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
+    const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (tile > 20 && !adaf_conv_glds_ok(a)) tile = tile - 20 <= 5 ? tile - 20 : 1;   // shape not eligible for the DMA kernel
     switch (tile) {
-        case 1: launch_cfg<128, 128, 2, 2>(a, dense, s); break;
-        case 2: launch_cfg<128, 64, 2, 2>(a, dense, s); break;
-        case 3: launch_cfg<64, 64, 2, 2>(a, dense, s); break;
-        case 4: launch_cfg<64, 128, 2, 2>(a, dense, s); break;
+        case 1: launch_cfg<128, 128, 2, 2, 32, 0>(a, dense, s); break;
+        case 2: launch_cfg<128, 64, 2, 2, 32, 0>(a, dense, s); break;
+        case 3: launch_cfg<64, 64, 2, 2, 32, 0>(a, dense, s); break;
+        case 4: launch_cfg<64, 128, 2, 2, 32, 0>(a, dense, s); break;
+        case 5: launch_cfg<256, 128, 4, 2, 32, 0>(a, dense, s); break;   // 8 waves, 1 block/CU
+        case 21: launch_glds<128, 128, 2, 2>(a, dense, s); break;
+        case 22: launch_glds<128, 64, 2, 2>(a, dense, s); break;
+        case 23: launch_glds<64, 64, 2, 2>(a, dense, s); break;
+        case 24: launch_glds<64, 128, 2, 2>(a, dense, s); break;
+        case 25: launch_glds<256, 128, 4, 2>(a, dense, s); break;        // 8 waves of 64x64
+        case 26: launch_glds<256, 128, 2, 2>(a, dense, s); break;        // 4 waves of 128x64
+        case 27: launch_glds<256, 256, 2, 4>(a, dense, s); break;        // 8 waves of 128x64
         default: return -1;
     }
     return tile;

@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--patch", type=int, default=96)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--tile", type=int, default=-1, help="-1 = sweep 1..4 and auto")
+    ap.add_argument("--tile", type=str, default="", help="comma list of tile ids; default = auto,1..4")
     ap.add_argument("--gemm", action="store_true", help="also time big plain GEMMs (asymptotic main-loop rate)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -46,8 +46,8 @@ def main():
     if a.gemm:
         shapes += [("gemm8k_k4096", 8192, 1, 1, 4096, 8192, 1, 1, 0, False), ("gemm64k_k512", 65536, 1, 1, 512, 1024, 1, 1, 0, False)]
     if a.only:
-        shapes = [s for s in shapes if s[0] == a.only]
-    tiles = [a.tile] if a.tile >= 0 else [0, 1, 2, 3, 4]
+        shapes = [s for s in shapes if s[0] in a.only.split(",")]
+    tiles = [int(t) for t in a.tile.split(',')] if a.tile else [0, 1, 2, 3, 4]
     print("%-14s %9s %6s | " % ("shape", "M", "K") + " ".join("%12s" % ("tile%d" % t) for t in tiles))
     for name, n, h, w, cin, cout, k, stride, pad, res in shapes:
         x = torch.randn((n, h, w, cin), device=dev)
