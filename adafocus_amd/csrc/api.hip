@@ -303,11 +303,11 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         ConvArgs a;
         int rc = make_conv_args(h, &p, in, L.w, L.scale, L.bias, res, out, &a);
         if (rc) return rc;
-        const int tile = p.tile ? p.tile : adaf_pick_conv_tile(a.M, a.N, a.K, h->cus);
         const double macs = (double)a.M * L.cout * L.k * L.k * L.cin;   // algorithmic: un-padded cin
         const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
-        mark(2.0 * macs, bytes, tile);
-        adaf_launch_conv_gemm(a, tile, h->cus, st);
+        mark(2.0 * macs, bytes, 0);
+        const int used = adaf_launch_conv_gemm(a, p.tile, h->cus, st);
+        if (info && !info->empty()) info->back().tile = used;
         *oh = a.OH; *ow = a.OW;
         ++li;
         return ADAF_OK;
@@ -468,7 +468,7 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
     if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
     for (int i = 0; i < count; ++i) {
-        if (tile[i] < 0 || tile[i] > ADAF_CONV_TILES) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        if (tile[i] < 0 || tile[i] > 32) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
         net->tiles[i] = tile[i];
     }
     return ADAF_OK;

@@ -505,7 +505,7 @@ struct TileShape { int bm, bn; float eff; };
 // Tiles 1..4 are the production shapes; higher ids are variants reachable only through the
 // explicit `tile` override (tools/conv_probe.py).  Ids 21.. use the direct-to-LDS kernel.
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
-    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 0.97f}, {64, 64, 0.95f}, {64, 128, 0.97f}};
+    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.00f}, {64, 64, 0.95f}, {64, 128, 0.98f}};
 
 template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
@@ -539,7 +539,7 @@ int adaf_pick_conv_tile(int M, int N, int K, int cus) {
         const double cost = (double)rounds * kTiles[t].bm * kTiles[t].bn / kTiles[t].eff;
         if (cost < best_t * 0.999) { best_t = cost; best = t; }
     }
-    return best;
+    return best;   // 1..4; the launcher upgrades it to the direct-to-LDS form (id + 20) when the shape allows
 }
 
 bool adaf_conv_glds_ok(const ConvArgs& a) {
@@ -550,7 +550,10 @@ bool adaf_conv_glds_ok(const ConvArgs& a) {
 }
 
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
-    if (tile <= 0) tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
+    if (tile <= 0) {
+        tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
+        if (adaf_conv_glds_ok(a)) tile += 20;
+    }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     if (tile > 20 && !adaf_conv_glds_ok(a)) tile = tile - 20 <= 5 ? tile - 20 : 1;   // shape not eligible for the DMA kernel
     switch (tile) {

@@ -94,7 +94,9 @@ typedef struct adaf_conv_params {
                            only for kh = kw = 1, stride 1, pad 0 */
     int tsm_div;        /* fold = cin / tsm_div, must be a multiple of 4 */
     int ldx, ldo, ldr;  /* pixel strides in floats of x / out / residual; 0 = dense (cin / cout / cout) */
-    int tile;           /* 0 = choose automatically; 1..ADAF_CONV_TILES = force a tile shape (tuning) */
+    int tile;           /* 0 = choose automatically; otherwise force a kernel variant (tuning / tests):
+                           1..4 = 128x128, 128x64, 64x64, 64x128 block tiles with register staging,
+                           21..24 = the same tiles with direct-to-LDS loads, 5 / 25..27 = larger experimental tiles */
 } adaf_conv_params;
 
 #define ADAF_CONV_TILES 4
@@ -153,7 +155,7 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
                                    int tsm_segments, int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes,
                                    void* stream, float* launch_ms, double* launch_flops, double* launch_bytes,
                                    int* launch_tile);
-/* Tile-shape override table for tuning: tile[i] in 0..ADAF_CONV_TILES for conv launch i (0 = auto). */
+/* Kernel-variant override table for tuning: tile[i] as in adaf_conv_params.tile for conv launch i (0 = auto). */
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
 
 /* ---- a7: GRU classifier ----------------------------------------------------------------
