@@ -1,0 +1,250 @@
+"""Something-Something V1/V2 model composition -- host-side mirror of STH/models/gfv_net.py for
+offline inference (the call sequence of STH/evaluate.py:195-213 and stage-3 validation).
+
+Differences from the ActivityNet model: one (y,x) per CLIP from a continuous policy applied to all
+T focuser frames (``get_patch`` on a (B, 3T, H, W) view, STH/models/gfv_net.py:148-152), TSM-ResNet-50
+local CNN (shift fused into conv1), and a linear classifier with temporal-mean consensus added to the
+glancer's mean logits (:164-174).  Hot path here: ONE gather launch with ``frames_per_action = T``
+(NHWC4), ONE TSM trunk pass over B*T patches -- the reward-baseline branch (:153-160,176-186), when
+requested, rides in the SAME pass as a second half of the batch -- then ``adaf_fc_meanpool_forward_f32``.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import hip_ops
+from .basic_ops import ConsensusModule
+from .mobilenetv2 import InvertedResidual, mobilenet_v2
+from .ppo import PPO, Memory
+from .ppo_continuous import PPO_Continuous
+from .synth import grid_table
+from .temporal_shift import TemporalShift
+from .tsn import TSN
+from .utils import get_patch, get_patch_nhwc4, nchw_to_nhwc4
+
+__all__ = ["GFV", "Glancer", "Focuser", "PatchSampler"]
+
+
+class GFV(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.num_segments_glancer = args.num_segments_glancer
+        self.num_segments_focuser = args.num_segments_focuser
+        self.num_class = args.num_classes
+        self.input_size = 224
+        self.batch_size = args.batch_size
+        self.patch_size = args.patch_size
+        self.input_mean = [0.485, 0.456, 0.406]
+        self.input_std = [0.229, 0.224, 0.225]
+        self.with_glancer = args.with_glancer
+        self.glancer = Glancer(args)
+        tg = args.num_segments_glancer // args.video_div
+        cells = math.ceil(args.glance_size / 32)
+        policy_params = dict(feature_dim=args.feature_map_channels * tg,
+                             state_dim=args.feature_map_channels * tg * cells * cells, action_dim=args.action_dim,
+                             hidden_state_dim=args.hidden_state_dim, policy_conv=args.policy_conv, gpu=args.gpu,
+                             ppo_continuous=args.ppo_continuous, gamma=args.gamma, policy_lr=args.policy_lr,
+                             action_std=args.action_std, with_bn=args.actorcritic_with_bn)
+        base = dict(num_segments=args.num_segments_focuser, modality=args.modality, base_model=args.base_model,
+                    partial_bn=args.partial_bn, pretrain=args.pretrain, is_shift=args.is_shift, shift_div=args.shift_div,
+                    shift_place=args.shift_place, fc_lr5=args.fc_lr5, temporal_pool=args.temporal_pool,
+                    non_local=args.non_local)
+        self.focuser = Focuser(args.patch_size, args.random_patch, policy_params, base)
+        self.dropout = nn.Dropout(p=args.dropout)
+        self.classifier = nn.Linear(in_features=self.focuser.feature_dim, out_features=args.num_classes)
+        self.consensus = ConsensusModule(consensus_type="avg")
+
+    def _apply(self, fn, *a, **k):   # the continuous policy is a plain holder, move it with the model
+        super()._apply(fn, *a, **k)
+        pol = self.focuser.policy
+        if pol is not None and not isinstance(pol, nn.Module):
+            pol.policy._apply(fn)
+            pol.policy_old._apply(fn)
+        return self
+
+    # ---- reference surface --------------------------------------------------------------
+    def glance(self, input_prime):
+        b, tc, hh, ww = input_prime.shape
+        t = tc // 3
+        fm, logit = self.glancer(input_prime.view(b * t, 3, hh, ww))
+        return fm.view(b, t, *fm.shape[1:]), logit.view(b, t, -1)
+
+    @torch.no_grad()
+    def _stage(self, focuser_image, global_feat_map, global_feat_logit, step, args, prev_local_patch, with_baseline,
+               forced_action=None):
+        if self.training:
+            raise RuntimeError("adafocus_amd: eval mode only")
+        nfg = args.num_segments_glancer // args.video_div
+        nff = args.num_segments_focuser // args.video_div
+        b, _, c, hh, ww = focuser_image.shape
+        cur = focuser_image[:, step * nff:(step + 1) * nff].reshape(b * nff, c, hh, ww)
+        fb, _, fc_, fh, fw = global_feat_map.shape
+        state = global_feat_map[:, step * nfg:(step + 1) * nfg].reshape(fb, -1, fh, fw)
+        action = self.focuser.act(state, restart_batch=(step == 0))
+        if forced_action is not None:
+            action = forced_action.to(action.device)
+        p = args.patch_size
+        cur_patch = get_patch(cur.view(b, nff * c, hh, ww), action, p).view(b, nff, 3, p, p)     # API-layout return value
+        local_patch = cur_patch if prev_local_patch is None else torch.cat([prev_local_patch, cur_patch], dim=1)
+        frames_total = local_patch.shape[1]
+        if prev_local_patch is None:
+            main4 = get_patch_nhwc4(cur, action, p, nff)             # gather straight into the trunk's layout
+        else:
+            main4 = nchw_to_nhwc4(local_patch.reshape(b * frames_total, 3, p, p))
+        groups = [main4]
+        if with_baseline:
+            rand_action = torch.rand(b, 2).to(cur.device)           # Focuser.random_patching, gfv_net.py:424-427
+            base_cur = get_patch(cur.view(b, nff * c, hh, ww), rand_action, p).view(b, nff, 3, p, p)
+            base_patch = base_cur if prev_local_patch is None else torch.cat([prev_local_patch, base_cur], dim=1)
+            groups.append(nchw_to_nhwc4(base_patch.reshape(b * frames_total, 3, p, p)))
+        # TSM segments = frames per clip in this pass (tsn.py:num_segments is fixed at construction in the
+        # reference; with video_div = 1 both agree)
+        feat = self.focuser.net.features_nhwc4(torch.cat(groups, 0) if len(groups) > 1 else groups[0])
+        per = b * frames_total
+        glog = global_feat_logit if self.with_glancer else None
+        logits = [hip_ops.fc_meanpool_forward(feat[g * per:(g + 1) * per], b, self.classifier.weight.detach(),
+                                              self.classifier.bias.detach(), glog) for g in range(len(groups))]
+        return logits, local_patch, action
+
+    def action_stage2(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
+                      prev_local_patch=None, training=True, with_baseline=True, forced_action=None):
+        """STH/models/gfv_net.py:136-188 -> (total_logit, baseline_logit, local_patch)."""
+        if training:
+            raise NotImplementedError("stage-2 policy training is out of scope; call with training=False")
+        logits, local_patch, _ = self._stage(focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
+                                             prev_local_patch, with_baseline, forced_action)
+        return logits[0], (logits[1] if with_baseline else None), local_patch
+
+    def action_stage3(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
+                      prev_local_patch=None, forced_action=None):
+        """STH/models/gfv_net.py:190-225 -> (total_logit, local_patch)."""
+        logits, local_patch, _ = self._stage(focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
+                                             prev_local_patch, False, forced_action)
+        return logits[0], local_patch
+
+    @torch.no_grad()
+    def forward(self, *argv, **kwargs):
+        """STH/models/gfv_net.py:74-99 (eval): glance, one clip-level action, local CNN, consensus sum."""
+        if kwargs.get("training"):
+            raise NotImplementedError("training forward is out of scope")
+        focuser_input, glancer_input = kwargs["input"], kwargs["scan"]
+        b, tc, hh, ww = focuser_input.shape
+        fm, glog = self.glance(glancer_input)
+
+        class _A:
+            pass
+        a = _A()
+        a.num_segments_glancer, a.num_segments_focuser, a.video_div, a.patch_size = \
+            self.num_segments_glancer, self.num_segments_focuser, 1, self.patch_size
+        logits, _, _ = self._stage(focuser_input.view(b, tc // 3, 3, hh, ww), fm, glog, 0, a, None, False)
+        return logits[0]
+
+    def adjust_patch_size(self, patch_size):
+        self.patch_size = patch_size
+        self.focuser.patch_size = patch_size
+        self.focuser.patch_sampler.size = patch_size
+
+    @property
+    def scale_size(self):
+        return self.input_size * 256 // 224
+
+    @property
+    def crop_size(self):
+        return self.input_size
+
+
+class Glancer(nn.Module):
+    """TSM-MobileNetV2 glancer (STH/models/gfv_net.py:228-250): PyTorch-ROCm producer; the shift in front
+    of conv[0] of every residual block runs through the HIP shift kernel."""
+
+    def __init__(self, args, skip=False):
+        super().__init__()
+        self.net = mobilenet_v2(n_class=args.num_classes, pretrained=False)
+        for m in self.net.modules():
+            if isinstance(m, InvertedResidual) and len(m.conv) == 8 and m.use_res_connect:
+                m.conv[0] = TemporalShift(m.conv[0], n_segment=args.num_segments_glancer, n_div=args.shift_div)
+        self.skip = skip
+
+    def forward(self, input):
+        return self.net.get_featmap(input)
+
+    def predict(self, input):
+        return self.net(input)
+
+    @property
+    def feature_dim(self):
+        return self.net.feature_dim
+
+
+class Focuser(nn.Module):
+    def __init__(self, size=96, random=False, policy_params=None, focuser_base_model_params=None):
+        super().__init__()
+        self.net = TSN(**focuser_base_model_params)
+        self.patch_size = size
+        self.random = random
+        self.patch_sampler = PatchSampler(self.patch_size, self.random)
+        self.policy = None
+        self.memory = Memory()
+        if not self.random:
+            assert policy_params is not None
+            self._tables = {s * s: torch.from_numpy(grid_table(s)) for s in range(4, 11)}   # 16 ... 100 cells
+            self.policy_action_dim = policy_params["action_dim"]
+            self.ppo_continuous = policy_params["ppo_continuous"]
+            pp = policy_params
+            if self.ppo_continuous:
+                self.policy = PPO_Continuous(pp["feature_dim"], pp["state_dim"], pp["hidden_state_dim"], pp["policy_conv"],
+                                             pp["gpu"], gamma=pp["gamma"], lr=pp["policy_lr"],
+                                             action_std=pp["action_std"], with_bn=pp["with_bn"])
+            else:
+                self.policy = PPO(pp["feature_dim"], pp["state_dim"], pp["action_dim"], pp["hidden_state_dim"],
+                                  pp["policy_conv"], pp["gpu"], gamma=pp["gamma"], lr=pp["policy_lr"])
+
+    @property
+    def standard_actions_set(self):
+        return self._tables
+
+    def _get_standard_action(self, action):
+        table = self._tables[self.policy_action_dim]
+        if table.device != action.device:
+            table = self._tables[self.policy_action_dim] = table.to(action.device)
+        return table[action], None
+
+    @torch.no_grad()
+    def act(self, state, restart_batch=True):
+        action = self.policy.select_action(state, self.memory, restart_batch, False)
+        return action if self.ppo_continuous else self._get_standard_action(action)[0]
+
+    def forward(self, *argv, **kwargs):
+        """Returns the PATCH (STH/models/gfv_net.py:402-422), reference layout (B, 3T, P, P)."""
+        if self.random:
+            return self.random_patching(kwargs["input"])
+        if kwargs.get("training"):
+            raise NotImplementedError("training branch is out of scope")
+        action = self.act(kwargs["state"], kwargs.get("restart_batch", True))
+        return get_patch(kwargs["input"], action, self.patch_size)
+
+    def random_patching(self, imgs):
+        return get_patch(imgs, torch.rand(imgs.size(0), 2).to(imgs.device), self.patch_size)
+
+    def predict(self, input):
+        return self.net(input)
+
+    @property
+    def feature_dim(self):
+        return self.net.feature_dim
+
+
+class PatchSampler(nn.Module):
+    def __init__(self, size=96, random=True):
+        super().__init__()
+        self.random, self.size = random, size
+
+    def sample(self, imgs, action=None):
+        if self.random:
+            raise NotImplementedError("random cropping is a training-stage path")
+        assert action is not None
+        return get_patch(imgs, action, self.size)
+
+    def forward(self, *argv, **kwargs):
+        raise NotImplementedError("Policy driven patch sampler not implemented.")

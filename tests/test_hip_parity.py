@@ -352,3 +352,62 @@ def test_act_full_forward_golden(dev):
         assert np.abs(last2.cpu().numpy() - g["last"]).max() < TOL
     else:
         pytest.xfail("policy argmax differs between MIOpen and oneDNN on near-ties; forced-action parity passed")
+
+
+# ------------------------------------------------------------------------------------ end to end (STH)
+def _sth_model(dev):
+    from adafocus_amd.gfv_net_sth import GFV
+    from tests.test_state_dict_compat import sth_args
+    a = sth_args()
+    a.gpu = 0
+    m = GFV(a).eval()
+    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])  # evaluate.py:83
+    m.load_state_dict(synth_sd("STH", 1007), strict=True)
+    pol = {k[len("policy."):]: v for k, v in synth_sd("STH_POLICY", 1007).items()}
+    m.focuser.policy.policy_old.load_state_dict(pol)
+    m.focuser.policy.policy.load_state_dict(pol)
+    m.focuser.policy.policy_old.eval()
+    m.focuser.policy.policy.eval()
+    return m.to(dev), a
+
+
+def test_sth_end_to_end_golden(dev):
+    """G7 (config 4: TSM-ResNet-50, Tg = Tf = 8, P = 128, B = 2): glance + action_stage2/3 against the real
+    reference's logits; patches bit-exact."""
+    g = golden("g7_sth_e2e")
+    m, a = _sth_model(dev)
+    gl = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=3)).to(dev)
+    fo = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=4)).view(2, 8, 3, 224, 224).to(dev)
+    forced = torch.from_numpy(g["forced_action"]).to(dev)
+    with torch.no_grad():
+        fm, glog = m.glance(gl)
+        assert np.abs(glog.cpu().numpy() - g["glancer_logit"]).max() < 1e-3     # PyTorch-ROCm producer
+        pred_f, base, patch_f = m.action_stage2(fo, fm, glog, 0, a, prev_local_patch=None, training=False,
+                                                forced_action=forced)
+        pred3, patch3 = m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced)
+        pred, _, patch = m.action_stage2(fo, fm, glog, 0, a, prev_local_patch=None, training=False, with_baseline=False)
+        act = m.focuser.act(fm.view(2, -1, 7, 7), True)
+    assert patch_f.shape == (2, 8, 3, 128, 128) and base.shape == (2, 174)
+    assert np.array_equal(patch_f[:, :, :, :4, :4].cpu().numpy(), g["patch_forced_corner"])
+    assert np.abs(pred_f.cpu().numpy() - g["logits_forced"]).max() < TOL
+    assert np.abs(pred3.cpu().numpy() - g["logits_stage3_forced"]).max() < TOL
+    assert torch.equal(patch3, patch_f)
+    # policy-driven action: continuous output of a PyTorch-ROCm producer; the crop origin floor() may differ
+    # by one pixel if the action lands within float noise of a pixel boundary, so compare when coords agree
+    ref_xy = np.floor(g["policy_action"] * (224 - 128)).astype(np.int32)
+    got_xy = np.floor(act.cpu().numpy() * (224 - 128)).astype(np.int32)
+    assert np.abs(act.cpu().numpy() - g["policy_action"]).max() < 1e-3
+    if np.array_equal(ref_xy, got_xy):
+        assert np.array_equal(patch[:, :, :, :4, :4].cpu().numpy(), g["patch_corner"])
+        assert np.abs(pred.cpu().numpy() - g["logits"]).max() < TOL
+
+
+def test_tsm_glancer_shift_kernel(dev, O):
+    """TemporalShift module in front of a conv (the glancer's use) equals the oracle's shift + conv."""
+    from adafocus_amd.temporal_shift import TemporalShift
+    conv = torch.nn.Conv2d(24, 16, 1, bias=False).to(dev)
+    x = rnd((8, 24, 5, 5), 91)
+    with torch.no_grad():
+        got = TemporalShift(conv, n_segment=4, n_div=8)(x.to(dev)).cpu()
+        ref = torch.nn.functional.conv2d(O.temporal_shift(x, 4, 8), conv.weight.cpu())
+    assert (got - ref).abs().max().item() < 1e-4
