@@ -52,26 +52,47 @@ def synth_model_state(model, seed):
     return {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed).items()}
 
 
+def load_traffic(t, p, b):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json);
+    only reported when it was collected on this very workload."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        w = d["workload"]
+        if (w["frames"], w["patch"], w["batch"]) == (t, p, b):
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sd, t, p, clips, threads):
-    """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host."""
+    """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host.
+    oneDNN convs on this box peak at a modest thread count (measured: 8 threads beat 128 by 5x at 4
+    clips), so a small sweep is run and the BEST rate is reported together with the threads it used."""
     from adafocus_amd import synth
     from oracle import ref_model as O
-    if threads:
-        torch.set_num_threads(threads)
-    cores = torch.get_num_threads()
     frames = torch.from_numpy(synth.synth_frames(clips, t, 224, seed=1)).view(clips * t, 3, 224, 224)
     _, actions = synth.synth_actions(clips * t, 7, seed=2)
     gvec = torch.randn(clips, t, 1280)
-    times = []
+    ncpu = os.cpu_count() or 1
+    sweep = [threads] if threads > 0 else sorted({min(c, ncpu) for c in (8, 16, 32, 64)})
+    best_rate, best_thr, best_t, log = 0.0, sweep[0], 0.0, []
     with torch.no_grad():
-        for i in range(4):
-            t0 = time.perf_counter()
-            O.act_hot_path(sd, frames, gvec, torch.from_numpy(actions), p)
-            times.append(time.perf_counter() - t0)
-    best = float(np.median(times[1:]))
-    return {"value": round(clips / best, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "oracle.act_hot_path (batched crop -> ResNet-50 -> GRU), %d clips x T=%d, P=%d, fp32, "
-                      "median of 3 after 1 warm-up, %.2f s/iter" % (clips, t, p, best)}
+        for th in sweep:
+            torch.set_num_threads(th)
+            times = []
+            for i in range(3):
+                t0 = time.perf_counter()
+                O.act_hot_path(sd, frames, gvec, torch.from_numpy(actions), p)
+                times.append(time.perf_counter() - t0)
+            sec = min(times[1:])
+            log.append("%d thr: %.2f clips/s" % (th, clips / sec))
+            if clips / sec > best_rate:
+                best_rate, best_thr, best_t = clips / sec, th, sec
+    return {"value": round(best_rate, 3), "unit": "clips/s", "cores": best_thr, "kind": "port",
+            "sample": "oracle.act_hot_path (batched crop -> ResNet-50 -> GRU), %d clips x T=%d, P=%d, fp32, best of 2 "
+                      "after 1 warm-up per thread count, %.2f s/iter; sweep on %d logical CPUs: %s"
+                      % (clips, t, p, best_t, ncpu, "; ".join(log))}
 
 
 def main():
@@ -82,7 +103,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--patch", type=int, default=96)
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=16, help="clips in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=2, help="extra per-launch HIP-event passes for the roofline")
     ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy producers)")
@@ -180,7 +201,7 @@ def main():
                     nconv += 1
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": load_traffic(t, p, b),
                            "kernel": "conv_gemm_kernel (implicit-GEMM conv+BN+ReLU, v_mfma_f32_32x32x2_f32), %d launches/step"
                                      % (nconv // max(a.profile_steps, 1)),
                            "avg_launch_ms": round(conv_ms / max(nconv, 1), 4),
