@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadafocus_hip.so")
 
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 CONV_TILES = 4
 
 # every symbol include/adafocus.h declares (tests check the library exports all of them)
@@ -25,6 +25,9 @@ SYMBOLS = (
     "adaf_resnet50_workspace_bytes", "adaf_resnet50_forward", "adaf_resnet50_launch_count",
     "adaf_resnet50_forward_profiled", "adaf_resnet50_set_tiles", "adaf_gru_cls_workspace_bytes",
     "adaf_gru_cls_forward_f32", "adaf_fc_meanpool_forward_f32", "adaf_copy2d_f32",
+    "adaf_pack_dw_weight_f32", "adaf_dwconv3x3_bn_act_f32", "adaf_mobilenetv2_create", "adaf_mobilenetv2_destroy",
+    "adaf_mobilenetv2_set_param", "adaf_mobilenetv2_finalize", "adaf_mobilenetv2_workspace_bytes",
+    "adaf_mobilenetv2_forward", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
 )
 
 
@@ -79,6 +82,17 @@ def load_library():
                                              C.c_size_t, vp]
     lib.adaf_fc_meanpool_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp, C.c_size_t, vp]
     lib.adaf_copy2d_f32.argtypes = [vp, vp, ip, vp, ip, ip, ip, vp]
+    lib.adaf_pack_dw_weight_f32.argtypes = [vp, vp, ip, vp, vp]
+    lib.adaf_dwconv3x3_bn_act_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp]
+    lib.adaf_mobilenetv2_create.argtypes = [vp, C.POINTER(vp)]
+    lib.adaf_mobilenetv2_destroy.argtypes = [vp]
+    lib.adaf_mobilenetv2_set_param.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    lib.adaf_mobilenetv2_finalize.argtypes = [vp, vp]
+    lib.adaf_mobilenetv2_workspace_bytes.restype = C.c_size_t
+    lib.adaf_mobilenetv2_workspace_bytes.argtypes = [vp, ip, ip, ip]
+    lib.adaf_mobilenetv2_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, C.c_size_t, vp]
+    lib.adaf_grid_actions_f32.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp]
+    lib.adaf_gru_seq_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     _lib = lib
     return lib
 

@@ -54,3 +54,8 @@ void adaf_launch_gru_gates(const float* gi, int ldgi_t, const float* gh, const f
 void adaf_launch_segment_mean(const float* logit, int B, int T, int C, const float* glog, int Tg, float* out,
                               hipStream_t s);
 void adaf_launch_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+void adaf_launch_pack_dw_weight(const float* w, int c, float* o, hipStream_t s);
+void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int stride, const float* wt, const float* scale,
+                           const float* bias, int act, float* o, hipStream_t s);
+void adaf_launch_grid_actions(const float* logits, int rows, int a, const float* table, long long* idx, float* act,
+                              hipStream_t s);

@@ -39,7 +39,7 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
     const int ldx = p->ldx ? p->ldx : p->cin, ldo = p->ldo ? p->ldo : p->cout, ldr = p->ldr ? p->ldr : p->cout;
     if (ldx < p->cin || ldo < p->cout || ldr < p->cout) return fail(h, ADAF_E_BADARG, "conv: pixel stride smaller than channels");
     if (ldx % 4 || !aligned16(x) || !aligned16(w)) return fail(h, ADAF_E_LAYOUT, "conv: x/w must be 16-byte aligned, ldx % 4 == 0");
-    if (p->act < ADAF_ACT_NONE || p->act > ADAF_ACT_RELU6) return fail(h, ADAF_E_BADARG, "conv: unknown activation %d", p->act);
+    if (p->act < ADAF_ACT_NONE || p->act > ADAF_ACT_SIGMOID) return fail(h, ADAF_E_BADARG, "conv: unknown activation %d", p->act);
     const int oh = conv_out(p->h, p->kh, p->stride, p->pad), ow = conv_out(p->w, p->kw, p->stride, p->pad);
     if (oh <= 0 || ow <= 0) return fail(h, ADAF_E_BADARG, "conv: empty output");
     const long long M = (long long)p->n * oh * ow;
@@ -496,6 +496,42 @@ static int linear_launch(adaf_handle* h, const float* x, int rows, int ldx, int 
     return ADAF_OK;
 }
 
+// h_t for every step: hs[b, t, :] (row stride ldh between steps of one clip = hidden, between clips = T*hidden)
+static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
+                    const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* gi, float* gh,
+                    float* hs, hipStream_t st) {
+    int rc;
+    // all input projections at once: gi[b*T+t, :] = W_ih x[b,t] + b_ih
+    if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
+    for (int t = 0; t < steps; ++t) {
+        const float* hprev = t ? hs + (size_t)(t - 1) * hidden : nullptr;
+        if (t) {  // gh = W_hh h_{t-1}; rows are strided views into hs
+            if ((rc = linear_launch(h, hprev, batch, steps * hidden, hidden, 3 * hidden, w_hh, nullptr, gh, 0, st))) return rc;
+        }
+        adaf_launch_gru_gates(gi + (size_t)t * 3 * hidden, steps * 3 * hidden, t ? gh : nullptr, b_hh, hprev, steps * hidden,
+                              hs + (size_t)t * hidden, steps * hidden, batch, hidden, st);
+    }
+    return ADAF_OK;
+}
+
+int adaf_gru_seq_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
+                             const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* hs,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (batch == 0) return ADAF_OK;
+    if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !hs || !ws) return fail(h, ADAF_E_BADARG, "gru_seq: null pointer");
+    if (batch < 0 || steps <= 0 || feat <= 0 || hidden <= 0) return fail(h, ADAF_E_BADARG, "gru_seq: non-positive extent");
+    if (ldx == 0) ldx = feat;
+    if (feat % 4 || hidden % 4 || ldx % 4) return fail(h, ADAF_E_LAYOUT, "gru_seq: feat, hidden, ldx must be multiples of 4");
+    if (ws_bytes < adaf_gru_cls_workspace_bytes(batch, steps, hidden)) return fail(h, ADAF_E_NOMEM, "gru_seq: workspace too small");
+    float* gi = static_cast<float*>(ws);
+    float* gh = gi + (size_t)batch * steps * 3 * hidden;
+    int rc = gru_scan(h, x, ldx, batch, steps, feat, hidden, w_ih, w_hh, b_ih, b_hh, gi, gh, hs, (hipStream_t)stream);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "gru_seq forward");
+}
+
 int adaf_gru_cls_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
                              int classes, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                              const float* fc_w, const float* fc_b, float* logits_all, float* last, void* ws,
@@ -512,17 +548,8 @@ int adaf_gru_cls_forward_f32(adaf_handle* h, const float* x, int ldx, int batch,
     float* gi = static_cast<float*>(ws);
     float* gh = gi + (size_t)batch * steps * 3 * hidden;
     float* hs = gh + (size_t)batch * 3 * hidden;  // [B, T, H]
-    int rc;
-    // all input projections at once: gi[b*T+t, :] = W_ih x[b,t] + b_ih
-    if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
-    for (int t = 0; t < steps; ++t) {
-        const float* hprev = t ? hs + (size_t)(t - 1) * hidden : nullptr;
-        if (t) {  // gh = W_hh h_{t-1}; rows are strided views into hs
-            if ((rc = linear_launch(h, hprev, batch, steps * hidden, hidden, 3 * hidden, w_hh, nullptr, gh, 0, st))) return rc;
-        }
-        adaf_launch_gru_gates(gi + (size_t)t * 3 * hidden, steps * 3 * hidden, t ? gh : nullptr, b_hh, hprev, steps * hidden,
-                              hs + (size_t)t * hidden, steps * hidden, batch, hidden, st);
-    }
+    int rc = gru_scan(h, x, ldx, batch, steps, feat, hidden, w_ih, w_hh, b_ih, b_hh, gi, gh, hs, st);
+    if (rc) return rc;
     // logits for every step, then the last step's rows
     if ((rc = linear_launch(h, hs, batch * steps, hidden, hidden, classes, fc_w, fc_b, logits_all, 0, st))) return rc;
     adaf_launch_copy2d(logits_all + (size_t)(steps - 1) * classes, steps * classes, last, classes, batch, classes, st);
@@ -547,6 +574,39 @@ int adaf_fc_meanpool_forward_f32(adaf_handle* h, const float* feat, int batch, i
     adaf_launch_segment_mean(logit, batch, steps, classes, global_logit, global_steps, out, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "fc_meanpool forward");
+}
+
+
+int adaf_pack_dw_weight_f32(adaf_handle* h, const float* w_c133, int channels, float* w_33c, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!w_c133 || !w_33c || channels <= 0) return fail(h, ADAF_E_BADARG, "pack_dw: bad arguments");
+    adaf_launch_pack_dw_weight(w_c133, channels, w_33c, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "pack_dw launch");
+}
+
+int adaf_dwconv3x3_bn_act_f32(adaf_handle* h, const float* x, int n, int hh, int ww, int c, int stride,
+                              const float* w_33c, const float* scale, const float* bias, int act, float* out,
+                              void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!x || !w_33c || !scale || !bias || !out || n <= 0 || hh <= 0 || ww <= 0 || c <= 0) return fail(h, ADAF_E_BADARG, "dwconv: bad arguments");
+    if (stride != 1 && stride != 2) return fail(h, ADAF_E_BADARG, "dwconv: stride must be 1 or 2");
+    if (act < ADAF_ACT_NONE || act > ADAF_ACT_RELU6) return fail(h, ADAF_E_BADARG, "dwconv: activation");
+    if (c % 4 || !aligned16(x) || !aligned16(out) || !aligned16(w_33c) || !aligned16(scale) || !aligned16(bias))
+        return fail(h, ADAF_E_LAYOUT, "dwconv: c %% 4 == 0 and 16-byte alignment required");
+    adaf_launch_dwconv3x3(x, n, hh, ww, c, stride, w_33c, scale, bias, act, out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "dwconv launch");
+}
+
+int adaf_grid_actions_f32(adaf_handle* h, const float* logits, int rows, int n_actions, const float* table_yx,
+                          int64_t* idx_out, float* action_out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (rows == 0) return ADAF_OK;
+    if (!logits || !table_yx || !action_out || rows < 0 || n_actions <= 0) return fail(h, ADAF_E_BADARG, "grid_actions: bad arguments");
+    adaf_launch_grid_actions(logits, rows, n_actions, table_yx, reinterpret_cast<long long*>(idx_out), action_out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "grid_actions launch");
 }
 
 }  // extern "C"

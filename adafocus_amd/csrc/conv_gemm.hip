@@ -22,12 +22,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 
 namespace {
 
+__device__ __forceinline__ float finish_act(float v, bool sig) { return sig ? 1.f / (1.f + expf(-v)) : v; }
+
 // ---- epilogue shared by both kernel families: BN affine, residual, activation ---------------
 // C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0,
                                               int wm, int wn, int lane, int wave) {
-    const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const bool sig = a.act == ADAF_ACT_SIGMOID;
+    const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
     const int crow = 4 * (lane >> 5);
     if (a.vec_epi) {
@@ -69,10 +72,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
                     const int m = m0 + wm * WM + i * 32 + row;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
                     f32x4 o;
-                    o.x = fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, act_lo), act_hi);
-                    o.y = fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi);
-                    o.z = fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi);
-                    o.w = fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi);
+                    o.x = finish_act(fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, act_lo), act_hi), sig);
+                    o.y = finish_act(fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi), sig);
+                    o.z = finish_act(fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi), sig);
+                    o.w = finish_act(fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi), sig);
                     if (n_ok && m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
                 }
             }
@@ -101,7 +104,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                const float v = fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi);
+                const float v = finish_act(fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi), sig);
                 if (n_ok && m < a.M) a.out[(size_t)m * a.ldo + n] = v;
             }
         }
@@ -497,6 +500,7 @@ __global__ void conv_naive_kernel(const ConvArgs a) {
     if (a.res) v += a.res[(size_t)m * a.ldr + n];
     if (a.act == ADAF_ACT_RELU) v = fmaxf(v, 0.f);
     else if (a.act == ADAF_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    else if (a.act == ADAF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
     a.out[(size_t)m * a.ldo + n] = v;
 }
 

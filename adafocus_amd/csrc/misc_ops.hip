@@ -141,6 +141,75 @@ __global__ void segment_mean_kernel(const float* __restrict__ logit, int B, int 
     out[idx] = r;
 }
 
+// [C,1,3,3] (PyTorch depthwise) -> [3][3][C]
+__global__ void pack_dw_weight_kernel(const float* __restrict__ w, int c, float* __restrict__ o) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 9 * c) return;
+    const int ch = idx % c, tap = idx / c;
+    o[idx] = w[ch * 9 + tap];
+}
+
+// Depthwise 3x3 (pad 1, stride 1|2) + BN affine + ReLU6|ReLU|none, NHWC, 4 channels per thread.
+// HBM/LDS-bound VALU work (no contraction across channels, so the matrix cores have nothing to do):
+// the 9 taps of a pixel are 9 aligned 16-byte loads that neighbouring lanes (adjacent channel groups)
+// coalesce; the 3x re-use across rows / columns is served by L1/L2.
+__global__ void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow, int stride,
+                                 const float* __restrict__ wt, const float* __restrict__ scale,
+                                 const float* __restrict__ bias, float lo, float hi, float* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)n * oh * ow * c4;
+    if (idx >= total) return;
+    const int cq = (int)(idx % c4);
+    long long t = idx / c4;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int img = (int)(t / oh);
+    const int c = 4 * c4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride - 1 + ky;
+        if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * stride - 1 + kx;
+            if ((unsigned)ix >= (unsigned)w) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + iy) * w + ix) * (size_t)c + 4 * cq);
+            const f32x4 k = *reinterpret_cast<const f32x4*>(wt + (ky * 3 + kx) * c + 4 * cq);
+            acc.x = fmaf(v.x, k.x, acc.x);
+            acc.y = fmaf(v.y, k.y, acc.y);
+            acc.z = fmaf(v.z, k.z, acc.z);
+            acc.w = fmaf(v.w, k.w, acc.w);
+        }
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
+    const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
+    f32x4 r;
+    r.x = fminf(fmaxf(fmaf(acc.x, sc.x, bi.x), lo), hi);
+    r.y = fminf(fmaxf(fmaf(acc.y, sc.y, bi.y), lo), hi);
+    r.z = fminf(fmaxf(fmaf(acc.z, sc.z, bi.z), lo), hi);
+    r.w = fminf(fmaxf(fmaf(acc.w, sc.w, bi.w), lo), hi);
+    *reinterpret_cast<f32x4*>(o + (size_t)idx * 4) = r;
+}
+
+// Discrete policy head: idx = argmax_a logits[row, a] (first maximum, like Tensor.max(1)[1] --
+// softmax is monotone so the reference's argmax over probabilities is the argmax over logits),
+// action = table[idx]  (ACT/models/ppo.py:94, gfv_net.py:345-347).  One thread per row.
+__global__ void grid_actions_kernel(const float* __restrict__ logits, int rows, int a, const float* __restrict__ table,
+                                    long long* __restrict__ idx_out, float* __restrict__ act_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = logits + (size_t)r * a;
+    int best = 0;
+    float bv = p[0];
+    for (int i = 1; i < a; ++i)
+        if (p[i] > bv) { bv = p[i]; best = i; }
+    if (idx_out) idx_out[r] = best;
+    act_out[2 * r] = table[2 * best];
+    act_out[2 * r + 1] = table[2 * best + 1];
+}
+
 __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,
                               int cols) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,6 +256,25 @@ void adaf_launch_segment_mean(const float* logit, int B, int T, int C, const flo
                               hipStream_t s) {
     hipLaunchKernelGGL(segment_mean_kernel, dim3(blocks_for((long long)B * C)), dim3(256), 0, s, logit, B, T, C, glog, Tg,
                        out);
+}
+
+void adaf_launch_pack_dw_weight(const float* w, int c, float* o, hipStream_t s) {
+    hipLaunchKernelGGL(pack_dw_weight_kernel, dim3(blocks_for(9LL * c)), dim3(256), 0, s, w, c, o);
+}
+
+void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int stride, const float* wt, const float* scale,
+                           const float* bias, int act, float* o, hipStream_t s) {
+    const int oh = (h + 2 - 3) / stride + 1, ow = (w + 2 - 3) / stride + 1;
+    const long long total = (long long)n * oh * ow * (c / 4);
+    const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, stride, wt,
+                       scale, bias, lo, hi, o);
+}
+
+void adaf_launch_grid_actions(const float* logits, int rows, int a, const float* table, long long* idx, float* act,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(grid_actions_kernel, dim3(blocks_for(rows)), dim3(256), 0, s, logits, rows, a, table, idx, act);
 }
 
 void adaf_launch_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {

@@ -7,9 +7,10 @@ Same class names, constructor arguments (`args` fields of ACT/conf/default.yaml)
 state-dict keys as the reference, so its checkpoints load unchanged.  What differs is the
 execution plan of ``GFV.forward(one_step=True)`` (gfv_net.py:95-133):
 
-  reference: for t in range(T): policy step -> python-loop crop (4 .item() syncs per sample) ->
+  reference: glancer; for t in range(T): policy step -> python-loop crop (4 .item() syncs per sample) ->
              ResNet-50 on B patches -> cat;  then GRU
-  here:      policy over all T (its input never depends on local features in eval mode) ->
+  here:      glancer on adaf_mobilenetv2 -> policy over all T on the engine (its input never depends
+             on local features in eval mode) ->
              ONE batched HIP gather of B*T patches (NHWC4) -> ONE ResNet-50 trunk pass over B*T
              patches whose avgpool writes straight into the GRU input matrix -> HIP GRU + FC
 
@@ -84,16 +85,18 @@ class GFV(nn.Module):
     @torch.no_grad()
     def offline_forward(self, images, scan, forced_action_idx=None):
         """images, scan: (B, T*3, H, W) fp32 on the GPU.  Returns (logits (B*T,C), last (B,C),
-        action indices (B,T), feature matrix (B,T,F))."""
+        feature matrix (B,T,F), action indices (B,T))."""
         b, tc, hh, ww = images.shape
         t = tc // 3
-        global_feat_map, global_feat = self.glance(scan)
-        idx = self.focuser.policy.policy_old.act_sequence(global_feat_map)
+        # glancer (adaf_mobilenetv2) -> pixel-major map + 1280-d vectors; policy over all T steps at once
+        fmap, fvec = self.glancer.net.features_nhwc(scan.reshape(b * t, 3, scan.shape[2], scan.shape[3]))
+        table = self.focuser.action_table(images.device)
+        idx, actions = self.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table)
         if forced_action_idx is not None:
             idx = forced_action_idx.to(idx.device)
-        actions = self.focuser._get_standard_action(idx.reshape(-1))[0]
-        return self.hot_path(images.view(b * t, 3, hh, ww), global_feat if self.with_glancer else None, actions, b, t) \
-            + (idx,)
+            actions = table[idx.reshape(-1)]
+        return self.hot_path(images.view(b * t, 3, hh, ww), fvec.view(b, t, -1) if self.with_glancer else None, actions,
+                             b, t) + (idx,)
 
     def hot_path(self, frames, global_feat, actions, b, t):
         """Batched crop -> local CNN -> concat -> classifier: the benchmarked slice.
@@ -109,10 +112,11 @@ class GFV(nn.Module):
         return logits, last, feature
 
     def glance(self, input_prime):
+        """Reference layout: (featmap (B,T,1280,h,w) [a permuted view of the pixel-major map], vec (B,T,1280))."""
         b, tc, hh, ww = input_prime.shape
         t = tc // 3
-        fm, fv = self.glancer(input_prime.view(b * t, 3, hh, ww))
-        return fm.view(b, t, *fm.shape[1:]), fv.view(b, t, -1)
+        fm, fv = self.glancer(input_prime.reshape(b * t, 3, hh, ww))
+        return fm.unflatten(0, (b, t)), fv.view(b, t, -1)
 
     def one_step_act(self, *a, **k):
         raise NotImplementedError("one_step_act is the stage-2 (PPO) training loop body: out of scope")
@@ -175,12 +179,14 @@ class Focuser(nn.Module):
     def standard_actions_set(self):
         return self._tables
 
-    def _get_standard_action(self, action):
+    def action_table(self, device):
         table = self._tables[self.policy_action_dim]
-        if table.device != action.device:
-            table = table.to(action.device)
-            self._tables[self.policy_action_dim] = table
-        return table[action], None
+        if table.device != torch.device(device):
+            table = self._tables[self.policy_action_dim] = table.to(device)
+        return table
+
+    def _get_standard_action(self, action):
+        return self.action_table(action.device)[action], None
 
     def forward(self, *argv, **kwargs):
         """One focuser step with the reference's contract (gfv_net.py:316-331): returns

@@ -65,10 +65,11 @@ class GFV(nn.Module):
 
     # ---- reference surface --------------------------------------------------------------
     def glance(self, input_prime):
+        """Reference layout: featmap (B,T,1280,h,w) as a permuted view of the pixel-major map, logits (B,T,C)."""
         b, tc, hh, ww = input_prime.shape
         t = tc // 3
-        fm, logit = self.glancer(input_prime.view(b * t, 3, hh, ww))
-        return fm.view(b, t, *fm.shape[1:]), logit.view(b, t, -1)
+        fm, logit = self.glancer(input_prime.reshape(b * t, 3, hh, ww))
+        return fm.unflatten(0, (b, t)), logit.view(b, t, -1)
 
     @torch.no_grad()
     def _stage(self, focuser_image, global_feat_map, global_feat_logit, step, args, prev_local_patch, with_baseline,
@@ -80,8 +81,13 @@ class GFV(nn.Module):
         b, _, c, hh, ww = focuser_image.shape
         cur = focuser_image[:, step * nff:(step + 1) * nff].reshape(b * nff, c, hh, ww)
         fb, _, fc_, fh, fw = global_feat_map.shape
-        state = global_feat_map[:, step * nfg:(step + 1) * nfg].reshape(fb, -1, fh, fw)
-        action = self.focuser.act(state, restart_batch=(step == 0))
+        seg = global_feat_map[:, step * nfg:(step + 1) * nfg]
+        if step == 0 and self.focuser.ppo_continuous:
+            # pixel-major view of the map (free when it came from glance()) -> policy on the engine
+            nhwc = seg.permute(0, 1, 3, 4, 2).contiguous().view(fb * nfg, fh, fw, fc_)
+            action = self.focuser.policy.policy_old.act_nhwc(nhwc, fb, nfg)
+        else:
+            action = self.focuser.act(seg.reshape(fb, -1, fh, fw), restart_batch=(step == 0))
         if forced_action is not None:
             action = forced_action.to(action.device)
         p = args.patch_size
@@ -155,8 +161,8 @@ class GFV(nn.Module):
 
 
 class Glancer(nn.Module):
-    """TSM-MobileNetV2 glancer (STH/models/gfv_net.py:228-250): PyTorch-ROCm producer; the shift in front
-    of conv[0] of every residual block runs through the HIP shift kernel."""
+    """TSM-MobileNetV2 glancer (STH/models/gfv_net.py:228-250) on adaf_mobilenetv2; the TemporalShift
+    wrappers exist for state-dict key compatibility, the shift itself is fused into the expand conv."""
 
     def __init__(self, args, skip=False):
         super().__init__()
@@ -164,6 +170,7 @@ class Glancer(nn.Module):
         for m in self.net.modules():
             if isinstance(m, InvertedResidual) and len(m.conv) == 8 and m.use_res_connect:
                 m.conv[0] = TemporalShift(m.conv[0], n_segment=args.num_segments_glancer, n_div=args.shift_div)
+        self.net.tsm_segments, self.net.tsm_div = args.num_segments_glancer, args.shift_div
         self.skip = skip
 
     def forward(self, input):

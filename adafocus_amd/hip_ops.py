@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
 
 
 def _h(t):
@@ -264,3 +264,107 @@ class ResNet50Trunk:
     def set_tiles(self, tiles):
         arr = (C.c_int * len(tiles))(*tiles)
         L.check(self._lib.adaf_resnet50_set_tiles(self._net, arr, len(tiles)), self._h)
+
+
+def pack_dw_weight(w_c133):
+    """PyTorch depthwise weight [C,1,3,3] -> [3,3,C]."""
+    L.need_gpu_f32(w_c133)
+    w = w_c133.contiguous()
+    c = w.shape[0]
+    out = torch.empty((3, 3, c), device=w.device, dtype=torch.float32)
+    h = _h(w)
+    L.check(L.load_library().adaf_pack_dw_weight_f32(h, L.ptr(w), c, L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def dwconv3x3_bn_act(x, w_33c, scale, bias, stride=1, act=ACT_RELU6):
+    """Depthwise 3x3 (pad 1) + BN affine + activation; x (N,H,W,C) NHWC."""
+    L.need_gpu_f32(x, w_33c, scale, bias)
+    x = x.contiguous()
+    n, hh, ww, c = x.shape
+    out = torch.empty((n, (hh - 1) // stride + 1, (ww - 1) // stride + 1, c), device=x.device, dtype=torch.float32)
+    h = _h(x)
+    L.check(L.load_library().adaf_dwconv3x3_bn_act_f32(h, L.ptr(x), n, hh, ww, c, stride, L.ptr(w_33c.contiguous()),
+                                                       L.ptr(scale.contiguous()), L.ptr(bias.contiguous()), act,
+                                                       L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def grid_actions(logits, table):
+    """(rows, A) logits + (A,2) table -> (idx int64 (rows,), actions fp32 (rows,2)); first-max argmax."""
+    L.need_gpu_f32(logits, table)
+    logits = logits.contiguous()
+    rows, a = logits.shape
+    idx = torch.empty((rows,), device=logits.device, dtype=torch.int64)
+    act = torch.empty((rows, 2), device=logits.device, dtype=torch.float32)
+    h = _h(logits)
+    L.check(L.load_library().adaf_grid_actions_f32(h, L.ptr(logits), rows, a, L.ptr(table.contiguous()), L.ptr(idx), L.ptr(act),
+                                                   L.stream_ptr()), h)
+    return idx, act
+
+
+def gru_seq_forward(x, w_ih, w_hh, b_ih, b_hh):
+    """nn.GRU(batch_first=True, h0=0): x (B,T,F) -> hidden states (B,T,H)."""
+    L.need_gpu_f32(x, w_ih, w_hh, b_ih, b_hh)
+    b, t, f = x.shape
+    if x.stride(2) != 1 or x.stride(0) != t * x.stride(1):
+        x = x.contiguous()
+    hid = w_hh.shape[1]
+    lib = L.load_library()
+    ws_bytes = lib.adaf_gru_cls_workspace_bytes(b, t, hid)
+    ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
+    hs = torch.empty((b, t, hid), device=x.device, dtype=torch.float32)
+    h = _h(x)
+    L.check(lib.adaf_gru_seq_forward_f32(h, L.ptr(x), x.stride(1), b, t, f, hid, L.ptr(w_ih.contiguous()),
+                                         L.ptr(w_hh.contiguous()), L.ptr(b_ih.contiguous()), L.ptr(b_hh.contiguous()),
+                                         L.ptr(hs), L.ptr(ws), ws_bytes, L.stream_ptr()), h)
+    return hs
+
+
+class MobileNetV2Net:
+    """adaf_mobilenetv2: the glancer's feature extractor on the conv engine + depthwise kernel."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._h = L.handle(self.device)
+        self._lib = L.load_library()
+        net = C.c_void_p()
+        L.check(self._lib.adaf_mobilenetv2_create(self._h, C.byref(net)), self._h)
+        self._net = net
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_net", None):
+                self._lib.adaf_mobilenetv2_destroy(self._net)
+                self._net = None
+        except Exception:
+            pass
+
+    def load(self, params):
+        """params: neutral name ('stem.weight', 'b3.dw.bn.running_var', ...) -> tensor on this device."""
+        keep = []
+        for name, t in params.items():
+            L.need_gpu_f32(t)
+            t = t.detach().contiguous()
+            keep.append(t)
+            L.check(self._lib.adaf_mobilenetv2_set_param(self._net, name.encode(), L.ptr(t), t.numel()), self._h)
+        L.check(self._lib.adaf_mobilenetv2_finalize(self._net, L.stream_ptr()), self._h)
+        del keep
+
+    def forward(self, frames_nhwc4, tsm_segments=0, tsm_div=8, want_vec=True):
+        """(N,S,S,4) -> featmap (N,S/32,S/32,1280) NHWC, featvec (N,1280) or None."""
+        L.need_gpu_f32(frames_nhwc4)
+        x = frames_nhwc4.contiguous()
+        n, s = x.shape[0], x.shape[1]
+        fs = s
+        for _ in range(5):          # stem + four stride-2 blocks, each a 3x3 / pad 1 / stride 2 window
+            fs = (fs - 1) // 2 + 1
+        fmap = torch.empty((n, fs, fs, 1280), device=x.device, dtype=torch.float32)
+        fvec = torch.empty((n, 1280), device=x.device, dtype=torch.float32) if want_vec else None
+        need = self._lib.adaf_mobilenetv2_workspace_bytes(self._net, n, s, int(tsm_segments))
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty(need // 4, device=self.device, dtype=torch.float32)
+        L.check(self._lib.adaf_mobilenetv2_forward(self._net, L.ptr(x), n, s, int(tsm_segments), int(tsm_div), L.ptr(fmap),
+                                                   L.ptr(fvec), 1280, L.ptr(self._ws), need, L.stream_ptr()), self._h)
+        return fmap, fvec

@@ -1,11 +1,15 @@
 """Glancer backbone (MobileNetV2) with the key layout of ACT/models/mobilenet.py.
 
-Upstream of the named hot path ("next" row f2): in this round it runs as
-stock PyTorch-ROCm modules on the GPU and only PRODUCES the policy input and the 1280-d global
-feature; it is not a fallback for any HIP kernel.  ``get_featmap`` returns
-``(featmap, featmap.mean([2,3]))`` exactly like mobilenet.py:146-148.
+The nn.Modules below only hold parameters under the reference's names; ``get_featmap`` runs on
+``adaf_mobilenetv2`` (expand / project 1x1 convs on the MFMA engine, depthwise 3x3 on the VALU
+kernel -- SURVEY.md §8 a10 / f2) and returns ``(featmap, featmap.mean([2,3]))`` like
+mobilenet.py:146-148.  ``features_nhwc`` is the layout-native fast path the model composition uses.
 """
 from torch import nn
+
+from . import hip_ops
+from .glancer_hip import GlancerEngine
+from .utils import nchw_to_nhwc4
 
 __all__ = ["MobileNetV2", "mobilenet_v2", "InvertedResidual"]
 
@@ -43,13 +47,19 @@ class MobileNetV2(nn.Module):
         feats.append(_cbr(cin, self.last_channel, 1))
         self.features = nn.Sequential(*feats)
         self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(self.last_channel, num_classes))
+        self._engine = GlancerEngine(self, "act")
+
+    def features_nhwc(self, x_nchw):
+        """(N,3,S,S) NCHW frames -> (featmap (N,S/32,S/32,1280) NHWC, mean vector (N,1280))."""
+        return self._engine.features(nchw_to_nhwc4(x_nchw))
 
     def forward(self, x):
-        return self.classifier(self.features(x).mean([2, 3]))
+        lin = self.classifier[-1]
+        return hip_ops.linear(self.features_nhwc(x)[1], lin.weight.detach(), lin.bias.detach())
 
     def get_featmap(self, x):
-        x = self.features(x)
-        return x, x.mean([2, 3])
+        fmap, fvec = self.features_nhwc(x)
+        return fmap.permute(0, 3, 1, 2), fvec
 
     @property
     def feature_dim(self):

@@ -1,7 +1,13 @@
 """Glancer backbone for Something-Something: MobileNetV2 with the key layout of
-STH/models/mobilenetv2.py (flat Sequentials) -- a PyTorch-ROCm producer upstream of the hot path
-(SURVEY.md §8 a10).  ``get_featmap`` returns ``(featmap, classifier(mean))`` as mobilenetv2.py:116-121."""
+STH/models/mobilenetv2.py (flat Sequentials).  The modules hold parameters; ``get_featmap`` runs on
+``adaf_mobilenetv2`` (temporal shift fused into the expand conv of the residual blocks when
+``tsm_segments`` is set by the Glancer) and returns ``(featmap, classifier(mean))`` as
+mobilenetv2.py:116-121."""
 from torch import nn
+
+from . import hip_ops
+from .glancer_hip import GlancerEngine
+from .utils import nchw_to_nhwc4
 
 __all__ = ["MobileNetV2", "mobilenet_v2", "InvertedResidual"]
 
@@ -37,13 +43,18 @@ class MobileNetV2(nn.Module):
         feats.append(nn.Sequential(nn.Conv2d(cin, 1280, 1, 1, 0, bias=False), nn.BatchNorm2d(1280), nn.ReLU6(inplace=True)))
         self.features = nn.Sequential(*feats)
         self.classifier = nn.Linear(1280, n_class)
+        self.tsm_segments, self.tsm_div = 0, 8
+        self._engine = GlancerEngine(self, "sth")
+
+    def features_nhwc(self, x_nchw):
+        return self._engine.features(nchw_to_nhwc4(x_nchw), self.tsm_segments, self.tsm_div)
 
     def forward(self, x):
-        return self.classifier(self.features(x).mean(3).mean(2))
+        return hip_ops.linear(self.features_nhwc(x)[1], self.classifier.weight.detach(), self.classifier.bias.detach())
 
     def get_featmap(self, x):
-        x = self.features(x)
-        return x, self.classifier(x.mean(3).mean(2))
+        fmap, fvec = self.features_nhwc(x)
+        return fmap.permute(0, 3, 1, 2), hip_ops.linear(fvec, self.classifier.weight.detach(), self.classifier.bias.detach())
 
     @property
     def feature_dim(self):

@@ -1,16 +1,19 @@
 """Patch-location policy, inference branch only (ACT/models/ppo.py:27-96,125-145).
 
-The policy is the PRODUCER of the crop coordinates, so bit-exactness of the gather is defined
-relative to its output tensor; it stays a few small PyTorch-ROCm ops and its
-result is handed to the HIP gather without a host round trip.  The PPO update / Memory replay
-logic is training code and out of scope.
+The policy is the PRODUCER of the crop coordinates; its output tensor is handed
+to the HIP gather without a host round trip.  The PPO update / Memory replay logic is training code
+and out of scope.
 
-``ActorCritic.act_sequence`` is the offline-inference form: in eval mode the policy input is only
-the glancer feature map and its own hidden state (ppo.py:67-96), so all T actions are computed
-before any patch is cropped.
+``ActorCritic.act_sequence_nhwc`` is the offline-inference form on the HIP engine: in eval mode the
+policy input is only the glancer feature map and its own hidden state (ppo.py:67-96), so all T
+actions are computed before any patch is cropped -- 1x1 conv + Linear over all B*T frames at once,
+one GRU scan, one actor GEMM, arg-max + table lookup in one small kernel.  ``act`` (one step,
+reference signature) stays a few PyTorch-ROCm ops for API parity.
 """
 import torch
 from torch import nn
+
+from . import hip_ops
 
 __all__ = ["Memory", "ActorCritic", "PPO"]
 
@@ -52,6 +55,35 @@ class ActorCritic(nn.Module):
         state, hidden = self.gru(state.view(1, state.size(0), state.size(1)), memory.hidden[-1])
         memory.hidden.append(hidden)
         return self.actor(state[0]).max(1)[1]
+
+    def _hip_weights(self, hw):
+        """Engine-layout views of the parameters (cached on the parameter versions)."""
+        enc, lin = self.state_encoder[0], self.state_encoder[3]
+        sig = tuple((q.data_ptr(), q._version) for q in (enc.weight, lin.weight))
+        if getattr(self, "_hipw_sig", None) != sig:
+            cmid = enc.weight.shape[0]
+            w_enc = enc.weight.detach().reshape(cmid, 1, 1, -1).contiguous()
+            # reference flattens (B, cmid, h, w) channel-major; the engine's map is pixel-major
+            w_lin = lin.weight.detach().view(-1, cmid, hw).permute(0, 2, 1).reshape(lin.weight.shape[0], hw * cmid).contiguous()
+            self._hipw, self._hipw_sig = (w_enc, w_lin), sig
+        return self._hipw
+
+    @torch.no_grad()
+    def act_sequence_nhwc(self, featmap_nhwc, b, t, table):
+        """featmap (B*T, h, w, C) pixel-major (the HIP glancer's output) -> (idx (B,T) int64,
+        actions (B*T, 2) fp32 = table[idx])."""
+        if not self.policy_conv:
+            raise NotImplementedError("adafocus_amd policy: policy_conv=True (the shipped configs) only")
+        n, hh, ww, _ = featmap_nhwc.shape
+        w_enc, w_lin = self._hip_weights(hh * ww)
+        lin, g, act = self.state_encoder[3], self.gru, self.actor[0]
+        e = hip_ops.conv2d_bn_act(featmap_nhwc, w_enc, act=hip_ops.ACT_RELU)                     # (n, h, w, 32)
+        e = hip_ops.linear(e.view(n, -1), w_lin, lin.bias.detach(), act=hip_ops.ACT_RELU)        # (n, 1024)
+        hs = hip_ops.gru_seq_forward(e.view(b, t, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
+                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach())
+        logits = hip_ops.linear(hs.view(b * t, -1), act.weight.detach(), act.bias.detach())
+        idx, actions = hip_ops.grid_actions(logits, table)
+        return idx.view(b, t), actions
 
     @torch.no_grad()
     def act_sequence(self, states):

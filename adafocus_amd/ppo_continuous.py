@@ -5,6 +5,7 @@ code and absent."""
 import torch
 from torch import nn
 
+from . import hip_ops
 from .ppo import Memory  # noqa: F401  (same class in both reference files)
 
 __all__ = ["ActorCritic", "PPO_Continuous", "Memory"]
@@ -29,6 +30,37 @@ class ActorCritic(nn.Module):
         self.actor = nn.Sequential(nn.Linear(hidden_state_dim, 2), nn.Sigmoid())
         self.critic = nn.Sequential(nn.Linear(hidden_state_dim, 1))
         self.hidden_state_dim, self.policy_conv, self.feature_dim = hidden_state_dim, policy_conv, feature_dim
+
+    @torch.no_grad()
+    def act_nhwc(self, featmap_nhwc, b, tg):
+        """Clip-level action from the HIP glancer's map (B*Tg, h, w, C): the 1x1 conv over the
+        channel-concatenated state (B, Tg*C, h, w) is a (Tg x 1) convolution over the (Tg, h*w) grid of
+        the pixel-major map -- no concatenated tensor is built.  First step only (h0 = 0), which is all
+        video_div = 1 evaluation uses."""
+        if not self.policy_conv:
+            raise NotImplementedError("adafocus_amd policy: policy_conv=True (the shipped configs) only")
+        n, hh, ww, ch = featmap_nhwc.shape
+        hw = hh * ww
+        enc = self.state_encoder
+        with_bn = isinstance(enc[1], nn.BatchNorm2d)
+        conv, lin = enc[0], enc[4 if with_bn else 3]
+        cmid = conv.weight.shape[0]
+        w_enc = conv.weight.detach().view(cmid, tg, 1, ch).contiguous()
+        w_lin = lin.weight.detach().view(-1, cmid, hw).permute(0, 2, 1).reshape(lin.weight.shape[0], hw * cmid).contiguous()
+        sc1 = bi1 = sc2 = None
+        bi2 = lin.bias.detach()
+        if with_bn:
+            sc1, bi1 = hip_ops.fold_bn(enc[1].weight.detach(), enc[1].bias.detach(), enc[1].running_mean, enc[1].running_var)
+            sc2, t2 = hip_ops.fold_bn(enc[5].weight.detach(), enc[5].bias.detach(), enc[5].running_mean, enc[5].running_var)
+            bi2 = lin.bias.detach() * sc2 + t2        # BN1d(Wx + b) = (Wx) * s + (b * s + t)
+        x = featmap_nhwc.view(b, tg, hw, ch)                                   # "image" of Tg rows x hw columns
+        e = hip_ops.conv2d_bn_act(x, w_enc, sc1, bi1, act=hip_ops.ACT_RELU)    # (b, 1, hw, cmid)
+        e = hip_ops.conv2d_bn_act(e.view(b, 1, 1, hw * cmid), w_lin.view(-1, 1, 1, hw * cmid), sc2, bi2, act=hip_ops.ACT_RELU)
+        g = self.gru
+        hs = hip_ops.gru_seq_forward(e.view(b, 1, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
+                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach())
+        a = self.actor[0]
+        return hip_ops.linear(hs.view(b, -1), a.weight.detach(), a.bias.detach(), act=hip_ops.ACT_SIGMOID)
 
     @torch.no_grad()
     def act(self, state_ini, memory, restart_batch=False, training=False):

@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=16, help="clips in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=2, help="extra per-launch HIP-event passes for the roofline")
-    ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy producers)")
+    ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy + hot path)")
     ap.add_argument("--tiles", type=str, default="", help="comma list of per-conv tile overrides (tuning)")
     a = ap.parse_args()
 
@@ -234,8 +234,8 @@ def main():
                         model.offline_forward(scan, scan)
                     torch.cuda.synchronize()
                 res["full_forward"] = {"value": round(3 * b / (time.perf_counter() - t1), 2), "unit": "clips/s",
-                                       "note": "glancer (MobileNetV2) + policy as PyTorch-ROCm producers + hot path"}
-            except Exception as exc:  # producers are outside the path; never fail the bench on them
+                                       "note": "GFV.offline_forward: glancer (adaf_mobilenetv2) + policy on the engine + hot path, 3 iterations"}
+            except Exception as exc:  # upstream of the timed path; never fail the bench on it
                 res["full_forward"] = {"error": repr(exc)[:200]}
         if world == 1 and a.cpu_clips > 0:
             res["cpu_baseline"] = cpu_baseline(sd, t, p, a.cpu_clips, a.cpu_threads)

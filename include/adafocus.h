@@ -43,7 +43,7 @@ enum {
 };
 
 enum { ADAF_LAYOUT_NCHW = 0, ADAF_LAYOUT_NHWC = 1, ADAF_LAYOUT_NHWC4 = 2 /* C=3 padded to 4 with a zero lane */ };
-enum { ADAF_ACT_NONE = 0, ADAF_ACT_RELU = 1, ADAF_ACT_RELU6 = 2 };
+enum { ADAF_ACT_NONE = 0, ADAF_ACT_RELU = 1, ADAF_ACT_RELU6 = 2, ADAF_ACT_SIGMOID = 3 };
 
 typedef struct adaf_handle adaf_handle;
 typedef struct adaf_resnet50 adaf_resnet50;
@@ -157,6 +157,44 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
                                    int* launch_tile);
 /* Kernel-variant override table for tuning: tile[i] as in adaf_conv_params.tile for conv launch i (0 = auto). */
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
+
+/* ---- a10: MobileNetV2 building blocks and the glancer as one object ---------------------
+ * Depthwise 3x3 (pad 1) + BN(eval) + ReLU6 -- the middle conv of InvertedResidual
+ * (ACT/models/mobilenet.py:52-62, STH/models/mobilenetv2.py:36-63).  x [n,hh,ww,c] NHWC, c % 4 == 0,
+ * w_33c [3][3][c] (adaf_pack_dw_weight_f32 from PyTorch's [c,1,3,3]). */
+int adaf_pack_dw_weight_f32(adaf_handle* h, const float* w_c133, int channels, float* w_33c, void* stream);
+int adaf_dwconv3x3_bn_act_f32(adaf_handle* h, const float* x, int n, int hh, int ww, int c, int stride,
+                              const float* w_33c, const float* scale, const float* bias, int act, float* out,
+                              void* stream);
+/* MobileNetV2.features + mean -- ACT/models/mobilenet.py:146-148 (get_featmap), STH/models/mobilenetv2.py:116-121.
+ * Parameter names are layout-neutral ("stem", "b1".."b17" with ".expand/.dw/.project", "head"; each with
+ * ".weight", ".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var"); the Python mirror maps both
+ * reference key layouts onto them.  tsm_segments > 0: temporal shift in front of the expand conv of every
+ * residual block (STH/models/gfv_net.py:238-241).
+ *   frames_nhwc4 [n, size, size, 4]; featmap [n, size/32, size/32, 1280] NHWC; featvec [n, 1280] (row stride ldvec)
+ *   or NULL. */
+typedef struct adaf_mobilenetv2 adaf_mobilenetv2;
+int adaf_mobilenetv2_create(adaf_handle* h, adaf_mobilenetv2** out);
+int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net);
+int adaf_mobilenetv2_set_param(adaf_mobilenetv2* net, const char* name, const float* dev_ptr, size_t numel);
+int adaf_mobilenetv2_finalize(adaf_mobilenetv2* net, void* stream);
+size_t adaf_mobilenetv2_workspace_bytes(const adaf_mobilenetv2* net, int n, int size, int tsm_segments);
+int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, int n, int size, int tsm_segments,
+                             int tsm_div, float* featmap, float* featvec, int ldvec, void* ws, size_t ws_bytes,
+                             void* stream);
+
+/* ---- a11: policy head -------------------------------------------------------------------
+ * idx = argmax_a logits[row, a] (first maximum), action = table_yx[idx] -- the eval branch of
+ * ActorCritic.act (ACT/models/ppo.py:94: action_probs.max(1)[1]; softmax is monotone) followed by
+ * Focuser._get_standard_action (ACT/models/gfv_net.py:345-347).  idx_out (int64) may be NULL. */
+int adaf_grid_actions_f32(adaf_handle* h, const float* logits, int rows, int n_actions, const float* table_yx,
+                          int64_t* idx_out, float* action_out, void* stream);
+/* nn.GRU (batch_first, h0 = 0) over a whole sequence: hs[b, t, :] for every step -- the recurrent part
+ * of the policy (ACT/models/ppo.py:78-79 applied T times) and of the classifier.  Workspace as
+ * adaf_gru_cls_workspace_bytes. */
+int adaf_gru_seq_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
+                             const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* hs,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a7: GRU classifier ----------------------------------------------------------------
  * RecurrentClassifier.forward -- ACT/models/gfv_net.py:427-435 (nn.GRU batch_first, gate order
