@@ -59,3 +59,7 @@ void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int strid
                            const float* bias, int act, float* o, hipStream_t s);
 void adaf_launch_grid_actions(const float* logits, int rows, int a, const float* table, long long* idx, float* act,
                               hipStream_t s);
+void adaf_launch_ingest_u8(const uint8_t* u8, int clips, int T, int H, int W, const float* mean, const float* stdv,
+                           float* out, hipStream_t s);
+void adaf_launch_crop_nhwc4(const float* frames, int nf, int H, int W, const float* act, int fpa, int P, float* out,
+                            int32_t* coords, hipStream_t s);

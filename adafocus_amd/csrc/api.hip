@@ -126,6 +126,37 @@ int adaf_crop_gather_f32(adaf_handle* h, const float* frames, int n_frames, int 
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "crop launch");
 }
 
+int adaf_crop_gather_nhwc4_f32(adaf_handle* h, const float* frames_nhwc4, int n_frames, int height, int width,
+                               const float* action_yx, int n_actions, int frames_per_action, int patch, float* out_nhwc4,
+                               int32_t* coords_out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (n_frames == 0) return ADAF_OK;
+    if (!frames_nhwc4 || !action_yx || !out_nhwc4) return fail(h, ADAF_E_BADARG, "crop_nhwc4: null pointer");
+    if (n_frames < 0 || height <= 0 || width <= 0 || patch <= 0 || frames_per_action <= 0)
+        return fail(h, ADAF_E_BADARG, "crop_nhwc4: non-positive extent");
+    if (patch > height || width < height) return fail(h, ADAF_E_BADARG, "crop_nhwc4: patch > height or width < height");
+    if ((long long)n_actions * frames_per_action != n_frames) return fail(h, ADAF_E_BADARG, "crop_nhwc4: n_actions*frames_per_action != n_frames");
+    if (!aligned16(frames_nhwc4) || !aligned16(out_nhwc4)) return fail(h, ADAF_E_LAYOUT, "crop_nhwc4: 16-byte alignment required");
+    adaf_launch_crop_nhwc4(frames_nhwc4, n_frames, height, width, action_yx, frames_per_action, patch, out_nhwc4, coords_out,
+                           (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "crop_nhwc4 launch");
+}
+
+int adaf_ingest_u8_f32(adaf_handle* h, const uint8_t* clips_hwc, int n_clips, int frames, int height, int width,
+                       const float* mean3, const float* std3, float* out_nhwc4, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (n_clips == 0) return ADAF_OK;
+    if (!clips_hwc || !mean3 || !std3 || !out_nhwc4) return fail(h, ADAF_E_BADARG, "ingest: null pointer");
+    if (n_clips < 0 || frames <= 0 || height <= 0 || width <= 0) return fail(h, ADAF_E_BADARG, "ingest: non-positive extent");
+    if (!aligned16(out_nhwc4)) return fail(h, ADAF_E_LAYOUT, "ingest: output must be 16-byte aligned");
+    for (int c = 0; c < 3; ++c)
+        if (!(std3[c] > 0.f)) return fail(h, ADAF_E_BADARG, "ingest: std must be positive");
+    adaf_launch_ingest_u8(clips_hwc, n_clips, frames, height, width, mean3, std3, out_nhwc4, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "ingest launch");
+}
+
 // ---- conv ------------------------------------------------------------------------------
 int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const float* x, const float* w_ohwi,
                            const float* scale, const float* bias, const float* residual, float* out, void* stream) {

@@ -111,7 +111,67 @@ hipError_t launch_mode(const float* frames, int nf, int C, int H, int W, const f
     return hipGetLastError();
 }
 
+// ---- row f1: uint8 ingest ---------------------------------------------------------------------
+// Loader layout (ACT/ops/transforms.py:305-315 Stack + :318-336 ToTorchFormatTensor): one clip =
+// (H, W, T*3) uint8, frame t's RGB at channels 3t..3t+2.  Output: (clip*T + t, H, W, 4) fp32 with
+//   v = ((float(u8) / 255) - mean[c]) / std[c]        (img.float().div(255); t.sub_(m).div_(s), :64-77)
+// computed with IEEE fp32 divide/subtract in that order (bit-exact with the reference), lane 3 = 0.
+// One thread per source pixel: reads T*3 contiguous bytes, writes one 16-byte pixel into each of the
+// T frames (for a fixed t consecutive lanes write consecutive pixels -> coalesced).
+__global__ void ingest_u8_kernel(const uint8_t* __restrict__ u8, long long pixels, int hw, int T, float m0, float m1,
+                                 float m2, float s0, float s1, float s2, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pixels) return;
+    const long long clip = idx / hw;
+    const int p = (int)(idx - clip * hw);
+    const uint8_t* src = u8 + idx * (3 * T);
+    float* dst = out + ((size_t)clip * T * hw + p) * 4;
+    for (int t = 0; t < T; ++t) {
+        f32x4 v;
+        v.x = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[3 * t + 0], 255.f), m0), s0);
+        v.y = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[3 * t + 1], 255.f), m1), s1);
+        v.z = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[3 * t + 2], 255.f), m2), s2);
+        v.w = 0.f;
+        *reinterpret_cast<f32x4*>(dst + (size_t)t * hw * 4) = v;
+    }
+}
+
+// Patch gather from pixel-major frames (N, H, W, 4) -> (N, P, P, 4): every patch row is one aligned
+// run of P*16 bytes, so this is a strided 2-D copy with 16-byte accesses and no transpose.
+__global__ __launch_bounds__(256) void crop_nhwc4_kernel(const float* __restrict__ frames, int H, int W,
+                                                         const float* __restrict__ act, int fpa, int P,
+                                                         float* __restrict__ out, int32_t* __restrict__ coords) {
+    const int frame = blockIdx.x;
+    const int r0 = blockIdx.y * RB;
+    const int rows = min(RB, P - r0);
+    const int ai = frame / fpa;
+    int y0, x0, ry, rx;
+    window_origin(act, ai, H, W, P, y0, x0, ry, rx);
+    if (coords && blockIdx.y == 0 && threadIdx.x == 0 && frame == ai * fpa) {
+        coords[2 * ai] = ry;
+        coords[2 * ai + 1] = rx;
+    }
+    const float* src = frames + (((size_t)frame * H + y0 + r0) * W + x0) * 4;
+    float* dst = out + ((size_t)frame * P + r0) * (size_t)P * 4;
+    for (int idx = threadIdx.x; idx < rows * P; idx += 256) {
+        const int row = idx / P, x = idx - row * P;
+        *reinterpret_cast<f32x4*>(dst + (size_t)idx * 4) = *reinterpret_cast<const f32x4*>(src + ((size_t)row * W + x) * 4);
+    }
+}
+
 }  // namespace
+
+void adaf_launch_ingest_u8(const uint8_t* u8, int clips, int T, int H, int W, const float* mean, const float* stdv,
+                           float* out, hipStream_t s) {
+    const long long pixels = (long long)clips * H * W;
+    hipLaunchKernelGGL(ingest_u8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, u8, pixels, H * W, T, mean[0],
+                       mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
+}
+
+void adaf_launch_crop_nhwc4(const float* frames, int nf, int H, int W, const float* act, int fpa, int P, float* out,
+                            int32_t* coords, hipStream_t s) {
+    hipLaunchKernelGGL(crop_nhwc4_kernel, dim3(nf, (P + RB - 1) / RB), dim3(256), 0, s, frames, H, W, act, fpa, P, out, coords);
+}
 
 hipError_t adaf_launch_crop(const float* frames, int nf, int C, int H, int W, const float* act, int fpa, int P,
                             float* out, int layout, int32_t* coords, hipStream_t s) {

@@ -98,13 +98,29 @@ class GFV(nn.Module):
         return self.hot_path(images.view(b * t, 3, hh, ww), fvec.view(b, t, -1) if self.with_glancer else None, actions,
                              b, t) + (idx,)
 
+    @torch.no_grad()
+    def offline_forward_nhwc4(self, frames_nhwc4, b, t, forced_action_idx=None):
+        """Same as offline_forward for frames that are already normalised pixel-major (B*T,H,W,4)
+        (``transforms.ingest_uint8``): the glancer and the gather read them directly."""
+        fmap, fvec = self.glancer.net.features_from_nhwc4(frames_nhwc4)
+        table = self.focuser.action_table(frames_nhwc4.device)
+        idx, actions = self.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table)
+        if forced_action_idx is not None:
+            idx = forced_action_idx.to(idx.device)
+            actions = table[idx.reshape(-1)]
+        return self.hot_path(frames_nhwc4, fvec.view(b, t, -1) if self.with_glancer else None, actions, b, t) + (idx,)
+
     def hot_path(self, frames, global_feat, actions, b, t):
         """Batched crop -> local CNN -> concat -> classifier: the benchmarked slice.
-        frames (B*T,3,H,W), global_feat (B,T,1280) or None, actions (B*T,2)."""
+        frames (B*T,3,H,W) [reference layout] or (B*T,H,W,4) [pixel-major], global_feat (B,T,1280) or
+        None, actions (B*T,2)."""
         gdim = global_feat.shape[2] if global_feat is not None else 0
         feature = torch.empty((b, t, gdim + self.focuser.feature_dim), device=frames.device, dtype=torch.float32)
         flat = feature.view(b * t, -1)
-        patches = get_patch_nhwc4(frames, actions, self.patch_size)
+        if frames.shape[-1] == 4 and frames.shape[1] != 3:
+            patches = hip_ops.crop_gather_nhwc4(frames, actions, self.patch_size)
+        else:
+            patches = get_patch_nhwc4(frames, actions, self.patch_size)
         self.focuser.net.features_nhwc4(patches, out=flat[:, gdim:])
         if gdim:
             hip_ops.copy2d(global_feat.reshape(b * t, gdim), flat[:, :gdim])

@@ -368,3 +368,36 @@ class MobileNetV2Net:
         L.check(self._lib.adaf_mobilenetv2_forward(self._net, L.ptr(x), n, s, int(tsm_segments), int(tsm_div), L.ptr(fmap),
                                                    L.ptr(fvec), 1280, L.ptr(self._ws), need, L.stream_ptr()), self._h)
         return fmap, fvec
+
+
+def ingest_u8(clips_hwc_u8, frames, mean, std):
+    """Loader tail fused (ACT/ops/transforms.py:305-336,64-77): (B, H, W, T*3) uint8 stacked clips ->
+    (B*T, H, W, 4) fp32 normalised pixel-major frames (lane 3 = 0)."""
+    if not clips_hwc_u8.is_cuda or clips_hwc_u8.dtype != torch.uint8:
+        raise L.AdafError("ingest_u8: a uint8 tensor on the GPU is required")
+    x = clips_hwc_u8.contiguous()
+    b, hh, ww, c = x.shape
+    if c != 3 * frames:
+        raise ValueError("ingest_u8: last dim %d != 3*frames" % c)
+    out = torch.empty((b * frames, hh, ww, 4), device=x.device, dtype=torch.float32)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    h = _h(x)
+    L.check(L.load_library().adaf_ingest_u8_f32(h, L.ptr(x), b, int(frames), hh, ww, m, s, L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def crop_gather_nhwc4(frames_nhwc4, actions, patch, frames_per_action=1, return_coords=False):
+    """get_patch from pixel-major (N,H,W,4) frames -> (N,P,P,4)."""
+    L.need_gpu_f32(frames_nhwc4, actions)
+    x = frames_nhwc4.contiguous()
+    actions = actions.contiguous()
+    n, hh, ww, _ = x.shape
+    p = int(patch)
+    out = torch.empty((n, p, p, 4), device=x.device, dtype=torch.float32)
+    coords = torch.empty((actions.shape[0], 2), device=x.device, dtype=torch.int32) if return_coords else None
+    h = _h(x)
+    L.check(L.load_library().adaf_crop_gather_nhwc4_f32(h, L.ptr(x), n, hh, ww, L.ptr(actions), actions.shape[0],
+                                                        int(frames_per_action), p, L.ptr(out), L.ptr(coords),
+                                                        L.stream_ptr()), h)
+    return (out, coords) if return_coords else out

@@ -53,6 +53,9 @@ class MobileNetV2(nn.Module):
         """(N,3,S,S) NCHW frames -> (featmap (N,S/32,S/32,1280) NHWC, mean vector (N,1280))."""
         return self._engine.features(nchw_to_nhwc4(x_nchw))
 
+    def features_from_nhwc4(self, frames_nhwc4):
+        return self._engine.features(frames_nhwc4)
+
     def forward(self, x):
         lin = self.classifier[-1]
         return hip_ops.linear(self.features_nhwc(x)[1], lin.weight.detach(), lin.bias.detach())

@@ -78,6 +78,20 @@ int adaf_crop_gather_f32(adaf_handle* h, const float* frames, int n_frames, int 
                          const float* action_yx, int n_actions, int frames_per_action, int patch, float* out,
                          int out_layout, int32_t* coords_out, void* stream);
 
+/* Same gather from frames that are already pixel-major (N, H, W, 4) -- the layout
+ * adaf_ingest_u8_f32 emits and the glancer consumes; output (N, P, P, 4).  Coordinates as above. */
+int adaf_crop_gather_nhwc4_f32(adaf_handle* h, const float* frames_nhwc4, int n_frames, int height, int width,
+                               const float* action_yx, int n_actions, int frames_per_action, int patch, float* out_nhwc4,
+                               int32_t* coords_out, void* stream);
+
+/* ---- f1: frame ingest ---------------------------------------------------------------------
+ * Stack + ToTorchFormatTensor + GroupNormalize -- ACT/ops/transforms.py:305-336,64-77 -- fused:
+ *   clips_hwc [n_clips, height, width, frames*3] uint8 (the loader's stacked clip; frame t = channels 3t..3t+2)
+ *   out_nhwc4 [n_clips*frames, height, width, 4] fp32, value = ((u8 / 255) - mean[c]) / std[c] in IEEE fp32
+ *   (the reference's op order, bit-exact), lane 3 = 0.  mean3 / std3 are HOST arrays of 3 floats. */
+int adaf_ingest_u8_f32(adaf_handle* h, const uint8_t* clips_hwc, int n_clips, int frames, int height, int width,
+                       const float* mean3, const float* std3, float* out_nhwc4, void* stream);
+
 /* ---- a4: fused conv + BN(eval) + residual + activation, implicit GEMM on fp32 MFMA ------
  * Replaces the nn.Conv2d -> nn.BatchNorm2d -> (+identity) -> ReLU sequences of
  * Bottleneck.forward -- ACT/models/resnet.py:94-114, the stem (:212-214), the pointwise

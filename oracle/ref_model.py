@@ -346,3 +346,22 @@ def canonical_resnet_keys(sd, prefix):
         else:
             out[k] = v
     return out
+
+
+# --------------------------------------------------------------------------------------
+# f1: frame ingest (loader tail): Stack -> ToTorchFormatTensor -> GroupNormalize
+# --------------------------------------------------------------------------------------
+INPUT_MEAN = (0.485, 0.456, 0.406)   # GFV.input_mean / input_std, ACT/models/gfv_net.py:29-30
+INPUT_STD = (0.229, 0.224, 0.225)
+
+
+def ingest_uint8(stacked_hwc_u8, mean=INPUT_MEAN, std=INPUT_STD):
+    """stacked (H, W, T*3) uint8 numpy array of one clip -> (T*3, H, W) fp32, the reference's exact op
+    sequence: torch.from_numpy(pic).permute(2,0,1).contiguous().float().div(255)
+    (ACT/ops/transforms.py:325-336) then per channel t.sub_(m).div_(s) with the mean/std lists
+    repeated T times (:69-77)."""
+    img = torch.from_numpy(stacked_hwc_u8).permute(2, 0, 1).contiguous().float().div(255)
+    reps = img.size(0) // len(mean)
+    for t, m, s in zip(img, list(mean) * reps, list(std) * reps):
+        t.sub_(m).div_(s)
+    return img

@@ -483,3 +483,50 @@ def test_policy_on_engine_vs_oracle(dev, O):
         ref = torch.stack(ref, 1)
     assert torch.equal(idx.cpu(), ref)
     assert torch.equal(actions.cpu(), table[ref.reshape(-1)])
+
+
+# ------------------------------------------------------------------------------------ f1: uint8 ingest
+def test_ingest_uint8_bit_exact(dev, ops, O):
+    from adafocus_amd.transforms import ingest_uint8
+    g = golden("g8_ingest")
+    gen8 = np.random.Generator(np.random.PCG64([88, 0xC0]))
+    u8 = gen8.integers(0, 256, size=(40, 56, 4 * 3), dtype=np.uint8)
+    u8[0, 0, :] = 0
+    u8[0, 1, :] = 255
+    out = ingest_uint8(torch.from_numpy(u8)[None].to(dev), 4).cpu()           # (4, 40, 56, 4)
+    chw = out[..., :3].permute(0, 3, 1, 2).reshape(12, 40, 56).contiguous().numpy()
+    assert np.array_equal(_sha(chw), g["sha"])                                 # the real reference's bytes
+    assert float(out[..., 3].abs().max()) == 0.0
+    # all 256 byte values x 3 channels against the oracle, two clips
+    allv = np.arange(256, dtype=np.uint8)
+    u = np.stack([np.tile(allv[:, None, None], (1, 8, 6)), np.tile(allv[::-1, None, None], (1, 8, 6))])   # (2,256,8,6)
+    got = ingest_uint8(torch.from_numpy(u).to(dev), 2).cpu()
+    for b in range(2):
+        ref = O.ingest_uint8(u[b]).view(2, 3, 256, 8)
+        assert torch.equal(got[2 * b:2 * b + 2, ..., :3].permute(0, 3, 1, 2), ref)
+
+
+def test_crop_from_pixel_major_frames(dev, ops, O):
+    fr = rnd((6, 3, 64, 64), 81)
+    a = torch.tensor([[0.0, 1.0], [1.0, 0.0], [0.37, 0.52]])
+    f4 = torch.zeros((6, 64, 64, 4))
+    f4[..., :3] = fr.permute(0, 2, 3, 1)
+    got, coords = ops.crop_gather_nhwc4(f4.to(dev), a.to(dev), 40, 2, return_coords=True)
+    ref = O.get_patch(fr.view(3, 6, 64, 64), a, 40).view(6, 3, 40, 40)
+    assert torch.equal(got.cpu()[..., :3], ref.permute(0, 2, 3, 1))
+    assert torch.equal(coords.cpu(), O.patch_coords(a, 64, 40))
+
+
+def test_act_forward_from_uint8_matches_fp32_path(dev, O):
+    """uint8 loader clips -> ingest -> glancer/policy/gather/trunk/GRU must equal the fp32 NCHW entry
+    point fed with the oracle-normalised frames (same bytes, different layout)."""
+    from adafocus_amd.transforms import ingest_uint8
+    m, _ = _act_model(dev)
+    gen = np.random.Generator(np.random.PCG64([91, 7]))
+    u8 = gen.integers(0, 256, size=(2, 224, 224, 8 * 3), dtype=np.uint8)
+    frames = torch.stack([O.ingest_uint8(u8[b]) for b in range(2)])              # (2, 24, 224, 224) fp32
+    forced = torch.from_numpy(golden("g7_act_e2e")["forced_idx"])
+    with torch.no_grad():
+        l1, last1, _, _ = m.offline_forward(frames.to(dev), frames.to(dev), forced)
+        l2, last2, _, _ = m.offline_forward_nhwc4(ingest_uint8(torch.from_numpy(u8).to(dev), 8), 2, 8, forced)
+    assert torch.equal(l1, l2) and torch.equal(last1, last2)

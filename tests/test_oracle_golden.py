@@ -175,3 +175,15 @@ def test_c_oracle_temporal_shift():
     out = np.empty_like(x)
     lib.ref_temporal_shift(_p(x), 16, 16, 9, 8, 8, _p(out))
     assert np.array_equal(out.reshape(16, 16, 3, 3), g["out_arange"])
+
+
+def test_g8_ingest_uint8():
+    g = golden("g8_ingest")
+    gen8 = np.random.Generator(np.random.PCG64([88, 0xC0]))
+    u8 = gen8.integers(0, 256, size=(40, 56, 4 * 3), dtype=np.uint8)
+    u8[0, 0, :] = 0
+    u8[0, 1, :] = 255
+    out = O.ingest_uint8(u8).numpy()
+    assert out.shape == (12, 40, 56)
+    assert np.array_equal(_sha(out), g["sha"])
+    assert np.array_equal(out[:, :4, :4], g["corner"])

@@ -234,6 +234,16 @@ def gen_act():
         model.focuser.policy.select_action = fake_select
         logits_f, last_f = model(input=frames, scan=frames, training=False, backbone_pred=False, one_step=True,
                                  gpu=None)
+    # ---- G8: loader tail (Stack output -> ToTorchFormatTensor -> GroupNormalize), the reference's own classes
+    import ops.transforms as TR
+    gen8 = np.random.Generator(np.random.PCG64([88, 0xC0]))
+    u8 = gen8.integers(0, 256, size=(40, 56, 4 * 3), dtype=np.uint8)
+    u8[0, 0, :] = 0
+    u8[0, 1, :] = 255
+    norm = TR.GroupNormalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])(TR.ToTorchFormatTensor(div=True)(u8.copy()))
+    save("g8_ingest", seed=np.array([88]), sha=np.frombuffer(hashlib.sha256(np.ascontiguousarray(norm.numpy()).tobytes()).digest(), dtype=np.uint8),
+         corner=norm[:, :4, :4].numpy().copy())
+
     save("g7_act_e2e", seed_weights=np.array([1007]), weights_sha256=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8),
          policy_idx=pol_idx.numpy(), logits=logits.numpy(), last=last.numpy(), forced_idx=forced.numpy(),
          logits_forced=logits_f.numpy(), last_forced=last_f.numpy(), glancer_vec=fv.numpy(),
