@@ -1,0 +1,145 @@
+"""Evaluation harness for the offline-inference path (row f3 of SURVEY.md §8f): the metric and
+meter helpers of ACT/ops/utils.py and the stage-3 branch of ``validate`` (ACT/main_dist.py:307-422),
+with the one thing the reference lacks -- the validation set is SHARDED over ranks and the logits are
+all-gathered (the reference evaluates the whole set on every rank, main_dist.py:239).
+
+Metrics run on the host over the gathered logits exactly as in the reference (they are O(N*C) and not
+on the hot path).  ``cal_map`` keeps the reference's label handling, including its re-ranking of the
+label values that occur in the evaluated set (utils.py:56-60, called with assumes_starts_zero=False).
+"""
+import time
+
+import torch
+import torch.nn.functional as F
+
+from .parallel import gather_variable, shard_range
+
+__all__ = ["AverageMeter", "ProgressMeter", "accuracy", "get_multi_hot", "cal_map", "validate"]
+
+
+class AverageMeter(object):
+    """utils.py:11-33."""
+
+    def __init__(self, name, fmt=":f"):
+        self.name, self.fmt = name, fmt
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+    def __str__(self):
+        return ("{name} {val" + self.fmt + "} ({avg" + self.fmt + "})").format(**self.__dict__)
+
+
+class ProgressMeter(object):
+    """utils.py:95-111."""
+
+    def __init__(self, num_batches, *meters, prefix=""):
+        digits = len(str(num_batches // 1))
+        self.batch_fmtstr = "[{:" + str(digits) + "d}/" + ("{:" + str(digits) + "d}").format(num_batches) + "]"
+        self.meters, self.prefix = meters, prefix
+
+    def print(self, batch, quiet=False):
+        out = "\t".join([self.prefix + self.batch_fmtstr.format(batch)] + [str(m) for m in self.meters])
+        if not quiet:
+            print(out)
+        return out + "\n"
+
+
+def accuracy(output, target, topk=(1,)):
+    """Top-k accuracy in percent (utils.py:35-49)."""
+    with torch.no_grad():
+        maxk = max(topk)
+        _, pred = output.topk(maxk, 1, True, True)
+        correct = pred.t().eq(target.reshape(1, -1).expand(maxk, -1))
+        return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / target.size(0)) for k in topk]
+
+
+def get_multi_hot(test_y, classes, assumes_starts_zero=True):
+    """utils.py:51-66: (N, L) integer labels (-1 = absent) -> (N, classes) multi-hot; with
+    assumes_starts_zero=False the label VALUES present are first re-ranked to 0..K-1 (in place)."""
+    bs = test_y.shape[0]
+    if not assumes_starts_zero:
+        nxt = 0
+        for val in torch.unique(test_y):
+            if val >= 0:
+                test_y[test_y == val] = nxt
+                nxt += 1
+    gt = torch.zeros(bs, classes + 1)        # the extra column absorbs the -1 labels
+    rows = torch.arange(bs)
+    for i in range(test_y.shape[1]):
+        gt[rows, test_y[:, i]] = 1
+    return gt[:, :classes]
+
+
+def cal_map(output, old_test_y):
+    """Mean average precision in percent over softmax scores (utils.py:68-88).  Returns (mAP, per-class AP)."""
+    n, ncls = output.size(0), output.size(1)
+    gt = get_multi_hot(old_test_y.clone(), ncls, False)
+    probs = F.softmax(output, dim=1)
+    rank = torch.arange(1, n + 1).float()
+    ap = torch.zeros(ncls)
+    for k in range(ncls):
+        _, order = torch.sort(probs[:, k], 0, True)
+        truth = gt[:, k][order]
+        precision = truth.float().cumsum(0).div(rank)
+        ap[k] = precision[truth.bool()].sum() / max(float(truth.sum()), 1)
+    return ap.mean() * 100, ap * 100
+
+
+@torch.no_grad()
+def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
+    """Stage-3 evaluation (main_dist.py:307-422, branch :367-371) over this rank's shard of `dataset`
+    (indexable -> (images (T*3,H,W) fp32 | uint8 stacked clip, target (L,) int64)).  Every rank returns the
+    metrics of the WHOLE set: logits and targets are all-gathered once at the end.
+    Returns (top1, top5, mAP, logs)."""
+    bs = batch_size or args.batch_size
+    start, stop = shard_range(len(dataset), rank, world)
+    nb = (stop - start + bs - 1) // bs
+    batch_time, losses = AverageMeter("Time", ":6.3f"), AverageMeter("Loss", ":.4e")
+    top1, top5, mean_ap = AverageMeter("Acc@1", ":6.2f"), AverageMeter("Acc@5", ":6.2f"), AverageMeter("mAP", ":6.2f")
+    progress = ProgressMeter(nb, batch_time, losses, top1, top5, prefix="Test: ")
+    model.eval()
+    dev = device or next(model.parameters()).device
+    logs, preds, step_logits, targets = [], [], [], []
+    end = time.time()
+    for bi, lo in enumerate(range(start, stop, bs)):
+        items = [dataset[i] for i in range(lo, min(lo + bs, stop))]
+        images = torch.stack([it[0] for it in items]).to(dev)
+        target_full = torch.stack([it[1] for it in items])
+        target = target_full[:, 0].to(dev)
+        b = images.shape[0]
+        outputs, pred = model(input=images, scan=images, training=False, backbone_pred=False, one_step=True, gpu=args.gpu)
+        loss = criterion(outputs, target.view(b, -1).expand(b, args.num_segments).reshape(-1))
+        acc1, acc5 = accuracy(pred, target, topk=(1, 5))
+        losses.update(loss.item(), b)
+        top1.update(acc1[0].item(), b)
+        top5.update(acc5[0].item(), b)
+        preds.append(pred)
+        step_logits.append(outputs.reshape(b, args.num_segments, -1))
+        targets.append(target_full.to(dev))
+        batch_time.update(time.time() - end)
+        end = time.time()
+        logs.append(progress.print(bi, quiet=quiet or rank != 0))
+    ncls = args.num_classes
+    empty = torch.zeros((0, ncls), device=dev)
+    all_pred = gather_variable(torch.cat(preds) if preds else empty).cpu()
+    all_tgt = gather_variable(torch.cat(targets) if targets else torch.zeros((0, 1), dtype=torch.int64, device=dev)).cpu()
+    acc1, acc5 = accuracy(all_pred, all_tgt[:, 0], topk=(1, 5))
+    if getattr(args, "dataset", "actnet") == "fcvid":
+        m_ap, _ = cal_map(all_pred, all_tgt)
+    else:
+        m_ap, _ = cal_map(all_pred, all_tgt[:, 0:1])
+    mean_ap.update(float(m_ap), 1)
+    logs.append("mAP: {mAP:.5f}\n".format(mAP=mean_ap.avg))
+    summary = " * Acc@1 {:.5f} Acc@5 {:.5f} mAP {:.5f}".format(acc1[0].item(), acc5[0].item(), mean_ap.avg)
+    if rank == 0 and not quiet:
+        print(summary)
+    logs.append(summary + "\n")
+    return acc1[0].item(), acc5[0].item(), mean_ap.avg, logs

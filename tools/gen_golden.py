@@ -244,6 +244,23 @@ def gen_act():
     save("g8_ingest", seed=np.array([88]), sha=np.frombuffer(hashlib.sha256(np.ascontiguousarray(norm.numpy()).tobytes()).digest(), dtype=np.uint8),
          corner=norm[:, :4, :4].numpy().copy())
 
+    # ---- G9: evaluation metrics over logits (the reference's own accuracy / cal_map)
+    import ops.utils as UT
+    gen9 = np.random.Generator(np.random.PCG64([99, 0xC0]))
+    lg = torch.from_numpy(gen9.standard_normal((300, 20)).astype(np.float32) * 2)
+    tg = torch.from_numpy(gen9.integers(0, 20, size=(300, 1)).astype(np.int64))
+    lg[torch.arange(300), tg[:, 0]] += 1.5                       # make the scores informative
+    a1, a5 = UT.accuracy(lg, tg[:, 0], topk=(1, 5))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m_ap, ap = UT.cal_map(lg, tg)
+        tg2 = torch.cat([tg, torch.full((300, 1), -1, dtype=torch.int64)], 1)
+        tg2[::7, 1] = (tg2[::7, 0] + 3) % 20
+        m_ap2, ap2 = UT.cal_map(lg, tg2)
+    save("g9_metrics", seed=np.array([99]), acc1=a1.numpy(), acc5=a5.numpy(), mAP=np.array([float(m_ap)]), ap=ap.numpy(),
+         mAP_multi=np.array([float(m_ap2)]), ap_multi=ap2.numpy())
+
     save("g7_act_e2e", seed_weights=np.array([1007]), weights_sha256=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8),
          policy_idx=pol_idx.numpy(), logits=logits.numpy(), last=last.numpy(), forced_idx=forced.numpy(),
          logits_forced=logits_f.numpy(), last_forced=last_f.numpy(), glancer_vec=fv.numpy(),
