@@ -164,7 +164,7 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > 32) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (p->tile < 0 || p->tile > 40) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");
@@ -315,11 +315,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     for (int i = 0; i < 5; ++i) buf[i] = static_cast<float*>(ws) + i * slab;
 
     auto mark = [&](double flops, double bytes, int tile) {
-        if (rec) {
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
-            (void)hipEventRecord(e, st);
-            rec->push_back(e);
+        if (rec) {   // events are created up front by the caller: recording is the only work between launches
+            (void)hipEventRecord((*rec)[info->size()], st);
             info->push_back({flops, bytes, tile});
         }
     };
@@ -377,12 +374,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     }
     mark(0.0, 4.0 * ((double)n * hh * ww * 2048 + (double)n * 2048), 0);
     adaf_launch_avgpool(cur, n, hh * ww, 2048, feat, ldfeat, st);
-    if (rec) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        (void)hipEventRecord(e, st);
-        rec->push_back(e);
-    }
+    if (rec) (void)hipEventRecord((*rec)[info->size()], st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "resnet50 forward");
 }
@@ -474,7 +466,8 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
                                    int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream,
                                    float* launch_ms, double* launch_flops, double* launch_bytes, int* launch_tile) {
     if (!net || !launch_ms || !launch_flops || !launch_bytes || !launch_tile) return ADAF_E_BADARG;
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev(adaf_resnet50_launch_count(net) + 1);
+    for (auto& e : ev) (void)hipEventCreate(&e);
     std::vector<Launch> info;
     int rc = run_trunk(net, patches_nhwc4, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream,
                        &ev, &info);
@@ -499,7 +492,7 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
     if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
     for (int i = 0; i < count; ++i) {
-        if (tile[i] < 0 || tile[i] > 32) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        if (tile[i] < 0 || tile[i] > 40) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
         net->tiles[i] = tile[i];
     }
     return ADAF_OK;

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 //   - a wave instruction fills 8 consecutive rows x 128 B; lane -> (row = 8*g + lane/8, slot = lane%8).
 //   - requirements (checked by the launcher): K % 32 == 0; for non-1x1: cin % 32 == 0, KH*KW <= 32.
 //   - 2 LDS stages; per slice: s_waitcnt vmcnt(0) ; s_barrier ; issue DMA for the next slice ; multiply.
-template <int BM, int BN, int WGM, int WGN, bool DENSE>
+template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -381,42 +381,49 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
-    auto issue = [&](int kt, int buf) {
-        float* As = smem + buf * STAGE + wave * 8 * 32;   // + j*NW*8*32 per instruction
-        float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
-#pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[j], (lptr_t)(Bs + j * NW * 8 * 32), 16, 0, 0);
-            pb[j] += step_b[j];
-        }
+    // per-slice wave-uniform state of the NEXT slice's DMA (set by prep)
+    bool nx_tsm = false;
+    int nx_kt = 0, nx_tap = 0;
+    long long nx_toff = 0;
+    auto prep = [&](int kt) {
+        nx_kt = kt;
         if (DENSE) {
-            const bool tsm_slice = a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;   // wave-uniform
-#pragma unroll
-            for (int j = 0; j < AI; ++j) {
-                const float* src = pa[j];
-                if (tsm_slice) {   // this slice holds shifted channels: pick the neighbour frame per chunk
-                    const int c = kt * 32 + qa[j];
-                    if (c < a.tsm_fold) src = (tflag[j] & 2) ? src + tsm_stride : a.zeros;
-                    else if (c < 2 * a.tsm_fold) src = (tflag[j] & 1) ? src - tsm_stride : a.zeros;
-                    if (!(tflag[j] & 4)) src = a.zeros;
-                }
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
-                pa[j] += step_a[j];
-            }
+            nx_tsm = a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;
         } else {
             const int k0 = kt * 32;
-            const int tap = k0 / a.cin;               // wave-uniform: one tap per slice (cin % 32 == 0)
-            const int c0 = k0 - tap * a.cin;
-            const int kh = tap / a.KW;
-            const int kw = tap - kh * a.KW;
-            const long long toff = ((long long)kh * a.W + kw) * a.ldx + c0;
-#pragma unroll
-            for (int j = 0; j < AI; ++j) {
-                const float* src = ((amask[j] >> tap) & 1u) ? a.x + boff[j] + toff : a.zeros;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
-            }
+            nx_tap = k0 / a.cin;                  // one filter tap per slice (cin % 32 == 0)
+            const int c0 = k0 - nx_tap * a.cin;
+            const int kh = nx_tap / a.KW;
+            const int kw = nx_tap - kh * a.KW;
+            nx_toff = ((long long)kh * a.W + kw) * a.ldx + c0;
         }
     };
+    // one DMA instruction: q < BI -> weight rows, else activation rows
+    auto issue_one = [&](int q, int buf) {
+        if (q < BI) {
+            float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[q], (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
+            pb[q] += step_b[q];
+            return;
+        }
+        const int j = q - BI;
+        float* As = smem + buf * STAGE + wave * 8 * 32;
+        const float* src;
+        if (DENSE) {
+            src = pa[j];
+            if (nx_tsm) {   // this slice holds shifted channels: pick the neighbour frame per chunk
+                const int c = nx_kt * 32 + qa[j];
+                if (c < a.tsm_fold) src = (tflag[j] & 2) ? src + tsm_stride : a.zeros;
+                else if (c < 2 * a.tsm_fold) src = (tflag[j] & 1) ? src - tsm_stride : a.zeros;
+                if (!(tflag[j] & 4)) src = a.zeros;
+            }
+            pa[j] += step_a[j];
+        } else {
+            src = ((amask[j] >> nx_tap) & 1u) ? a.x + boff[j] + nx_toff : a.zeros;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
+    };
+    constexpr int NI = AI + BI;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -436,35 +443,54 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     const int b_base = BM * 32 + wn * TN * 32 * 32;
 
     const int nk = a.K / 32;
-    issue(0, 0);
+    prep(0);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) issue_one(q, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for slice kt has landed
         __builtin_amdgcn_s_barrier();                        // ... everyone's has, and slice kt-1 is consumed
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const bool more = kt + 1 < nk;
+        const int nbuf = (kt + 1) & 1;
+        if (more) prep(kt + 1);
         const float* St = smem + (kt & 1) * STAGE;
+        if (!PIPE) {
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < NI; ++q) issue_one(q, nbuf);
+            }
+        }
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foff[0]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            f32x4 af[TM], bf[TN];
+            const int cb = kk & 1, nb = cb ^ 1;
+            if (kk < 3) {   // next fragments are in flight while this step multiplies
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[kk]);
+                for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[kk + 1]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foff[kk]);
+                for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foff[kk + 1]);
+            }
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][s4], bf[cb][j][s4], acc[i][j], 0, 0, 0);
+                if (PIPE && s4 < 2) {
+                    // the DMA for the next slice is issued in the shadow of the MFMAs just queued: slot = 2*kk + s4
+                    if (more) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                        for (int q = 0; q < NI; ++q)
+                            if ((q * 8) / NI == 2 * kk + s4) issue_one(q, nbuf);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
@@ -509,7 +535,7 @@ struct TileShape { int bm, bn; float eff; };
 // Tiles 1..4 are the production shapes; higher ids are variants reachable only through the
 // explicit `tile` override (tools/conv_probe.py).  Ids 21.. use the direct-to-LDS kernel.
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
-    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.00f}, {64, 64, 0.95f}, {64, 128, 0.98f}};
+    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.00f}, {64, 64, 0.97f}, {64, 128, 0.98f}};
 
 template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
@@ -521,14 +547,14 @@ void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, false, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool PIPE>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (dense)
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
 }  // namespace
@@ -556,9 +582,10 @@ bool adaf_conv_glds_ok(const ConvArgs& a) {
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
     if (tile <= 0) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
-        if (adaf_conv_glds_ok(a)) tile += 20;
+        if (adaf_conv_glds_ok(a)) tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
     }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (tile > 30 && !adaf_conv_glds_ok(a)) tile -= 10;
     if (tile > 20 && !adaf_conv_glds_ok(a)) tile = tile - 20 <= 5 ? tile - 20 : 1;   // shape not eligible for the DMA kernel
     switch (tile) {
         case 1: launch_cfg<128, 128, 2, 2, 32, 0>(a, dense, s); break;
@@ -566,13 +593,18 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 3: launch_cfg<64, 64, 2, 2, 32, 0>(a, dense, s); break;
         case 4: launch_cfg<64, 128, 2, 2, 32, 0>(a, dense, s); break;
         case 5: launch_cfg<256, 128, 4, 2, 32, 0>(a, dense, s); break;   // 8 waves, 1 block/CU
-        case 21: launch_glds<128, 128, 2, 2>(a, dense, s); break;
-        case 22: launch_glds<128, 64, 2, 2>(a, dense, s); break;
-        case 23: launch_glds<64, 64, 2, 2>(a, dense, s); break;
-        case 24: launch_glds<64, 128, 2, 2>(a, dense, s); break;
-        case 25: launch_glds<256, 128, 4, 2>(a, dense, s); break;        // 8 waves of 64x64
-        case 26: launch_glds<256, 128, 2, 2>(a, dense, s); break;        // 4 waves of 128x64
-        case 27: launch_glds<256, 256, 2, 4>(a, dense, s); break;        // 8 waves of 128x64
+        case 21: launch_glds<128, 128, 2, 2, false>(a, dense, s); break;
+        case 22: launch_glds<128, 64, 2, 2, false>(a, dense, s); break;
+        case 23: launch_glds<64, 64, 2, 2, false>(a, dense, s); break;
+        case 24: launch_glds<64, 128, 2, 2, false>(a, dense, s); break;
+        case 25: launch_glds<256, 128, 4, 2, false>(a, dense, s); break;        // 8 waves of 64x64
+        case 26: launch_glds<256, 128, 2, 2, false>(a, dense, s); break;        // 4 waves of 128x64
+        case 27: launch_glds<256, 256, 2, 4, false>(a, dense, s); break;        // 8 waves of 128x64
+        case 31: launch_glds<128, 128, 2, 2, true>(a, dense, s); break;   // 3x = 2x with the DMA issued between MFMA groups
+        case 32: launch_glds<128, 64, 2, 2, true>(a, dense, s); break;
+        case 33: launch_glds<64, 64, 2, 2, true>(a, dense, s); break;
+        case 34: launch_glds<64, 128, 2, 2, true>(a, dense, s); break;
+        case 37: launch_glds<256, 256, 2, 4, true>(a, dense, s); break;
         default: return -1;
     }
     return tile;
