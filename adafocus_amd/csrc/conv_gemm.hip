@@ -535,7 +535,7 @@ struct TileShape { int bm, bn; float eff; };
 // Tiles 1..4 are the production shapes; higher ids are variants reachable only through the
 // explicit `tile` override (tools/conv_probe.py).  Ids 21.. use the direct-to-LDS kernel.
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
-    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.00f}, {64, 64, 0.97f}, {64, 128, 0.98f}};
+    {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.02f}, {64, 64, 0.98f}, {64, 128, 0.99f}};
 
 template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
