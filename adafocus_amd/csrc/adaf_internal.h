@@ -63,3 +63,8 @@ void adaf_launch_ingest_u8(const uint8_t* u8, int clips, int T, int H, int W, co
                            float* out, hipStream_t s);
 void adaf_launch_crop_nhwc4(const float* frames, int nf, int H, int W, const float* act, int fpa, int P, float* out,
                             int32_t* coords, hipStream_t s);
+// stem.hip
+void adaf_launch_pack_stem_weight(const float* w_oihw, float* wr, hipStream_t s);
+size_t adaf_stem_weight_floats();
+void adaf_launch_stem7x7(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
+                         int cus, hipStream_t s);

@@ -262,6 +262,7 @@ struct adaf_resnet50 {
     std::map<std::string, std::pair<const float*, size_t>> params;
     std::vector<ConvLayer> convs;  // [0] = stem, then per block conv1, conv2, conv3, (downsample)
     std::vector<int> tiles;        // per conv launch override
+    float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
     bool finalized = false;
 };
 
@@ -343,7 +344,13 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
 
     int hh, ww, rc;
     // stem: conv7x7 s2 + BN + ReLU -> maxpool 3x3 s2
-    if ((rc = conv(x4, P, P, ADAF_ACT_RELU, nullptr, buf[0], 0, &hh, &ww, 0))) return rc;
+    if (net->tiles[0] == 0) {   // specialised stem kernel (tile override != 0 runs it on the generic engine instead)
+        const ConvLayer& L = net->convs[0];
+        hh = ww = conv_out(P, 7, 2, 3);
+        mark(2.0 * (double)n * hh * ww * 64 * 147, 4.0 * ((double)n * P * P * 3 + (double)n * hh * ww * 64 + 64.0 * 147), 40);
+        adaf_launch_stem7x7(x4, n, P, net->stem_w, L.scale, L.bias, buf[0], h->cus, st);
+        ++li;
+    } else if ((rc = conv(x4, P, P, ADAF_ACT_RELU, nullptr, buf[0], 0, &hh, &ww, 0))) return rc;
     const int ph = conv_out(hh, 3, 2, 1), pw = conv_out(ww, 3, 2, 1);
     mark(0.0, 4.0 * ((double)n * hh * ww * 64 + (double)n * ph * pw * 64), 0);
     adaf_launch_maxpool(buf[0], n, hh, ww, 64, buf[1], st);
@@ -394,6 +401,7 @@ int adaf_resnet50_create(adaf_handle* h, adaf_resnet50** out) {
 
 int adaf_resnet50_destroy(adaf_resnet50* net) {
     if (!net) return ADAF_OK;
+    if (net->stem_w) (void)hipFree(net->stem_w);
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
         if (L.scale) (void)hipFree(L.scale);
@@ -436,6 +444,11 @@ int adaf_resnet50_finalize(adaf_resnet50* net, void* stream) {
         if (!L.bias && hipMalloc(reinterpret_cast<void**>(&L.bias), L.cout * sizeof(float)) != hipSuccess) return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc bias");
         adaf_launch_pack_weight(w, L.cout, L.cin, L.k, L.k, L.cin_pad, L.w, st);
         adaf_launch_fold_bn(g, b, m, v, 1e-5f, L.cout, L.scale, L.bias, st);
+        if (&L == &net->convs[0]) {
+            if (!net->stem_w && hipMalloc(reinterpret_cast<void**>(&net->stem_w), adaf_stem_weight_floats() * sizeof(float)) != hipSuccess)
+                return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc stem weights");
+            adaf_launch_pack_stem_weight(w, net->stem_w, st);
+        }
     }
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(h, e, "resnet50 finalize");
