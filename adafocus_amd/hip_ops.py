@@ -226,10 +226,16 @@ class ResNet50Trunk:
         del keep
 
     def _workspace(self, n, patch):
+        """One scratch buffer per HIP stream: passes enqueued on different streams (pipelined batches)
+        must not share intermediates."""
         need = self._lib.adaf_resnet50_workspace_bytes(self._net, n, patch)
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = torch.empty(need // 4, device=self.device, dtype=torch.float32)
-        return self._ws, need
+        key = torch.cuda.current_stream().cuda_stream
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = self._ws[key] = torch.empty(need // 4, device=self.device, dtype=torch.float32)
+        return ws, need
 
     def forward(self, patches_nhwc4, tsm_segments=0, tsm_div=8, out=None):
         """patches (N,P,P,4) -> (N,2048); `out` may be a (N,2048) row-strided view (e.g. the tail of
