@@ -299,7 +299,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 //     Bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index with (row>>1)&7,
 //     applied on the per-lane GLOBAL source address and again on the fragment read.
 //   - a wave instruction fills 8 consecutive rows x 128 B; lane -> (row = 8*g + lane/8, slot = lane%8).
-//   - requirements (checked by the launcher): K % 32 == 0; for non-1x1: cin % 32 == 0, KH*KW <= 32.
+//   - requirements (checked by the launcher): 1x1/stride 1: K % 4 == 0 (a partial last slice is zero-filled);
+//     other filters: cin % 32 == 0, KH*KW <= 32.
 //   - 2 LDS stages; per slice: s_waitcnt vmcnt(0) ; s_barrier ; issue DMA for the next slice ; multiply.
 template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
@@ -368,11 +369,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     }
     const float* pb[BI];
     int step_b[BI];
+    int qb[BI];                 // weight-row source chunk (swizzled) in floats
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int row = (j * NW + wave) * 8 + lr;
         const int n = n0 + row;
         const int q = (ls ^ ((row >> 1) & 7)) * 4;
+        qb[j] = q;
         if (n < a.N) { pb[j] = a.w + (size_t)n * a.K + q; step_b[j] = 32; }
         else { pb[j] = a.zeros; step_b[j] = 0; }
     }
@@ -382,11 +385,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     // per-slice wave-uniform state of the NEXT slice's DMA (set by prep)
-    bool nx_tsm = false;
+    bool nx_tsm = false, nx_tail = false;
     int nx_kt = 0, nx_tap = 0;
     long long nx_toff = 0;
     auto prep = [&](int kt) {
         nx_kt = kt;
+        nx_tail = DENSE && (kt + 1) * 32 > a.K;      // last, partial slice of a K that is not a multiple of 32
         if (DENSE) {
             nx_tsm = a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;
         } else {
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     auto issue_one = [&](int q, int buf) {
         if (q < BI) {
             float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[q], (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
+            const float* srcb = pb[q];
+            if (nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
             pb[q] += step_b[q];
             return;
         }
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                 else if (c < 2 * a.tsm_fold) src = (tflag[j] & 1) ? src - tsm_stride : a.zeros;
                 if (!(tflag[j] & 4)) src = a.zeros;
             }
+            if (nx_tail && nx_kt * 32 + qa[j] >= a.K) src = a.zeros;
             pa[j] += step_a[j];
         } else {
             src = ((amask[j] >> nx_tap) & 1u) ? a.x + boff[j] + nx_toff : a.zeros;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     const int a_base = wm * TM * 32 * 32;
     const int b_base = BM * 32 + wn * TN * 32 * 32;
 
-    const int nk = a.K / 32;
+    const int nk = (a.K + 31) / 32;
     prep(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_one(q, 0);
@@ -574,8 +581,8 @@ int adaf_pick_conv_tile(int M, int N, int K, int cus) {
 
 bool adaf_conv_glds_ok(const ConvArgs& a) {
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
-    if (a.K % 32) return false;
-    if (!dense && (a.cin % 32 || a.KH * a.KW > 32)) return false;
+    if (dense) return a.K % 4 == 0;      // partial last slice is zero-filled
+    if (a.K % 32 || a.cin % 32 || a.KH * a.KW > 32) return false;
     return true;
 }
 

@@ -49,20 +49,22 @@ __global__ void maxpool_kernel(const float* __restrict__ x, int n, int h, int w,
     const int img = (int)(t / oh);
     const float ninf = -__builtin_inff();
     f32x4 best = {ninf, ninf, ninf, ninf};
+    f32x4 v[9];   // unconditional loads from clamped addresses (a clamped tap duplicates a valid one: max is unaffected)
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * oy - 1 + ky;
-        if ((unsigned)iy >= (unsigned)h) continue;
+        const int iy = min(max(2 * oy - 1 + ky, 0), h - 1);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * ox - 1 + kx;
-            if ((unsigned)ix >= (unsigned)w) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + iy) * w + ix) * (size_t)(4 * c4) + 4 * cq);
-            best.x = fmaxf(best.x, v.x);
-            best.y = fmaxf(best.y, v.y);
-            best.z = fmaxf(best.z, v.z);
-            best.w = fmaxf(best.w, v.w);
+            const int ix = min(max(2 * ox - 1 + kx, 0), w - 1);
+            v[ky * 3 + kx] = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + iy) * w + ix) * (size_t)(4 * c4) + 4 * cq);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        best.x = fmaxf(best.x, v[i].x);
+        best.y = fmaxf(best.y, v[i].y);
+        best.z = fmaxf(best.z, v[i].z);
+        best.w = fmaxf(best.w, v[i].w);
     }
     *reinterpret_cast<f32x4*>(o + (size_t)idx * 4) = best;
 }
@@ -149,48 +151,74 @@ __global__ void pack_dw_weight_kernel(const float* __restrict__ w, int c, float*
     o[idx] = w[ch * 9 + tap];
 }
 
-// Depthwise 3x3 (pad 1, stride 1|2) + BN affine + ReLU6|ReLU|none, NHWC, 4 channels per thread.
-// HBM/LDS-bound VALU work (no contraction across channels, so the matrix cores have nothing to do):
-// the 9 taps of a pixel are 9 aligned 16-byte loads that neighbouring lanes (adjacent channel groups)
-// coalesce; the 3x re-use across rows / columns is served by L1/L2.
-__global__ void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow, int stride,
+// Depthwise 3x3 (pad 1, stride 1|2) + BN affine + ReLU6|ReLU|none, NHWC, 4 channels x PX output pixels per thread.
+// HBM/L2-bound VALU work (no contraction across channels, so the matrix cores have nothing to do): taps are
+// aligned 16-byte loads that neighbouring lanes (adjacent channel groups) coalesce; a thread that owns PX
+// horizontally adjacent outputs loads each input column once (stride 1: PX+2 columns instead of 3*PX).
+template <int PX, int S>
+__global__ void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow,
                                  const float* __restrict__ wt, const float* __restrict__ scale,
                                  const float* __restrict__ bias, float lo, float hi, float* __restrict__ o) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)n * oh * ow * c4;
+    const int owg = (ow + PX - 1) / PX;
+    const long long total = (long long)n * oh * owg * c4;
     if (idx >= total) return;
     const int cq = (int)(idx % c4);
     long long t = idx / c4;
-    const int ox = (int)(t % ow);
-    t /= ow;
+    const int oxg = (int)(t % owg);
+    t /= owg;
     const int oy = (int)(t % oh);
     const int img = (int)(t / oh);
     const int c = 4 * c4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int ox0 = oxg * PX;
+    constexpr int NC = S * (PX - 1) + 3;   // input columns the PX outputs touch
+    // every tap is loaded unconditionally from a clamped (always valid) address and zeroed by a select, so
+    // the 3 x NC loads of a thread are independent and issue back to back (no branch, no wait in between)
+    f32x4 v[3][NC];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * stride - 1 + ky;
-        if ((unsigned)iy >= (unsigned)h) continue;
+        const int iy = oy * S - 1 + ky;
+        const bool rv = (unsigned)iy < (unsigned)h;
+        const float* row = x + (((size_t)img * h + min(max(iy, 0), h - 1)) * w) * (size_t)c + 4 * cq;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * stride - 1 + kx;
-            if ((unsigned)ix >= (unsigned)w) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + iy) * w + ix) * (size_t)c + 4 * cq);
-            const f32x4 k = *reinterpret_cast<const f32x4*>(wt + (ky * 3 + kx) * c + 4 * cq);
-            acc.x = fmaf(v.x, k.x, acc.x);
-            acc.y = fmaf(v.y, k.y, acc.y);
-            acc.z = fmaf(v.z, k.z, acc.z);
-            acc.w = fmaf(v.w, k.w, acc.w);
+        for (int ci = 0; ci < NC; ++ci) {
+            const int ix = ox0 * S - 1 + ci;
+            const bool ok = rv && (unsigned)ix < (unsigned)w;
+            const f32x4 ld = *reinterpret_cast<const f32x4*>(row + (size_t)min(max(ix, 0), w - 1) * c);
+            v[ky][ci] = ok ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    f32x4 acc[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 k = *reinterpret_cast<const f32x4*>(wt + (ky * 3 + kx) * c + 4 * cq);
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                const f32x4 a = v[ky][p * S + kx];
+                acc[p].x = fmaf(a.x, k.x, acc[p].x);
+                acc[p].y = fmaf(a.y, k.y, acc[p].y);
+                acc[p].z = fmaf(a.z, k.z, acc[p].z);
+                acc[p].w = fmaf(a.w, k.w, acc[p].w);
+            }
+        }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
     const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
-    f32x4 r;
-    r.x = fminf(fmaxf(fmaf(acc.x, sc.x, bi.x), lo), hi);
-    r.y = fminf(fmaxf(fmaf(acc.y, sc.y, bi.y), lo), hi);
-    r.z = fminf(fmaxf(fmaf(acc.z, sc.z, bi.z), lo), hi);
-    r.w = fminf(fmaxf(fmaf(acc.w, sc.w, bi.w), lo), hi);
-    *reinterpret_cast<f32x4*>(o + (size_t)idx * 4) = r;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int ox = ox0 + p;
+        if (ox < ow) {
+            f32x4 r;
+            r.x = fminf(fmaxf(fmaf(acc[p].x, sc.x, bi.x), lo), hi);
+            r.y = fminf(fmaxf(fmaf(acc[p].y, sc.y, bi.y), lo), hi);
+            r.z = fminf(fmaxf(fmaf(acc[p].z, sc.z, bi.z), lo), hi);
+            r.w = fminf(fmaxf(fmaf(acc[p].w, sc.w, bi.w), lo), hi);
+            *reinterpret_cast<f32x4*>(o + ((((size_t)img * oh + oy) * ow + ox) * (size_t)c + 4 * cq)) = r;
+        }
+    }
 }
 
 // Discrete policy head: idx = argmax_a logits[row, a] (first maximum, like Tensor.max(1)[1] --
@@ -265,11 +293,17 @@ void adaf_launch_pack_dw_weight(const float* w, int c, float* o, hipStream_t s) 
 void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int stride, const float* wt, const float* scale,
                            const float* bias, int act, float* o, hipStream_t s) {
     const int oh = (h + 2 - 3) / stride + 1, ow = (w + 2 - 3) / stride + 1;
-    const long long total = (long long)n * oh * ow * (c / 4);
     const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
     const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, stride, wt,
-                       scale, bias, lo, hi, o);
+    if (stride == 1) {   // 4 outputs share 6 input columns
+        const long long total = (long long)n * oh * ((ow + 3) / 4) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
+                           scale, bias, lo, hi, o);
+    } else {             // 2 outputs share 5 input columns (more would spill the tap registers)
+        const long long total = (long long)n * oh * ((ow + 1) / 2) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<2, 2>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
+                           scale, bias, lo, hi, o);
+    }
 }
 
 void adaf_launch_grid_actions(const float* logits, int rows, int a, const float* table, long long* idx, float* act,
