@@ -229,6 +229,19 @@ def main():
         res["gather"] = {"bound": "hbm", "achieved": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(crop_bytes / (crop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "ms": round(crop_ms, 4), "bytes_per_patch": 2 * 3 * p * p * 4}
+        # BASELINE.json configs[1] (same model at T=8, N=512 patches per step), for reference
+        t8 = t // 2
+        fr8, ac8, gv8 = frames[: b * t8], actions[: b * t8], gvec[:, :t8].contiguous()
+        with torch.no_grad():
+            for i in range(2):
+                model.hot_path(fr8, gv8, ac8, b, t8)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(6):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    model.hot_path(fr8, gv8, ac8, b, t8)
+            torch.cuda.synchronize()
+        res["also"] = {"T%d_P%d_B%d_clips_per_s" % (t8, p, b): round(6 * b / (time.perf_counter() - t1), 1)}
         if os.environ.get("ADAF_BENCH_LAUNCHES"):
             res["launches"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()} for e in per_launch]
         if a.full:
