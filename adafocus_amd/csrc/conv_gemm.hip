@@ -15,6 +15,8 @@
 // one is multiplied.  A lane's ds_read_b128 brings four k-values for its row; MFMA sub-step s
 // consumes element s, so lanes 0-31 cover k = 8kk+s and lanes 32-63 cover k = 8kk+4+s -- the
 // same permutation on A and W, hence an exact (re-ordered) fp32 fma chain.
+#include <type_traits>
+
 #include "adaf_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -302,7 +304,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 //   - requirements (checked by the launcher): 1x1/stride 1: K % 4 == 0 (a partial last slice is zero-filled);
 //     other filters: cin % 32 == 0, KH*KW <= 32.
 //   - 2 LDS stages; per slice: s_waitcnt vmcnt(0) ; s_barrier ; issue DMA for the next slice ; multiply.
-template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE>
+// SPECIAL = the launch has a fused temporal shift or a K that is not a multiple of 32: only then does the DMA
+// issue path carry the per-slice source fix-ups (kept out of the common instantiation so the K loop is
+// straight-line code between the MFMA groups).
+template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE, bool SPECIAL>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -390,9 +395,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     long long nx_toff = 0;
     auto prep = [&](int kt) {
         nx_kt = kt;
-        nx_tail = DENSE && (kt + 1) * 32 > a.K;      // last, partial slice of a K that is not a multiple of 32
+        nx_tail = SPECIAL && DENSE && (kt + 1) * 32 > a.K;      // last, partial slice of a K that is not a multiple of 32
         if (DENSE) {
-            nx_tsm = a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;
+            nx_tsm = SPECIAL && a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;
         } else {
             const int k0 = kt * 32;
             nx_tap = k0 / a.cin;                  // one filter tap per slice (cin % 32 == 0)
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         if (q < BI) {
             float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
             const float* srcb = pb[q];
-            if (nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
+            if (SPECIAL && nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
             __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
             pb[q] += step_b[q];
             return;
@@ -417,13 +422,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         const float* src;
         if (DENSE) {
             src = pa[j];
-            if (nx_tsm) {   // this slice holds shifted channels: pick the neighbour frame per chunk
+            if (SPECIAL && nx_tsm) {   // this slice holds shifted channels: pick the neighbour frame per chunk
                 const int c = nx_kt * 32 + qa[j];
                 if (c < a.tsm_fold) src = (tflag[j] & 2) ? src + tsm_stride : a.zeros;
                 else if (c < 2 * a.tsm_fold) src = (tflag[j] & 1) ? src - tsm_stride : a.zeros;
                 if (!(tflag[j] & 4)) src = a.zeros;
             }
-            if (nx_tail && nx_kt * 32 + qa[j] >= a.K) src = a.zeros;
+            if (SPECIAL && nx_tail && nx_kt * 32 + qa[j] >= a.K) src = a.zeros;
             pa[j] += step_a[j];
         } else {
             src = ((amask[j] >> nx_tap) & 1u) ? a.x + boff[j] + nx_toff : a.zeros;
@@ -453,10 +458,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     prep(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_one(q, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    auto slice = [&](int kt, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;   // compile time: the last slice issues nothing
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for slice kt has landed
         __builtin_amdgcn_s_barrier();                        // ... everyone's has, and slice kt-1 is consumed
-        const bool more = kt + 1 < nk;
         const int nbuf = (kt + 1) & 1;
         if (more) prep(kt + 1);
         const float* St = smem + (kt & 1) * STAGE;
@@ -499,7 +504,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                 }
             }
         }
-    }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
+    slice(nk - 1, std::false_type{});
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
     conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
@@ -558,10 +565,13 @@ template <int BM, int BN, int WGM, int WGN, bool PIPE>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
-    if (dense)
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+    const bool special = a.tsm_T > 0 || (a.K & 31);
+    if (dense && special)
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+    else if (dense)
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, false>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE, false>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
 }  // namespace
