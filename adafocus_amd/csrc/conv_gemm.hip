@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
 
     // per-slice wave-uniform state of the NEXT slice's DMA (set by prep)
     bool nx_tsm = false, nx_tail = false;
-    int nx_kt = 0, nx_tap = 0;
+    int nx_kt = 0, nx_tap = 0, nx_c0 = 0, nx_kh = 0, nx_kw = 0;
     long long nx_toff = 0;
     auto prep = [&](int kt) {
         nx_kt = kt;
@@ -399,12 +399,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         if (DENSE) {
             nx_tsm = SPECIAL && a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;
         } else {
-            const int k0 = kt * 32;
-            nx_tap = k0 / a.cin;                  // one filter tap per slice (cin % 32 == 0)
-            const int c0 = k0 - nx_tap * a.cin;
-            const int kh = nx_tap / a.KW;
-            const int kw = nx_tap - kh * a.KW;
-            nx_toff = ((long long)kh * a.W + kw) * a.ldx + c0;
+            // one filter tap per slice (cin % 32 == 0); prep() is called for kt = 0, 1, 2, ... so the
+            // (tap, channel offset) pair is advanced incrementally -- scalar adds, no division
+            if (kt == 0) { nx_c0 = 0; nx_tap = 0; nx_kh = 0; nx_kw = 0; }
+            else {
+                nx_c0 += 32;
+                if (nx_c0 == a.cin) {
+                    nx_c0 = 0;
+                    ++nx_tap;
+                    if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
+                }
+            }
+            nx_toff = ((long long)nx_kh * a.W + nx_kw) * a.ldx + nx_c0;
         }
     };
     // one DMA instruction: q < BI -> weight rows, else activation rows
