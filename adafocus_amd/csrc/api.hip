@@ -164,7 +164,7 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > 40) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (p->tile < 0 || p->tile > 60) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");
@@ -262,6 +262,7 @@ struct adaf_resnet50 {
     std::map<std::string, std::pair<const float*, size_t>> params;
     std::vector<ConvLayer> convs;  // [0] = stem, then per block conv1, conv2, conv3, (downsample)
     std::vector<int> tiles;        // per conv launch override
+    int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
     float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
     bool finalized = false;
 };
@@ -328,7 +329,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         adaf_conv_params p;
         memset(&p, 0, sizeof(p));
         p.n = n; p.h = hh; p.w = ww; p.cin = L.cin_pad; p.cout = L.cout; p.kh = p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
-        p.act = act; p.tsm_segments = tsm ? tsm_T : 0; p.tsm_div = tsm_div; p.ldo = ldo; p.tile = net->tiles[li];
+        p.act = act; p.tsm_segments = tsm ? tsm_T : 0; p.tsm_div = tsm_div; p.ldo = ldo;
+        p.tile = net->tiles[li] ? net->tiles[li] : (net->math == ADAF_MATH_F32_SPLIT_BF16 ? 40 : 0);
         ConvArgs a;
         int rc = make_conv_args(h, &p, in, L.w, L.scale, L.bias, res, out, &a);
         if (rc) return rc;
@@ -505,9 +507,16 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
     if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
     for (int i = 0; i < count; ++i) {
-        if (tile[i] < 0 || tile[i] > 40) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        if (tile[i] < 0 || tile[i] > 60) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
         net->tiles[i] = tile[i];
     }
+    return ADAF_OK;
+}
+
+int adaf_resnet50_set_math(adaf_resnet50* net, int mode) {
+    if (!net) return ADAF_E_BADARG;
+    if (mode != ADAF_MATH_F32 && mode != ADAF_MATH_F32_SPLIT_BF16) return fail(net->h, ADAF_E_BADARG, "set_math: unknown mode %d", mode);
+    net->math = mode;
     return ADAF_OK;
 }
 

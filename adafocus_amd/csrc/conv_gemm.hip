@@ -21,8 +21,40 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct defeats SROA)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+// ---- fp32 operands on the bf16 matrix pipe (opt-in "split" tiles) -----------------------------------
+// x = h + m + l EXACTLY, each part a bf16 (8 significant bits; the parts are taken by truncation, so the
+// three 8-bit fields tile the 24-bit significand).  The fp32 product x*y is then the sum of nine bf16*bf16
+// products, each exact in the fp32 accumulator's input; the "6" form drops the three terms below 2^-24 |xy|
+// (m*l, l*m, l*l).  Eight consecutive k values of a row -> three registers-quads of packed bf16 pairs.
+__device__ __forceinline__ void split3(const f32x4 v0, const f32x4 v1, u32x4& H, u32x4& M, u32x4& L) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned b0 = __float_as_uint(x[2 * p]), b1 = __float_as_uint(x[2 * p + 1]);
+        h[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);          // {hi16(x0), hi16(x1)}
+        const f32x2 xv = {x[2 * p], x[2 * p + 1]};
+        const f32x2 hv = {__uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+        const f32x2 r1 = xv - hv;                                    // exact
+        const unsigned c0 = __float_as_uint(r1.x), c1 = __float_as_uint(r1.y);
+        m[p] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+        const f32x2 mv = {__uint_as_float(c0 & 0xffff0000u), __uint_as_float(c1 & 0xffff0000u)};
+        const f32x2 r2 = r1 - mv;                                    // exact, <= 8 significant bits left
+        l[p] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
+    }
+    H = u32x4{h[0], h[1], h[2], h[3]};
+    M = u32x4{m[0], m[1], m[2], m[3]};
+    L = u32x4{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ float finish_act(float v, bool sig) { return sig ? 1.f / (1.f + expf(-v)) : v; }
 
@@ -307,7 +339,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // SPECIAL = the launch has a fused temporal shift or a K that is not a multiple of 32: only then does the DMA
 // issue path carry the per-slice source fix-ups (kept out of the common instantiation so the K loop is
 // straight-line code between the MFMA groups).
-template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE, bool SPECIAL>
+// EMU = 0: v_mfma_f32_32x32x2_f32 (the default, exact fp32 FMA chain).  EMU = 6 / 9: the fragments are split into
+// three bf16 parts after the LDS read and multiplied with 6 / 9 v_mfma_f32_32x32x16_bf16 per 16 k (see split3).
+template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE, bool SPECIAL, int EMU>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -459,6 +493,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 32 + ((((2 * kk) ^ (sw & 6)) | hb) << 2);
     const int a_base = wm * TM * 32 * 32;
     const int b_base = BM * 32 + wn * TN * 32 * 32;
+    // split form: k16 step j, lane half h reads chunks 4j + 2h and 4j + 2h + 1 (8 consecutive k of its row)
+    int foffe[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) foffe[j][e] = (lane & 31) * 32 + (((4 * j + 2 * (lane >> 5) + e) ^ sw) << 2);
 
     const int nk = (a.K + 31) / 32;
     prep(0);
@@ -476,6 +516,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
 #pragma unroll
                 for (int q = 0; q < NI; ++q) issue_one(q, nbuf);
             }
+        }
+        if constexpr (EMU != 0) {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                u32x4 ap[3][TM], bp[3][TN];   // [h, m, l]
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    split3(*reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foffe[j2][0]),
+                           *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foffe[j2][1]), ap[0][i], ap[1][i], ap[2][i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    split3(*reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foffe[j2][0]),
+                           *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foffe[j2][1]), bp[0][j], bp[1][j], bp[2][j]);
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
+                // smallest terms first; (A part, B part)
+                constexpr int TA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+                constexpr int TB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 9 - EMU; t < 9; ++t) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(ap[TA[t]][i], bp[TB[t]][j], acc[i][j]);
+                    const int g = j2 * EMU + (t - (9 - EMU));   // MFMA group index within the slice
+                    if (PIPE && g < 8) {
+                        if (more) {
+#pragma unroll
+                            for (int q = 0; q < NI; ++q)
+                                if ((q * 8) / NI == g) issue_one(q, nbuf);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            return;
         }
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -567,17 +642,17 @@ void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, false, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, bool PIPE, int EMU = 0>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
     const bool special = a.tsm_T > 0 || (a.K & 31);
     if (dense && special)
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true, EMU>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else if (dense)
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, false>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, false, EMU>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE, false>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE, false, EMU>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
 }  // namespace
@@ -603,11 +678,21 @@ bool adaf_conv_glds_ok(const ConvArgs& a) {
 }
 
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
+    if (tile == 40) {   // split tiles, automatic: the bigger the wave tile the fewer split instructions per product
+        tile = 0;
+        if (adaf_conv_glds_ok(a)) {
+            const long long blocks = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+            if (a.N <= 64) tile = 42;
+            else if (blocks * 2 >= cus) tile = 41;
+            else tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus) + 40;   // tiny problems: fill the CUs first
+        }
+    }
     if (tile <= 0) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
         if (adaf_conv_glds_ok(a)) tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
     }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (tile > 40 && !adaf_conv_glds_ok(a)) tile = tile % 10 <= 5 ? tile % 10 : 1;   // split tiles exist only in the DMA form
     if (tile > 30 && !adaf_conv_glds_ok(a)) tile -= 10;
     if (tile > 20 && !adaf_conv_glds_ok(a)) tile = tile - 20 <= 5 ? tile - 20 : 1;   // shape not eligible for the DMA kernel
     switch (tile) {
@@ -628,6 +713,18 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 33: launch_glds<64, 64, 2, 2, true>(a, dense, s); break;
         case 34: launch_glds<64, 128, 2, 2, true>(a, dense, s); break;
         case 37: launch_glds<256, 256, 2, 4, true>(a, dense, s); break;
+        // 4x / 5x: fp32 operands split into bf16 parts on the bf16 matrix pipe (6 / 9 products per element pair); opt-in
+        case 41: launch_glds<128, 128, 2, 2, true, 6>(a, dense, s); break;
+        case 42: launch_glds<128, 64, 2, 2, true, 6>(a, dense, s); break;
+        case 43: launch_glds<64, 64, 2, 2, true, 6>(a, dense, s); break;
+        case 44: launch_glds<64, 128, 2, 2, true, 6>(a, dense, s); break;
+        case 45: launch_glds<256, 128, 4, 2, true, 6>(a, dense, s); break;        // 8 waves of 64x64
+        case 46: launch_glds<256, 128, 2, 2, true, 6>(a, dense, s); break;        // 4 waves of 128x64
+        case 47: launch_glds<256, 256, 2, 4, true, 6>(a, dense, s); break;        // 8 waves of 128x64
+        case 51: launch_glds<128, 128, 2, 2, true, 9>(a, dense, s); break;
+        case 52: launch_glds<128, 64, 2, 2, true, 9>(a, dense, s); break;
+        case 53: launch_glds<64, 64, 2, 2, true, 9>(a, dense, s); break;
+        case 54: launch_glds<64, 128, 2, 2, true, 9>(a, dense, s); break;
         default: return -1;
     }
     return tile;

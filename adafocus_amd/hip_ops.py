@@ -9,6 +9,7 @@ import torch
 
 from . import _lib as L
 from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
+from ._lib import MATH_F32, MATH_F32_SPLIT_BF16  # noqa: F401
 
 
 def _h(t):
@@ -270,6 +271,12 @@ class ResNet50Trunk:
     def set_tiles(self, tiles):
         arr = (C.c_int * len(tiles))(*tiles)
         L.check(self._lib.adaf_resnet50_set_tiles(self._net, arr, len(tiles)), self._h)
+
+    def set_math(self, mode):
+        """"f32" (default: fp32 MFMA, exact FMA chain) or "split_bf16" (opt-in: fp32 operands decomposed into three
+        bf16 parts, six bf16 MFMA products per element pair, fp32 accumulate -- include/adafocus.h ADAF_MATH_*)."""
+        code = {"f32": MATH_F32, "split_bf16": MATH_F32_SPLIT_BF16}.get(mode, mode)
+        L.check(self._lib.adaf_resnet50_set_math(self._net, int(code)), self._h)
 
 
 def pack_dw_weight(w_c133):

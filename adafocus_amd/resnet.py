@@ -78,9 +78,17 @@ class ResNet(nn.Module):
         if self._trunk is None or self._trunk.device != dev or sig != self._sig:
             if self._trunk is None or self._trunk.device != dev:
                 self._trunk = hip_ops.ResNet50Trunk(dev)
+                self._trunk.set_math(getattr(self, "_math", "f32"))
             self._trunk.load(params)
             self._sig = sig
         return self._trunk
+
+    def set_math(self, mode):
+        """Opt-in arithmetic of the convolutions: "f32" (default, fp32 matrix pipe) or "split_bf16" (fp32 operands
+        as three exact bf16 parts on the bf16 matrix pipe, fp32 accumulate); no reference counterpart."""
+        self._math = mode
+        if self._trunk is not None:
+            self._trunk.set_math(mode)
 
     # ---- reference surface --------------------------------------------------------------
     def features_nhwc4(self, patches_nhwc4, out=None):

@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=2, help="extra per-launch HIP-event passes for the roofline")
     ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy + hot path)")
+    ap.add_argument("--math", choices=["f32", "split_bf16"], default="f32",
+                    help="conv arithmetic: f32 = fp32 matrix pipe (default, the reported configuration); split_bf16 = opt-in, "
+                         "fp32 operands as three exact bf16 parts on the bf16 matrix pipe, fp32 accumulate")
     ap.add_argument("--tiles", type=str, default="", help="comma list of per-conv tile overrides (tuning)")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed steps + roofline pass (for rocprofv3 runs)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps are round-robined over (batch i+1's "
@@ -144,6 +147,7 @@ def main():
     _, act_np = synth.synth_actions(b * t, 7, seed=2 + rank)
     actions = torch.from_numpy(act_np).to(dev)
     gvec = torch.randn((b, t, 1280), device=dev)
+    model.focuser.net.set_math(a.math)
     trunk = model.focuser.net._sync()
     if a.tiles:
         trunk.set_tiles([int(v) for v in a.tiles.split(",")])
@@ -184,7 +188,9 @@ def main():
     res = {
         "metric": "clips/sec (T=%d, patch=%d^2, ResNet-50 local)" % (t, p), "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if a.math == "f32" else "f32 (operands split into 3 bf16 parts, 6 bf16-MFMA products, f32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "ActivityNet AdaFocus hot path: gather + ResNet-50 local CNN + GRU classifier, "
                                "T=%d, P=%d, B=%d clips/GPU (%d patches/GPU/step), random-init weights seed 1007"
                                % (t, p, b, b * t),
@@ -246,6 +252,25 @@ def main():
                         model.hot_path(fr8, gv8, ac8, b, t8)
                 torch.cuda.synchronize()
             res["also"] = {"T%d_P%d_B%d_clips_per_s" % (t8, p, b): round(6 * b / (time.perf_counter() - t1), 1)}
+        if a.math == "f32" and not a.skip_extras:
+            # opt-in arithmetic (not the reported configuration): same step with the convs on the bf16 matrix pipe
+            with torch.no_grad():
+                ref_logits = model.hot_path(frames, gvec, actions, b, t)[0].clone()
+                model.focuser.net.set_math("split_bf16")
+                alt_logits = model.hot_path(frames, gvec, actions, b, t)[0].clone()
+                for i in range(3):
+                    step(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(10):
+                    step(i)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                model.focuser.net.set_math("f32")
+            res.setdefault("also", {})["opt_in_split_bf16"] = {
+                "clips_per_s": round(10 * b / dt, 1),
+                "max_abs_logit_diff_vs_f32": float((alt_logits - ref_logits).abs().max().item()),
+                "note": "ADAF_MATH_F32_SPLIT_BF16: fp32 operands as three exact bf16 parts, 6 products, fp32 accumulate"}
         if os.environ.get("ADAF_BENCH_LAUNCHES"):
             res["launches"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()} for e in per_launch]
         if a.full and not a.skip_extras:

@@ -110,7 +110,12 @@ typedef struct adaf_conv_params {
     int ldx, ldo, ldr;  /* pixel strides in floats of x / out / residual; 0 = dense (cin / cout / cout) */
     int tile;           /* 0 = choose automatically; otherwise force a kernel variant (tuning / tests):
                            1..4 = 128x128, 128x64, 64x64, 64x128 block tiles with register staging,
-                           21..24 = the same tiles with direct-to-LDS loads, 5 / 25..27 = larger experimental tiles */
+                           21..24 = the same tiles with direct-to-LDS loads, 5 / 25..27 = larger experimental tiles,
+                           31..34 / 37 = direct-to-LDS with the loads issued between the MFMA groups (the default form),
+                           40 = choose automatically among the split tiles, 41..47 / 51..54 = split tiles: fp32
+                           operands decomposed into three bf16 parts after the LDS read and multiplied on the bf16
+                           matrix pipe with 6 (4x) or 9 (5x) products per element pair, fp32 accumulate
+                           (see ADAF_MATH_F32_SPLIT_BF16) */
 } adaf_conv_params;
 
 #define ADAF_CONV_TILES 4
@@ -171,6 +176,15 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
                                    int* launch_tile);
 /* Kernel-variant override table for tuning: tile[i] as in adaf_conv_params.tile for conv launch i (0 = auto). */
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
+/* Arithmetic of the trunk's convolutions (no reference counterpart; the reference is plain fp32).
+ *   ADAF_MATH_F32            (default) v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain per output.
+ *   ADAF_MATH_F32_SPLIT_BF16 (opt-in)  every fp32 operand x is decomposed EXACTLY into bf16 parts h + m + l (three 8-bit
+ *                            fields of its significand) and x*y is accumulated in fp32 from the six bf16 products
+ *                            whose magnitude is >= 2^-24 |xy| on v_mfma_f32_32x32x16_bf16.  Inputs, outputs, weights
+ *                            and the accumulator stay fp32; measured error against an fp64 convolution is not larger
+ *                            than the default's (tools/emu_probe.py).  The stem keeps the default. */
+enum { ADAF_MATH_F32 = 0, ADAF_MATH_F32_SPLIT_BF16 = 1 };
+int adaf_resnet50_set_math(adaf_resnet50* net, int mode);
 
 /* ---- a10: MobileNetV2 building blocks and the glancer as one object ---------------------
  * Depthwise 3x3 (pad 1) + BN(eval) + ReLU6 -- the middle conv of InvertedResidual

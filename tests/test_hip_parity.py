@@ -166,7 +166,8 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 32, 33, 34, 37])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 32, 33, 34, 37,
+                                  40, 41, 42, 43, 44, 45, 46, 47, 51, 52, 53, 54])
 def test_conv_engine_vs_oracle(dev, ops, O, tile):
     for i, (n, h, w, cin, cout, k, s, pad, act, res, tsm) in enumerate(CONV_CASES):
         got, naive, ref = _conv_case(O, ops, dev, n, h, w, cin, cout, k, s, pad, act, res, tile, tsm, seed=i,
@@ -183,6 +184,39 @@ def test_conv_tiles_bit_identical(dev, ops, O):
     outs = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 32, 33, 34, 37)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+def test_conv_split_tiles_bit_identical_and_close_to_fp32(dev, ops, O):
+    """The split tiles (fp32 operands as three exact bf16 parts on the bf16 matrix pipe) share one k / term order, so
+    they agree bit for bit among themselves; against the fp32-MFMA tiles they differ only by accumulation rounding."""
+    six = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (41, 42, 43, 44, 45, 46, 47)]
+    nine = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (51, 52, 53, 54)]
+    for o in six[1:]:
+        assert torch.equal(o, six[0])
+    for o in nine[1:]:
+        assert torch.equal(o, nine[0])
+    native = _conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, 33, seed=99)[0]
+    scale = native.abs().max().item()
+    assert (six[0] - native).abs().max().item() < 2e-5 * scale
+    assert (nine[0] - native).abs().max().item() < 2e-5 * scale
+
+
+def test_conv_split_error_vs_fp64_not_worse_than_fp32(dev, ops):
+    """Error against an fp64 convolution: the six-product split form must be as accurate as the fp32 matrix pipe
+    (wide dynamic range, non-negative activations so nothing cancels)."""
+    g = torch.Generator().manual_seed(5)
+    n, hw, cin, cout = 16, 6, 512, 256
+    x = torch.randn((n, hw, hw, cin), generator=g).abs_() * torch.exp(torch.randn((n, hw, hw, cin), generator=g))
+    w = torch.randn((cout, 3, 3, cin), generator=g) * (1.0 / (9 * cin) ** 0.5)
+    y64 = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, 1, 1).permute(0, 2, 3, 1)
+    rms = y64.pow(2).mean().sqrt().item()
+    one, zero = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    err = {}
+    for t in (33, 43, 53):
+        y = ops.conv2d_bn_act(x.to(dev), w.to(dev), one, zero, None, 1, 1, ops.ACT_NONE, tile=t).cpu().double()
+        err[t] = ((y - y64).pow(2).mean().sqrt().item() / rms, (y - y64).abs().max().item() / rms)
+    assert err[43][0] <= 1.25 * err[33][0] and err[53][0] <= 1.25 * err[33][0], err
+    assert err[43][1] < 1e-4 and err[33][1] < 1e-4, err
 
 
 def test_conv_rejects_bad_arguments(dev, ops):
@@ -253,6 +287,24 @@ def test_resnet50_trunk_vs_oracle(dev, O, p, tsm):
     err = (got - ref).abs().max().item()
     assert err < 3e-4, err
     assert ref.abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("p,tsm", [(96, 0), (128, 8), (100, 0)])
+def test_resnet50_trunk_split_math_vs_oracle(dev, O, p, tsm):
+    """Opt-in ADAF_MATH_F32_SPLIT_BF16: same tolerance as the default arithmetic."""
+    net, sd = _trunk(dev, 1007 + p)
+    net.set_math("split_bf16")
+    net.tsm_segments = tsm
+    n = 8 if p != 100 else 5
+    x = rnd((n, 3, p, p), 300 + p)
+    with torch.no_grad():
+        got = net.get_featvec(x.to(dev)).cpu()
+        net.set_math("f32")
+        native = net.get_featvec(x.to(dev)).cpu()
+        ref = O.resnet50_trunk(sd, "", x, tsm_segments=tsm).view(n, -1)
+    assert (got - ref).abs().max().item() < 3e-4
+    assert (native - ref).abs().max().item() < 3e-4
+    assert not torch.equal(got, native)      # the mode really switched kernels
 
 
 def test_resnet50_batch_invariance_full_size(dev):
