@@ -18,6 +18,7 @@ struct adaf_handle {
 struct ConvArgs {
     const float* x;
     const float* w;      // [N][K] with K ordered (kh, kw, cin)
+    const unsigned short* wsp;  // optional: the same weights as three bf16 planes [3][N][K] (h, m, l parts; split tiles 6x)
     const float* scale;  // may be null (= 1)
     const float* bias;   // may be null (= 0)
     const float* res;    // may be null
@@ -43,6 +44,7 @@ hipError_t adaf_launch_crop(const float* frames, int nf, int C, int H, int W, co
                             float* out, int layout, int32_t* coords, hipStream_t s);
 
 // misc_ops.hip
+void adaf_launch_split_weight(const float* w, size_t count, unsigned short* planes, hipStream_t s);
 void adaf_launch_pack_weight(const float* w, int cout, int cin, int kh, int kw, int cin_pad, float* o, hipStream_t s);
 void adaf_launch_fold_bn(const float* g, const float* b, const float* m, const float* v, float eps, int c,
                          float* scale, float* bias, hipStream_t s);

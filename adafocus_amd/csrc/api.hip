@@ -52,6 +52,7 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
         fold = p->cin / p->tsm_div;
         if (fold % 4) return fail(h, ADAF_E_LAYOUT, "conv: temporal-shift fold=%d must be a multiple of 4", fold);
     }
+    a->wsp = nullptr;
     a->x = x; a->w = w; a->scale = scale; a->bias = bias; a->res = res; a->out = out;
     a->M = (int)M; a->N = p->cout; a->K = p->kh * p->kw * p->cin;
     a->cin = p->cin; a->H = p->h; a->W = p->w; a->OH = oh; a->OW = ow; a->KH = p->kh; a->KW = p->kw;
@@ -164,7 +165,7 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > 60) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (p->tile < 0 || p->tile > 70) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");
@@ -253,6 +254,7 @@ struct ConvLayer {
     int cin, cout, k, stride, pad;
     int cin_pad;
     float* w = nullptr;    // packed OHWI
+    unsigned short* wsp = nullptr;   // the same as three bf16 planes (ADAF_MATH_F32_SPLIT_BF16 only)
     float* scale = nullptr;
     float* bias = nullptr;
 };
@@ -334,6 +336,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         ConvArgs a;
         int rc = make_conv_args(h, &p, in, L.w, L.scale, L.bias, res, out, &a);
         if (rc) return rc;
+        a.wsp = net->math == ADAF_MATH_F32_SPLIT_BF16 ? L.wsp : nullptr;
         const double macs = (double)a.M * L.cout * L.k * L.k * L.cin;   // algorithmic: un-padded cin
         const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
         mark(2.0 * macs, bytes, 0);
@@ -406,6 +409,7 @@ int adaf_resnet50_destroy(adaf_resnet50* net) {
     if (net->stem_w) (void)hipFree(net->stem_w);
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
+        if (L.wsp) (void)hipFree(L.wsp);
         if (L.scale) (void)hipFree(L.scale);
         if (L.bias) (void)hipFree(L.bias);
     }
@@ -417,6 +421,22 @@ int adaf_resnet50_set_param(adaf_resnet50* net, const char* name, const float* d
     if (!net || !name || !dev_ptr) return ADAF_E_BADARG;
     net->params[name] = std::make_pair(dev_ptr, numel);
     net->finalized = false;
+    return ADAF_OK;
+}
+
+// Three bf16 planes of every packed filter bank except the stem's (idempotent; used by the split tiles 6x).
+static int split_weights(adaf_resnet50* net, void* stream) {
+    adaf_handle* h = net->h;
+    hipStream_t st = (hipStream_t)stream;
+    for (size_t i = 1; i < net->convs.size(); ++i) {
+        ConvLayer& L = net->convs[i];
+        const size_t wn = (size_t)L.cout * L.k * L.k * L.cin_pad;
+        if (!L.wsp && hipMalloc(reinterpret_cast<void**>(&L.wsp), 3 * wn * sizeof(unsigned short)) != hipSuccess)
+            return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc split weights");
+        adaf_launch_split_weight(L.w, wn, L.wsp, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(h, e, "resnet50 split weights");
     return ADAF_OK;
 }
 
@@ -455,6 +475,7 @@ int adaf_resnet50_finalize(adaf_resnet50* net, void* stream) {
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(h, e, "resnet50 finalize");
     net->finalized = true;
+    if (net->math == ADAF_MATH_F32_SPLIT_BF16) return split_weights(net, stream);
     return ADAF_OK;
 }
 
@@ -507,7 +528,7 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
     if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
     for (int i = 0; i < count; ++i) {
-        if (tile[i] < 0 || tile[i] > 60) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        if (tile[i] < 0 || tile[i] > 70) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
         net->tiles[i] = tile[i];
     }
     return ADAF_OK;
@@ -517,6 +538,7 @@ int adaf_resnet50_set_math(adaf_resnet50* net, int mode) {
     if (!net) return ADAF_E_BADARG;
     if (mode != ADAF_MATH_F32 && mode != ADAF_MATH_F32_SPLIT_BF16) return fail(net->h, ADAF_E_BADARG, "set_math: unknown mode %d", mode);
     net->math = mode;
+    if (mode == ADAF_MATH_F32_SPLIT_BF16 && net->finalized) return split_weights(net, nullptr);
     return ADAF_OK;
 }
 

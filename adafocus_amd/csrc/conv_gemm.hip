@@ -341,12 +341,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // straight-line code between the MFMA groups).
 // EMU = 0: v_mfma_f32_32x32x2_f32 (the default, exact fp32 FMA chain).  EMU = 6 / 9: the fragments are split into
 // three bf16 parts after the LDS read and multiplied with 6 / 9 v_mfma_f32_32x32x16_bf16 per 16 k (see split3).
-template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE, bool SPECIAL, int EMU>
+// BSP (split tiles only): the weights come pre-split as three bf16 planes (ConvArgs::wsp); their LDS image is
+// [plane][BN rows][64 B] with the 16-byte chunk index XOR-ed with (row>>2)&3, and a fragment is one ds_read_b128.
+template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE, bool SPECIAL, int EMU, bool BSP = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);   // DMA instructions per wave per slice
-    constexpr int STAGE = (BM + BN) * 32;
+    constexpr int AI = BM / (8 * NW);                                   // DMA instructions per wave per slice
+    constexpr int BI = BSP ? (3 * BN / 16) / NW : BN / (8 * NW);
+    constexpr int STAGE = BM * 32 + BN * (BSP ? 48 : 32);
+    static_assert(!BSP || (EMU != 0 && (3 * BN / 16) % NW == 0), "pre-split weights: split tiles only");
     constexpr int SLAB = NW * 32 * (TN * 32 + 4);
     constexpr int SMEM = 2 * STAGE > SLAB ? 2 * STAGE : SLAB;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "staging shape");
@@ -411,12 +415,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     int qb[BI];                 // weight-row source chunk (swizzled) in floats
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-        const int row = (j * NW + wave) * 8 + lr;
-        const int n = n0 + row;
-        const int q = (ls ^ ((row >> 1) & 7)) * 4;
-        qb[j] = q;
-        if (n < a.N) { pb[j] = a.w + (size_t)n * a.K + q; step_b[j] = 32; }
-        else { pb[j] = a.zeros; step_b[j] = 0; }
+        if (BSP) {
+            // instruction u = j*NW + wave fills LDS floats [u*256, u*256+256): plane u / (BN/16), rows 16*(u % (BN/16)) .. +15
+            const int u = j * NW + wave;
+            const int plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2);
+            const int n = n0 + row;
+            const int q = ((lane & 3) ^ ((row >> 2) & 3)) * 8;   // bf16 elements
+            qb[j] = q;
+            if (n < a.N) {
+                pb[j] = reinterpret_cast<const float*>(a.wsp + ((size_t)plane * a.N + n) * a.K + q);
+                step_b[j] = 16;   // 32 bf16 = 16 floats per slice
+            } else { pb[j] = a.zeros; step_b[j] = 0; }
+        } else {
+            const int row = (j * NW + wave) * 8 + lr;
+            const int n = n0 + row;
+            const int q = (ls ^ ((row >> 1) & 7)) * 4;
+            qb[j] = q;
+            if (n < a.N) { pb[j] = a.w + (size_t)n * a.K + q; step_b[j] = 32; }
+            else { pb[j] = a.zeros; step_b[j] = 0; }
+        }
     }
     const long long tsm_stride = (long long)a.tsm_hw * a.ldx;
 
@@ -450,9 +467,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     // one DMA instruction: q < BI -> weight rows, else activation rows
     auto issue_one = [&](int q, int buf) {
         if (q < BI) {
-            float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
+            float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;   // 8 rows x 128 B = 16 rows x 64 B = 256 floats per instruction
             const float* srcb = pb[q];
-            if (SPECIAL && nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
+            if (!BSP && SPECIAL && nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
             __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
             pb[q] += step_b[q];
             return;
@@ -499,6 +516,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 2; ++e) foffe[j][e] = (lane & 31) * 32 + (((4 * j + 2 * (lane >> 5) + e) ^ sw) << 2);
+    int foffb[2];   // pre-split weights: row (lane&31) of a 64-byte-row plane, chunk (2j + lane>>5) ^ ((row>>2)&3)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) foffb[j] = (lane & 31) * 16 + ((((2 * j + (lane >> 5)) ^ ((lane >> 2) & 3)) & 3) << 2);
 
     const int nk = (a.K + 31) / 32;
     prep(0);
@@ -526,9 +546,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                     split3(*reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foffe[j2][0]),
                            *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foffe[j2][1]), ap[0][i], ap[1][i], ap[2][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    split3(*reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foffe[j2][0]),
-                           *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foffe[j2][1]), bp[0][j], bp[1][j], bp[2][j]);
+                for (int j = 0; j < TN; ++j) {
+                    if (BSP) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            bp[pl][j] = *reinterpret_cast<const u32x4*>(St + BM * 32 + pl * BN * 16 + (wn * TN + j) * 32 * 16 + foffb[j2]);
+                    } else {
+                        split3(*reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foffe[j2][0]),
+                               *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foffe[j2][1]), bp[0][j], bp[1][j], bp[2][j]);
+                    }
+                }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);
                 // smallest terms first; (A part, B part)
                 constexpr int TA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
@@ -642,17 +669,17 @@ void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, false, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool PIPE, int EMU = 0>
+template <int BM, int BN, int WGM, int WGN, bool PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
     const bool special = a.tsm_T > 0 || (a.K & 31);
     if (dense && special)
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true, EMU>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true, EMU, BSP>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else if (dense)
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, false, EMU>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, false, EMU, BSP>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE, false, EMU>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, PIPE, false, EMU, BSP>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
 }  // namespace
@@ -678,6 +705,7 @@ bool adaf_conv_glds_ok(const ConvArgs& a) {
 }
 
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
+    const bool bsp_ok = a.wsp != nullptr && (a.K & 31) == 0 && adaf_conv_glds_ok(a);
     if (tile == 40) {   // split tiles, automatic: the bigger the wave tile the fewer split instructions per product
         tile = 0;
         if (adaf_conv_glds_ok(a)) {
@@ -685,8 +713,10 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
             if (a.N <= 64) tile = 42;
             else if (blocks * 2 >= cus) tile = 41;
             else tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus) + 40;   // tiny problems: fill the CUs first
+            if (bsp_ok) tile = tile == 41 ? 65 : tile + 20;   // weights pre-split: waves of 32x128 split the fewest activations per product
         }
     }
+    if (tile > 60 && !bsp_ok) tile = tile == 65 ? 41 : tile - 20;
     if (tile <= 0) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
         if (adaf_conv_glds_ok(a)) tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
@@ -721,6 +751,12 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 45: launch_glds<256, 128, 4, 2, true, 6>(a, dense, s); break;        // 8 waves of 64x64
         case 46: launch_glds<256, 128, 2, 2, true, 6>(a, dense, s); break;        // 4 waves of 128x64
         case 47: launch_glds<256, 256, 2, 4, true, 6>(a, dense, s); break;        // 8 waves of 128x64
+        // 6x: split tiles with the weights pre-split at load time (ConvArgs::wsp)
+        case 61: launch_glds<128, 128, 2, 2, true, 6, true>(a, dense, s); break;
+        case 62: launch_glds<128, 64, 2, 2, true, 6, true>(a, dense, s); break;
+        case 63: launch_glds<64, 64, 2, 2, true, 6, true>(a, dense, s); break;
+        case 64: launch_glds<64, 128, 2, 2, true, 6, true>(a, dense, s); break;
+        case 65: launch_glds<128, 128, 4, 1, true, 6, true>(a, dense, s); break;   // waves of 32x128: fewest activation splits per product
         case 51: launch_glds<128, 128, 2, 2, true, 9>(a, dense, s); break;
         case 52: launch_glds<128, 64, 2, 2, true, 9>(a, dense, s); break;
         case 53: launch_glds<64, 64, 2, 2, true, 9>(a, dense, s); break;

@@ -248,6 +248,24 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __r
 
 }  // namespace
 
+// fp32 -> three bf16 planes (h, m, l) with h + m + l == w exactly (truncation split, see split3 in conv_gemm.hip)
+__global__ void split_weight_kernel(const float* __restrict__ w, size_t count, unsigned short* __restrict__ planes) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float x = w[i];
+    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    planes[i] = (unsigned short)(hb >> 16);
+    planes[count + i] = (unsigned short)(mb >> 16);
+    planes[2 * count + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+void adaf_launch_split_weight(const float* w, size_t count, unsigned short* planes, hipStream_t s) {
+    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, w, count, planes);
+}
+
 void adaf_launch_pack_weight(const float* w, int cout, int cin, int kh, int kw, int cin_pad, float* o, hipStream_t s) {
     const long long total = (long long)cout * kh * kw * cin_pad;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks_for(total)), dim3(256), 0, s, w, cout, cin, kh, kw, cin_pad, o);

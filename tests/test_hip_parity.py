@@ -307,6 +307,22 @@ def test_resnet50_trunk_split_math_vs_oracle(dev, O, p, tsm):
     assert not torch.equal(got, native)      # the mode really switched kernels
 
 
+def test_resnet50_split_math_presplit_weights_bit_identical(dev):
+    """Tiles 6x read the weights pre-split at load time; tiles 4x split them on the fly: same parts, same order."""
+    net, _ = _trunk(dev, 1007)
+    net.set_math("split_bf16")
+    x = rnd((8, 3, 96, 96), 77).to(dev)
+    trunk = net._sync()
+    outs = []
+    with torch.no_grad():
+        for t in (0, 41, 42, 43, 61, 62, 63, 64, 65):
+            trunk.set_tiles([0] + [t] * 52)
+            outs.append(net.get_featvec(x).clone())
+    trunk.set_tiles([0] * 53)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_resnet50_batch_invariance_full_size(dev):
     """BASELINE size (N = 1024 patches of 96^2): the tile choice changes with the problem size but
     the fp32 fma chain per output does not, so a patch's feature must be bit-identical whether it
