@@ -524,6 +524,83 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     prep(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_one(q, 0);
+
+    if constexpr (EMU != 0 && BSP) {
+        // ---- production schedule of the split tiles: fragments always one k16 step ahead, ONE barrier per slice placed
+        // between its two steps.  At the barrier T_k every wave has (a) read all of slice k out of LDS, (b) seen its own
+        // DMA of slice k+1 land -- so after it buffer k&1 can take slice k+2 and slice k+1's first fragments can be read
+        // while slice k's second step multiplies.
+        constexpr int TA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};   // (A part, B part) of the products, smallest first
+        constexpr int TB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+        f32x4 ar[2][TM][2];        // raw fp32 activation fragments of a step (8 consecutive k per lane)
+        u32x4 bq[2][3][TN];        // pre-split weight fragments [h, m, l]
+        auto rd = [&](int sb, const float* St, int j2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ar[sb][i][0] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foffe[j2][0]);
+                ar[sb][i][1] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foffe[j2][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bq[sb][pl][j] = *reinterpret_cast<const u32x4*>(St + BM * 32 + pl * BN * 16 + (wn * TN + j) * 32 * 16 + foffb[j2]);
+        };
+        auto mm = [&](int sb, auto dma_tag, int nbuf) {
+            constexpr bool dma = decltype(dma_tag)::value;
+            u32x4 ap[3][TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) split3(ar[sb][i][0], ar[sb][i][1], ap[0][i], ap[1][i], ap[2][i]);
+#pragma unroll
+            for (int t = 9 - EMU; t < 9; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(ap[TA[t]][i], bq[sb][TB[t]][j], acc[i][j]);
+                if (dma) {
+                    const int g = t - (9 - EMU);
+#pragma unroll
+                    for (int q = 0; q < NI; ++q)
+                        if ((q * EMU) / NI == g) issue_one(q, nbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (nk > 1) {
+            prep(1);
+#pragma unroll
+            for (int q = 0; q < NI; ++q) issue_one(q, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");   // slice 0 landed, slice 1 still in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        rd(0, smem, 0);
+        auto body = [&](int k, auto has1_tag, auto has2_tag) {
+            constexpr bool has1 = decltype(has1_tag)::value, has2 = decltype(has2_tag)::value;
+            const float* St = smem + (k & 1) * STAGE;
+            rd(1, St, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0, std::false_type{}, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of slice k+1 landed, own reads of slice k done
+                __builtin_amdgcn_s_barrier();                                   // T_k
+                rd(0, smem + ((k + 1) & 1) * STAGE, 0);
+                if (has2) prep(k + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1, has2_tag, k & 1);
+        };
+        int k = 0;
+        for (; k + 2 < nk; ++k) body(k, std::true_type{}, std::true_type{});
+        if (nk > 1) { body(k, std::true_type{}, std::false_type{}); ++k; }
+        body(k, std::false_type{}, std::false_type{});
+        __syncthreads();
+        conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+        return;
+    }
+
     auto slice = [&](int kt, auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;   // compile time: the last slice issues nothing
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for slice kt has landed
@@ -716,7 +793,7 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
             if (bsp_ok) tile = tile == 41 ? 65 : tile + 20;   // weights pre-split: waves of 32x128 split the fewest activations per product
         }
     }
-    if (tile > 60 && !bsp_ok) tile = tile == 65 ? 41 : tile - 20;
+    if (tile > 60 && !bsp_ok) tile = tile >= 65 ? 41 : tile - 20;
     if (tile <= 0) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
         if (adaf_conv_glds_ok(a)) tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
@@ -757,6 +834,8 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 63: launch_glds<64, 64, 2, 2, true, 6, true>(a, dense, s); break;
         case 64: launch_glds<64, 128, 2, 2, true, 6, true>(a, dense, s); break;
         case 65: launch_glds<128, 128, 4, 1, true, 6, true>(a, dense, s); break;   // waves of 32x128: fewest activation splits per product
+        case 66: launch_glds<256, 128, 8, 1, true, 6, true>(a, dense, s); break;   // 8 waves of 32x128: 30 % less L2->LDS traffic per product
+        case 67: launch_glds<256, 128, 4, 2, true, 6, true>(a, dense, s); break;   // 8 waves of 64x64
         case 51: launch_glds<128, 128, 2, 2, true, 9>(a, dense, s); break;
         case 52: launch_glds<128, 64, 2, 2, true, 9>(a, dense, s); break;
         case 53: launch_glds<64, 64, 2, 2, true, 9>(a, dense, s); break;

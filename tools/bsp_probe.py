@@ -33,7 +33,7 @@ def run(tiles):
 ref, base = run([0] * nconv)
 print("auto (split math): %.3f ms" % sum(base), flush=True)
 res = {}
-for t in (41, 42, 61, 62, 63, 64, 65):
+for t in (41, 42, 61, 62, 63, 64, 65, 66, 67):
     out, res[t] = run([0] + [t] * (nconv - 1))
     print("all tile %d: %.3f ms  bit-identical to auto: %s" % (t, sum(res[t]), bool(torch.equal(out, ref))), flush=True)
 best = list(base)
@@ -45,4 +45,4 @@ for i in range(len(base)):
 print("best per launch: %.3f ms" % sum(best))
 print("picks:", pick)
 for i in range(len(base)):
-    print(i, "%.4f" % base[i], " ".join("%.4f" % res[t][i] for t in (41, 42, 61, 62, 63, 64, 65)))
+    print(i, "%.4f" % base[i], " ".join("%.4f" % res[t][i] for t in (41, 42, 61, 62, 63, 64, 65, 66, 67)))
