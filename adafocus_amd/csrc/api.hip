@@ -165,7 +165,7 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > 70) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (p->tile < 0 || p->tile > 80) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");
@@ -528,7 +528,7 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
     if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
     for (int i = 0; i < count; ++i) {
-        if (tile[i] < 0 || tile[i] > 70) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        if (tile[i] < 0 || tile[i] > 80) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
         net->tiles[i] = tile[i];
     }
     return ADAF_OK;

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // three bf16 parts after the LDS read and multiplied with 6 / 9 v_mfma_f32_32x32x16_bf16 per 16 k (see split3).
 // BSP (split tiles only): the weights come pre-split as three bf16 planes (ConvArgs::wsp); their LDS image is
 // [plane][BN rows][64 B] with the 16-byte chunk index XOR-ed with (row>>2)&3, and a fragment is one ds_read_b128.
-template <int BM, int BN, int WGM, int WGN, bool DENSE, bool PIPE, bool SPECIAL, int EMU, bool BSP = false>
+template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -601,6 +601,72 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         return;
     }
 
+    if constexpr (EMU == 0 && PIPE == 2) {
+        // ---- fp32 pipe, barrier between steps 2 and 3 of a slice: at T_k every wave has read all of slice k (step 3's
+        // fragments were fetched during step 2) and seen its DMA of slice k+1 land, so step 3 multiplies while the first
+        // fragments of slice k+1 are already being read -- no LDS latency is exposed behind a barrier.  DMA of slice k+2:
+        // first half during step 3 of slice k, second half during step 0 of slice k+1.
+        constexpr int QH = NI / 2;
+        f32x4 af[2][TM], bf[2][TN];
+        auto rdf = [&](int pb_, const float* St, int kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[pb_][i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[pb_][j] = *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foff[kk]);
+        };
+        auto mul = [&](int cb, auto dma_tag, int qlo, int qhi, int nbuf) {
+            constexpr bool dma = decltype(dma_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][s4], bf[cb][j][s4], acc[i][j], 0, 0, 0);
+                if (dma) {
+#pragma unroll
+                    for (int q = 0; q < NI; ++q)
+                        if (q >= qlo && q < qhi && ((q - qlo) * 4) / (qhi - qlo) == s4) issue_one(q, nbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nk > 1) {
+            prep(1);
+#pragma unroll
+            for (int q = 0; q < QH; ++q) issue_one(q, 1);
+        }
+        rdf(0, smem, 0);
+        auto body = [&](int k, auto has1_tag, auto has2_tag) {
+            constexpr bool has1 = decltype(has1_tag)::value, has2 = decltype(has2_tag)::value;
+            const float* St = smem + (k & 1) * STAGE;
+            const int nb1 = (k + 1) & 1;
+            rdf(1, St, 1);
+            mul(0, has1_tag, QH, NI, nb1);          // second half of the DMA of slice k+1
+            rdf(0, St, 2);
+            mul(1, std::false_type{}, 0, 0, 0);
+            rdf(1, St, 3);
+            mul(0, std::false_type{}, 0, 0, 0);
+            if (has1) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();         // T_k
+                if (has2) prep(k + 2);
+                rdf(0, smem + nb1 * STAGE, 0);
+            }
+            mul(1, has2_tag, 0, QH, k & 1);         // first half of the DMA of slice k+2
+        };
+        int k = 0;
+        for (; k + 2 < nk; ++k) body(k, std::true_type{}, std::true_type{});
+        if (nk > 1) { body(k, std::true_type{}, std::false_type{}); ++k; }
+        body(k, std::false_type{}, std::false_type{});
+        __syncthreads();
+        conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+        return;
+    }
+
     auto slice = [&](int kt, auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;   // compile time: the last slice issues nothing
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for slice kt has landed
@@ -746,7 +812,7 @@ void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, false, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool PIPE, int EMU = 0, bool BSP = false>
+template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
@@ -793,12 +859,13 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
             if (bsp_ok) tile = tile == 41 ? 65 : tile + 20;   // weights pre-split: waves of 32x128 split the fewest activations per product
         }
     }
-    if (tile > 60 && !bsp_ok) tile = tile >= 65 ? 41 : tile - 20;
+    if (tile > 60 && tile < 70 && !bsp_ok) tile = tile >= 65 ? 41 : tile - 20;
     if (tile <= 0) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
         if (adaf_conv_glds_ok(a)) tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
     }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (tile > 70 && !adaf_conv_glds_ok(a)) tile -= 70;
     if (tile > 40 && !adaf_conv_glds_ok(a)) tile = tile % 10 <= 5 ? tile % 10 : 1;   // split tiles exist only in the DMA form
     if (tile > 30 && !adaf_conv_glds_ok(a)) tile -= 10;
     if (tile > 20 && !adaf_conv_glds_ok(a)) tile = tile - 20 <= 5 ? tile - 20 : 1;   // shape not eligible for the DMA kernel
@@ -820,6 +887,11 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 33: launch_glds<64, 64, 2, 2, true>(a, dense, s); break;
         case 34: launch_glds<64, 128, 2, 2, true>(a, dense, s); break;
         case 37: launch_glds<256, 256, 2, 4, true>(a, dense, s); break;
+        // 7x: fp32 pipe with the barrier between steps 2 and 3 of a slice (next slice's first fragments prefetched)
+        case 71: launch_glds<128, 128, 2, 2, 2>(a, dense, s); break;
+        case 72: launch_glds<128, 64, 2, 2, 2>(a, dense, s); break;
+        case 73: launch_glds<64, 64, 2, 2, 2>(a, dense, s); break;
+        case 74: launch_glds<64, 128, 2, 2, 2>(a, dense, s); break;
         // 4x / 5x: fp32 operands split into bf16 parts on the bf16 matrix pipe (6 / 9 products per element pair); opt-in
         case 41: launch_glds<128, 128, 2, 2, true, 6>(a, dense, s); break;
         case 42: launch_glds<128, 64, 2, 2, true, 6>(a, dense, s); break;

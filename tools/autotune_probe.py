@@ -36,7 +36,7 @@ def run(tiles):
 base = run([0] * nconv)
 print("auto: %.3f ms" % sum(base))
 res = {}
-for t in (31, 32, 33, 34, 41, 42, 43, 44):
+for t in (31, 32, 33, 34, 71, 72, 73, 74):
     res[t] = run([0] + [t] * (nconv - 1))
     print("all tile %d: %.3f ms" % (t, sum(res[t])), flush=True)
 # launches: stem, maxpool, convs..., avgpool  -> conv index c maps to launch c+1 for c >= 1
@@ -53,4 +53,4 @@ print("picks native:", pick_native)
 print("picks any:", pick_any)
 print("per-launch ms (launch: auto 31 32 33 34 41 42 43 44)")
 for i in range(len(base)):
-    print(i, "%.4f" % base[i], " ".join("%.4f" % res[t][i] for t in (31, 32, 33, 34, 41, 42, 43, 44)))
+    print(i, "%.4f" % base[i], " ".join("%.4f" % res[t][i] for t in (31, 32, 33, 34, 71, 72, 73, 74)))
