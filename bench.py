@@ -271,6 +271,47 @@ def main():
                 "clips_per_s": round(10 * b / dt, 1),
                 "max_abs_logit_diff_vs_f32": float((alt_logits - ref_logits).abs().max().item()),
                 "note": "ADAF_MATH_F32_SPLIT_BF16: fp32 operands as three exact bf16 parts, 6 products, fp32 accumulate"}
+        if world == 1 and not a.skip_extras:
+            # ---- rows f1/f2 of the scope table, measured the same way (inputs resident, HIP events): uint8 ingest,
+            # glancer, policy, and the whole forward from the loader's uint8 clips
+            try:
+                from adafocus_amd.transforms import ingest_uint8
+
+                def timed(fn, iters=5):
+                    for _ in range(2):
+                        fn()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        out = fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / iters, out
+
+                u8 = torch.randint(0, 256, (b, 224, 224, t * 3), device=dev, dtype=torch.uint8)
+                with torch.no_grad():
+                    ing_ms, fr4 = timed(lambda: ingest_uint8(u8, t))
+                    gl_ms, (fmap, fvec) = timed(lambda: model.glancer.net.features_from_nhwc4(fr4), 3)
+                    table = model.focuser.action_table(dev)
+                    pol_ms, _ = timed(lambda: model.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table))
+                    full_ms, _ = timed(lambda: model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t), 3)
+                ing_bytes = float(b * t * 224 * 224 * (3 + 16))
+                gl_bytes = float(b * t) * 4.0 * (2 * 6.68e6 + 224 * 224 * 4)      # 6.68 M conv-output elements/frame
+                res["next_rows"] = {
+                    "f1_ingest_u8": {"bound": "hbm", "ms": round(ing_ms, 4), "achieved": round(ing_bytes / ing_ms / 1e6, 1),
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ing_bytes / ing_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                     "bytes_per_pixel": 19},
+                    "f2_glancer_mobilenetv2": {"bound": "hbm", "ms": round(gl_ms, 3), "achieved": round(gl_bytes / gl_ms / 1e6, 1),
+                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gl_bytes / gl_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                               "gflop_per_frame": 0.599, "tflops": round(0.599e9 * b * t / gl_ms / 1e9, 1)},
+                    "f2_policy": {"ms": round(pol_ms, 3), "note": "1x1 conv + FC over all B*T frames, GRU scan over T, arg-max + grid lookup"},
+                    "full_forward_from_uint8": {"value": round(b / full_ms * 1e3, 1), "unit": "clips/s", "ms": round(full_ms, 3),
+                                                "note": "ingest + glancer + policy + hot path (GFV.offline_forward_nhwc4), serial on one stream"},
+                }
+                del u8, fr4, fmap, fvec
+            except Exception as exc:  # upstream of the timed path; never fail the bench on it
+                res["next_rows"] = {"error": repr(exc)[:300]}
         if os.environ.get("ADAF_BENCH_LAUNCHES"):
             res["launches"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()} for e in per_launch]
         if a.full and not a.skip_extras:
