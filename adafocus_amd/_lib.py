@@ -28,7 +28,7 @@ SYMBOLS = (
     "adaf_gru_cls_forward_f32", "adaf_fc_meanpool_forward_f32", "adaf_copy2d_f32",
     "adaf_pack_dw_weight_f32", "adaf_dwconv3x3_bn_act_f32", "adaf_mobilenetv2_create", "adaf_mobilenetv2_destroy",
     "adaf_mobilenetv2_set_param", "adaf_mobilenetv2_finalize", "adaf_mobilenetv2_workspace_bytes",
-    "adaf_mobilenetv2_forward", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
+    "adaf_mobilenetv2_forward", "adaf_mobilenetv2_set_fusion", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
     "adaf_crop_gather_nhwc4_f32", "adaf_ingest_u8_f32",
 )
 
@@ -94,6 +94,7 @@ def load_library():
     lib.adaf_mobilenetv2_workspace_bytes.restype = C.c_size_t
     lib.adaf_mobilenetv2_workspace_bytes.argtypes = [vp, ip, ip, ip]
     lib.adaf_mobilenetv2_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, C.c_size_t, vp]
+    lib.adaf_mobilenetv2_set_fusion.argtypes = [vp, ip]
     lib.adaf_grid_actions_f32.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp]
     lib.adaf_gru_seq_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.adaf_crop_gather_nhwc4_f32.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, vp]

@@ -34,6 +34,24 @@ struct ConvArgs {
     int nblocks;
 };
 
+// mbconv.hip: fused expand 1x1 -> depthwise 3x3 of an inverted-residual block
+struct MbFuseArgs {
+    const float* x;      // [n][H][W][cin]
+    int n, H, W, cin;
+    const float* we;     // expand weights [hid][cin]
+    const float* se;     // expand BN scale / bias [hid]
+    const float* be;
+    const float* wd;     // depthwise weights [3][3][hid]
+    const float* sd;
+    const float* bd;
+    float* out;          // [n][OH][OW][hid]
+    int hid, OH, OW;
+    int tiles_x, tiles_y;
+    const float* zeros;
+};
+bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
+void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
+
 // conv_gemm.hip
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0
 int adaf_pick_conv_tile(int M, int N, int K, int cus);

@@ -34,6 +34,7 @@ struct adaf_mobilenetv2 {
     std::vector<MbConv> convs;
     std::vector<MbBlock> blocks;
     int stem = 0, head = 0;
+    bool fuse = true;       // expand -> depthwise in one kernel where the shape allows (mbconv.hip)
     bool finalized = false;
 };
 
@@ -150,6 +151,12 @@ int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
     return ADAF_OK;
 }
 
+int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on) {
+    if (!net) return ADAF_E_BADARG;
+    net->fuse = on != 0;
+    return ADAF_OK;
+}
+
 int adaf_mobilenetv2_set_param(adaf_mobilenetv2* net, const char* name, const float* dev_ptr, size_t numel) {
     if (!net || !name || !dev_ptr) return ADAF_E_BADARG;
     net->params[name] = std::make_pair(dev_ptr, numel);
@@ -234,24 +241,37 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
             const int hid = b.inp * b.t;
             const bool residual = b.stride == 1 && b.inp == b.oup;
             const float* dw_in = cur;
+            const MbConv& D = net->convs[b.dw];
+            bool fused = false;
             if (b.expand >= 0) {
                 const MbConv& E = net->convs[b.expand];
                 const bool tsm = tsm_segments > 0 && residual;      // STH/models/gfv_net.py:238-241
+                fused = net->fuse && adaf_mb_expand_dw_ok(b.inp, hid, hw);
                 const float* ein = cur;
                 int fused_T = 0;
                 if (tsm) {
-                    if ((b.inp / tsm_div) % 4 == 0) fused_T = tsm_segments;   // shift fused into the operand load
-                    else {   // fold not a multiple of 4 channels (24-channel block): materialise the shift once
-                        adaf_launch_tshift(cur, nc, b.inp, hw * hw, tsm_segments, tsm_div, ADAF_LAYOUT_NHWC, bufD, st);
-                        ein = bufD;
+                    if (!fused && (b.inp / tsm_div) % 4 == 0) fused_T = tsm_segments;   // shift fused into the operand load
+                    else {   // fold not a multiple of 4 channels (24-channel block), or the fused kernel: materialise the shift once
+                        float* sh = fused ? bufE : bufD;
+                        adaf_launch_tshift(cur, nc, b.inp, hw * hw, tsm_segments, tsm_div, ADAF_LAYOUT_NHWC, sh, st);
+                        ein = sh;
                     }
                 }
-                if ((rc = run_conv(net, E, ein, nc, hw, hw, ADAF_ACT_RELU6, nullptr, bufE, fused_T, tsm_div, st)))
-                    return mfail(h, rc, "mobilenetv2: expand launch");
-                dw_in = bufE;
+                if (fused) {
+                    MbFuseArgs fa;
+                    memset(&fa, 0, sizeof(fa));
+                    fa.x = ein; fa.n = nc; fa.H = hw; fa.W = hw; fa.cin = b.inp;
+                    fa.we = E.w; fa.se = E.scale; fa.be = E.bias; fa.wd = D.w; fa.sd = D.scale; fa.bd = D.bias;
+                    fa.out = bufD; fa.hid = hid; fa.OH = fa.OW = cdiv_out(hw, 3, b.stride, 1);
+                    fa.zeros = net->h->zeros;
+                    adaf_launch_mb_expand_dw(fa, b.stride, st);
+                } else {
+                    if ((rc = run_conv(net, E, ein, nc, hw, hw, ADAF_ACT_RELU6, nullptr, bufE, fused_T, tsm_div, st)))
+                        return mfail(h, rc, "mobilenetv2: expand launch");
+                    dw_in = bufE;
+                }
             }
-            const MbConv& D = net->convs[b.dw];
-            adaf_launch_dwconv3x3(dw_in, nc, hw, hw, hid, b.stride, D.w, D.scale, D.bias, ADAF_ACT_RELU6, bufD, st);
+            if (!fused) adaf_launch_dwconv3x3(dw_in, nc, hw, hw, hid, b.stride, D.w, D.scale, D.bias, ADAF_ACT_RELU6, bufD, st);
             const int ohw = cdiv_out(hw, 3, b.stride, 1);
             if ((rc = run_conv(net, net->convs[b.project], bufD, nc, ohw, ohw, ADAF_ACT_NONE, residual ? cur : nullptr, nxt, 0,
                                0, st)))

@@ -61,6 +61,7 @@ class GlancerEngine:
     def __init__(self, module, variant):
         self.module, self.variant = module, variant
         self._net, self._sig = None, None
+        self.fusion = True      # expand -> depthwise fused where the shape allows (adaf_mobilenetv2_set_fusion)
 
     def sync(self):
         sd = {k: v for k, v in self.module.state_dict().items()
@@ -74,6 +75,7 @@ class GlancerEngine:
                 self._net = hip_ops.MobileNetV2Net(dev)
             self._net.load(neutral_params(sd, self.variant))
             self._sig = sig
+        self._net.set_fusion(self.fusion)
         return self._net
 
     def features(self, frames_nhwc4, tsm_segments=0, tsm_div=8, want_vec=True):

@@ -365,6 +365,10 @@ class MobileNetV2Net:
         L.check(self._lib.adaf_mobilenetv2_finalize(self._net, L.stream_ptr()), self._h)
         del keep
 
+    def set_fusion(self, on):
+        """Expand 1x1 -> depthwise 3x3 in one kernel for the high-resolution blocks (default on)."""
+        L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, 1 if on else 0), self._h)
+
     def forward(self, frames_nhwc4, tsm_segments=0, tsm_div=8, want_vec=True):
         """(N,S,S,4) -> featmap (N,S/32,S/32,1280) NHWC, featvec (N,1280) or None."""
         L.need_gpu_f32(frames_nhwc4)

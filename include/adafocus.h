@@ -210,6 +210,9 @@ size_t adaf_mobilenetv2_workspace_bytes(const adaf_mobilenetv2* net, int n, int 
 int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, int n, int size, int tsm_segments,
                              int tsm_div, float* featmap, float* featvec, int ldvec, void* ws, size_t ws_bytes,
                              void* stream);
+/* Expand 1x1 -> depthwise 3x3 in one kernel (the 6x-expanded map stays on chip) for the blocks whose shape allows it
+ * (cin % 8 == 0, cin <= 32, map >= 28^2: b2..b7 at 224^2).  On by default; off = the three-launch form (tests, A/B). */
+int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
 
 /* ---- a11: policy head -------------------------------------------------------------------
  * idx = argmax_a logits[row, a] (first maximum), action = table_yx[idx] -- the eval branch of

@@ -513,6 +513,49 @@ def test_mobilenetv2_act_golden(dev):
     assert np.abs(fv.cpu().numpy() - g["fv"]).max() < TOL
 
 
+def test_mobilenetv2_fused_expand_dw_bit_identical(dev):
+    """mbconv.hip (expand 1x1 -> depthwise 3x3 in one kernel, b2..b7 at 224^2) against the three-launch form: same k
+    order in the expand GEMM, same tap order in the depthwise sum, so the feature maps agree bit for bit -- including
+    partial edge tiles (200^2, 120^2) and the chunked pass (300 frames > one chunk)."""
+    from adafocus_amd.mobilenet import mobilenet_v2
+    net = mobilenet_v2().eval()
+    sd = {k: v for k, v in synth_sd("ACT", 505, "glancer.net.", keep_prefix=False).items() if not k.startswith("classifier")}
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev)
+    for n, size in ((5, 224), (3, 200), (4, 120), (300, 96)):
+        x4 = torch.zeros((n, size, size, 4), device=dev)
+        x4[..., :3] = rnd((n, size, size, 3), 60 + size).to(dev)
+        with torch.no_grad():
+            net._engine.fusion = True
+            fm1, fv1 = [t.clone() for t in net.features_from_nhwc4(x4)]
+            net._engine.fusion = False
+            fm0, fv0 = [t.clone() for t in net.features_from_nhwc4(x4)]
+        net._engine.fusion = True
+        assert torch.equal(fm1, fm0) and torch.equal(fv1, fv0), (n, size)
+        assert fm0.abs().max().item() > 0.1
+
+
+def test_mobilenetv2_sth_tsm_fused_blocks_vs_oracle(dev, O):
+    """STH glancer at 128^2: the residual 24-channel block runs fused at a 32^2 map with the temporal shift materialised
+    in front of it; against the oracle and against the unfused form."""
+    from adafocus_amd.gfv_net_sth import Glancer
+    from tests.test_state_dict_compat import sth_args
+    gl = Glancer(sth_args()).eval()
+    sd = synth_sd("STH", 78, "glancer.", keep_prefix=False)
+    gl.load_state_dict(sd, strict=True)
+    gl = gl.to(dev)
+    x = rnd((16, 3, 128, 128), 55)
+    with torch.no_grad():
+        fm, logit = gl(x.to(dev))
+        gl.net._engine.fusion = False
+        fm0, logit0 = gl(x.to(dev))
+        gl.net._engine.fusion = True
+        rfm, rlogit = O.glancer_sth(sd, "net.", x, 8, 8)
+    assert torch.equal(fm, fm0) and torch.equal(logit, logit0)
+    assert (fm.cpu() - rfm).abs().max().item() < TOL
+    assert (logit.cpu() - rlogit).abs().max().item() < TOL
+
+
 def test_mobilenetv2_sth_tsm_vs_oracle(dev, O):
     """STH glancer: flat key layout + temporal shift on the residual blocks (fused where fold % 4 == 0,
     materialised for the 24-channel block), chunked over frames."""
