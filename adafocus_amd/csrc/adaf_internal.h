@@ -49,6 +49,23 @@ struct MbFuseArgs {
     int tiles_x, tiles_y;
     const float* zeros;
 };
+struct MbStemArgs {       // fused stem -> block 1 (t = 1: depthwise + project) of MobileNetV2
+    const float* x;       // [n][S][S][4] pixel-major frames
+    int n, S, H1;         // H1 = stem output size
+    const float* ws;      // stem filter [32][3][3][4]
+    const float* ss;      // BN scale / bias of the stem [32]
+    const float* bs;
+    const float* wd;      // depthwise [3][3][32]
+    const float* sd;
+    const float* bd;
+    const float* wp;      // project [16][32]
+    const float* sp;
+    const float* bp;
+    float* out;           // [n][H1][H1][16]
+    int tiles_x, tiles_y, total_tiles;
+    const float* zeros;
+};
+void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s);
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
 

@@ -232,12 +232,25 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
         const int nc = (n - f0) < chunk ? (n - f0) : chunk;
         int hw = cdiv_out(size, 3, 2, 1);
         int rc;
-        if ((rc = run_conv(net, net->convs[net->stem], frames_nhwc4 + (size_t)f0 * size * size * 4, nc, size, size,
-                           ADAF_ACT_RELU6, nullptr, bufA, 0, 0, st)))
-            return mfail(h, rc, "mobilenetv2: stem launch");
         float* cur = bufA;
         float* nxt = bufB;
-        for (auto& b : net->blocks) {
+        size_t first_block = 0;
+        const MbBlock& b1 = net->blocks[0];
+        if (net->fuse && b1.t == 1 && b1.inp == 32 && b1.oup == 16 && b1.stride == 1) {
+            // stem + block 1 in one kernel: the two 32-channel maps at the stem's resolution never reach HBM
+            const MbConv &S = net->convs[net->stem], &D = net->convs[b1.dw], &P = net->convs[b1.project];
+            MbStemArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.x = frames_nhwc4 + (size_t)f0 * size * size * 4; sa.n = nc; sa.S = size; sa.H1 = hw;
+            sa.ws = S.w; sa.ss = S.scale; sa.bs = S.bias; sa.wd = D.w; sa.sd = D.scale; sa.bd = D.bias;
+            sa.wp = P.w; sa.sp = P.scale; sa.bp = P.bias; sa.out = bufA; sa.zeros = net->h->zeros;
+            adaf_launch_mb_stem_b1(sa, net->h->cus, st);
+            first_block = 1;
+        } else if ((rc = run_conv(net, net->convs[net->stem], frames_nhwc4 + (size_t)f0 * size * size * 4, nc, size, size,
+                                  ADAF_ACT_RELU6, nullptr, bufA, 0, 0, st)))
+            return mfail(h, rc, "mobilenetv2: stem launch");
+        for (size_t bidx = first_block; bidx < net->blocks.size(); ++bidx) {
+            const MbBlock& b = net->blocks[bidx];
             const int hid = b.inp * b.t;
             const bool residual = b.stride == 1 && b.inp == b.oup;
             const float* dw_in = cur;
