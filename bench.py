@@ -252,7 +252,7 @@ def main():
                         model.hot_path(fr8, gv8, ac8, b, t8)
                 torch.cuda.synchronize()
             res["also"] = {"T%d_P%d_B%d_clips_per_s" % (t8, p, b): round(6 * b / (time.perf_counter() - t1), 1)}
-        if a.math == "f32" and not a.skip_extras:
+        if a.math == "f32" and not a.skip_extras and world == 1:   # (step() holds a collective when world > 1)
             # opt-in arithmetic (not the reported configuration): same step with the convs on the bf16 matrix pipe
             with torch.no_grad():
                 ref_logits = model.hot_path(frames, gvec, actions, b, t)[0].clone()
