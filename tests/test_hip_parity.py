@@ -422,6 +422,36 @@ def test_act_full_forward_golden(dev):
         pytest.xfail("policy argmax flipped on a near-tie (different fp32 summation order); forced-action parity passed")
 
 
+def test_validate_loop_real_model_on_gpu(dev):
+    """evaluate.validate (stage-3 loop, ACT/main_dist.py:307-422) driving the real GFV on the GPU over a 5-clip set
+    with a ragged last batch: its summary must equal the metrics of the model's own per-clip logits."""
+    from adafocus_amd import evaluate as E
+    from oracle import ref_metrics as RM
+    m, _ = _act_model(dev)
+    frames = torch.from_numpy(synth.synth_frames(5, 8, 224, seed=3))
+    labels = torch.tensor([[3], [150], [7], [199], [42]], dtype=torch.int64)
+
+    class DS:
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return frames[i], labels[i]
+
+    class A:
+        num_segments, num_classes, batch_size, gpu, dataset = 8, 200, 2, 0, "actnet"
+
+    with torch.no_grad():
+        top1, top5, m_ap, logs = E.validate(DS(), m, torch.nn.CrossEntropyLoss(), A(), quiet=True)
+        last = torch.cat([m(input=frames[i:i + 1].to(dev), scan=frames[i:i + 1].to(dev), training=False, backbone_pred=False,
+                            one_step=True, gpu=0)[1] for i in range(5)]).cpu()
+    a1, a5 = RM.accuracy(last.numpy(), labels[:, 0].numpy(), topk=(1, 5))
+    ref_map, _ = RM.cal_map(last.numpy(), labels.numpy())
+    assert abs(top1 - float(a1)) < 1e-4 and abs(top5 - float(a5)) < 1e-4
+    assert abs(m_ap - float(ref_map)) < 1e-3
+    assert logs[-1].startswith(" * Acc@1")
+
+
 # ------------------------------------------------------------------------------------ end to end (STH)
 def _sth_model(dev):
     from adafocus_amd.gfv_net_sth import GFV
