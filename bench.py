@@ -92,7 +92,32 @@ def cpu_baseline(sd, t, p, clips, threads):
                 log.append("%d clips/%d thr: %.2f" % (nc, th, nc / sec))
                 if nc / sec > best[0]:
                     best = (nc / sec, th, nc, sec)
+    # the reference's own loop structure (ACT/models/gfv_net.py:110-121: one crop + one local-CNN call per time step with
+    # batch B, then the GRU) at the best setting found above, for the record
+    per_step = None
+    try:
+        with torch.no_grad():
+            nc, th = best[2], best[1]
+            torch.set_num_threads(th)
+            frames = torch.from_numpy(synth.synth_frames(nc, t, 224, seed=1)).view(nc, t, 3, 224, 224)
+            _, actions = synth.synth_actions(nc * t, 7, seed=2)
+            act = torch.from_numpy(actions).view(nc, t, 2)
+            gvec = torch.randn(nc, t, 1280)
+
+            def ref_structured():
+                feats = []
+                for ti in range(t):
+                    patch = O.get_patch(frames[:, ti].contiguous(), act[:, ti].contiguous(), p)
+                    feats.append(O.resnet50_trunk(sd, "focuser.net.", patch).view(nc, 1, -1))
+                return O.recurrent_classifier(sd, "classifier.", torch.cat([gvec, torch.cat(feats, dim=1)], dim=2))
+            ref_structured()
+            t0 = time.perf_counter()
+            ref_structured()
+            per_step = round(nc / (time.perf_counter() - t0), 3)
+    except Exception:  # noqa: BLE001 - reporting only
+        per_step = None
     return {"value": round(best[0], 3), "unit": "clips/s", "cores": best[1], "kind": "port",
+            "reference_loop_structure_value": per_step,
             "sample": "oracle.act_hot_path (batched crop -> ResNet-50 -> GRU), %d clips x T=%d per call, P=%d, fp32, best of 2 after "
                       "1 warm-up, %.2f s/iter; sweep (clips/s) on %d logical CPUs: %s" % (best[2], t, p, best[3], ncpu, "; ".join(log))}
 
