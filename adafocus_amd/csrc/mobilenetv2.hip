@@ -101,7 +101,7 @@ void slab_sizes(const adaf_mobilenetv2* net, int size, size_t* io, size_t* ex, s
     if ((size_t)hw * hw * 32 > *ex) *ex = (size_t)hw * hw * 32;
 }
 
-const int kChunk = 256;   // frames per pass through the network
+const int kChunk = 512;   // frames per pass through the network
 
 int chunk_frames(int n, int tsm_segments) {
     int c = n < kChunk ? n : kChunk;

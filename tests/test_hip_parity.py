@@ -546,13 +546,13 @@ def test_mobilenetv2_act_golden(dev):
 def test_mobilenetv2_fused_expand_dw_bit_identical(dev):
     """mbconv.hip (expand 1x1 -> depthwise 3x3 in one kernel, b2..b7 at 224^2) against the three-launch form: same k
     order in the expand GEMM, same tap order in the depthwise sum, so the feature maps agree bit for bit -- including
-    partial edge tiles (200^2, 120^2) and the chunked pass (300 frames > one chunk)."""
+    partial edge tiles (200^2, 120^2) and the chunked pass (520 frames > one 512-frame chunk)."""
     from adafocus_amd.mobilenet import mobilenet_v2
     net = mobilenet_v2().eval()
     sd = {k: v for k, v in synth_sd("ACT", 505, "glancer.net.", keep_prefix=False).items() if not k.startswith("classifier")}
     net.load_state_dict(sd, strict=False)
     net = net.to(dev)
-    for n, size in ((5, 224), (3, 200), (4, 120), (300, 96)):
+    for n, size in ((5, 224), (3, 200), (4, 120), (520, 64)):
         x4 = torch.zeros((n, size, size, 4), device=dev)
         x4[..., :3] = rnd((n, size, size, 3), 60 + size).to(dev)
         with torch.no_grad():
