@@ -139,7 +139,7 @@ def main():
                          "fp32 operands as three exact bf16 parts on the bf16 matrix pipe, fp32 accumulate")
     ap.add_argument("--tiles", type=str, default="", help="comma list of per-conv tile overrides (tuning)")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed steps + roofline pass (for rocprofv3 runs)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps are round-robined over (batch i+1's "
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the steps are round-robined over (batch i+1's "
                     "trunk overlaps batch i's latency-bound GRU scan); 1 = strictly serial steps")
     a = ap.parse_args()
 
