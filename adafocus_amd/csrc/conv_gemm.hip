@@ -28,23 +28,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 // ---- fp32 operands on the bf16 matrix pipe (opt-in "split" tiles) -----------------------------------
-// x = h + m + l EXACTLY, each part a bf16 (8 significant bits; the parts are taken by truncation, so the
-// three 8-bit fields tile the 24-bit significand).  The fp32 product x*y is then the sum of nine bf16*bf16
-// products, each exact in the fp32 accumulator's input; the "6" form drops the three terms below 2^-24 |xy|
-// (m*l, l*m, l*l).  Eight consecutive k values of a row -> three registers-quads of packed bf16 pairs.
+// x = h + m + l EXACTLY with h = bf16(x), m = bf16(x - h), l = x - h - m, conversions round-to-nearest-even
+// (v_cvt_pk_bf16_f32): both subtractions are exact in fp32 and the last remainder has at most 8 significant bits,
+// so it is a bf16.  |m| <= 2^-8 |x|, |l| <= 2^-16 |x| with signs independent of x.  The fp32 product x*y is the sum of
+// nine bf16*bf16 products, each exact in the fp32 accumulator's input; the "6" form drops m*l, l*m, l*l -- below
+// 2^-24 |xy| and, because of the rounding, of either sign (with a truncating split the dropped terms all carry the
+// sign of xy and the bias adds up over K and over layers: measured 2.5x the fp32 pipe's error on the whole trunk).
+// Eight consecutive k values of a row -> three register quads of packed bf16 pairs.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3(const f32x4 v0, const f32x4 v1, u32x4& H, u32x4& M, u32x4& L) {
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const unsigned b0 = __float_as_uint(x[2 * p]), b1 = __float_as_uint(x[2 * p + 1]);
-        h[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);          // {hi16(x0), hi16(x1)}
         const f32x2 xv = {x[2 * p], x[2 * p + 1]};
-        const f32x2 hv = {__uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+        h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, bf16x2));
+        const f32x2 hv = {__uint_as_float(h[p] << 16), __uint_as_float(h[p] & 0xffff0000u)};
         const f32x2 r1 = xv - hv;                                    // exact
-        const unsigned c0 = __float_as_uint(r1.x), c1 = __float_as_uint(r1.y);
-        m[p] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-        const f32x2 mv = {__uint_as_float(c0 & 0xffff0000u), __uint_as_float(c1 & 0xffff0000u)};
+        m[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+        const f32x2 mv = {__uint_as_float(m[p] << 16), __uint_as_float(m[p] & 0xffff0000u)};
         const f32x2 r2 = r1 - mv;                                    // exact, <= 8 significant bits left
         l[p] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
     }

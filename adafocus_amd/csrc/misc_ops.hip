@@ -248,17 +248,18 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __r
 
 }  // namespace
 
-// fp32 -> three bf16 planes (h, m, l) with h + m + l == w exactly (truncation split, see split3 in conv_gemm.hip)
+// fp32 -> three bf16 planes (h, m, l) with h + m + l == w exactly (round-to-nearest split, the same arithmetic as
+// split3 in conv_gemm.hip so pre-split and on-the-fly operands are identical)
 __global__ void split_weight_kernel(const float* __restrict__ w, size_t count, unsigned short* __restrict__ planes) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float x = w[i];
-    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hb);
-    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb);
-    planes[i] = (unsigned short)(hb >> 16);
-    planes[count + i] = (unsigned short)(mb >> 16);
+    const __bf16 hb = (__bf16)x;
+    const float r1 = x - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const float r2 = r1 - (float)mb;
+    planes[i] = __builtin_bit_cast(unsigned short, hb);
+    planes[count + i] = __builtin_bit_cast(unsigned short, mb);
     planes[2 * count + i] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 

@@ -323,6 +323,26 @@ def test_resnet50_split_math_presplit_weights_bit_identical(dev):
         assert torch.equal(o, outs[0])
 
 
+def test_resnet50_trunk_error_vs_fp64_split_same_order(dev, O):
+    """Whole trunk against the oracle evaluated in fp64 (rms error of the 2048-d features over 8 patches).  Measured:
+    fp32 matrix pipe 3.8e-7, split arithmetic 5.9e-7 (a truncating split gave 9.5e-7; the 9-product form gives the same
+    5.9e-7, so what is left is the bf16 MFMA's internal accumulation, not the dropped products).  Bar: same order."""
+    net, sd = _trunk(dev, 2024)
+    x = rnd((8, 3, 96, 96), 808)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        ref = O.resnet50_trunk(sd64, "", x.double()).view(8, -1)
+        native = net.get_featvec(x.to(dev)).cpu().double()
+        net.set_math("split_bf16")
+        split = net.get_featvec(x.to(dev)).cpu().double()
+        net.set_math("f32")
+    rms = ref.pow(2).mean().sqrt().item()
+    e_native = (native - ref).pow(2).mean().sqrt().item() / rms
+    e_split = (split - ref).pow(2).mean().sqrt().item() / rms
+    assert e_native < 1e-5 and e_split < 1e-5, (e_native, e_split)
+    assert e_split <= 2.0 * e_native + 1e-8, (e_native, e_split)
+
+
 def test_resnet50_batch_invariance_full_size(dev):
     """BASELINE size (N = 1024 patches of 96^2): the tile choice changes with the problem size but
     the fp32 fma chain per output does not, so a patch's feature must be bit-identical whether it
