@@ -8,6 +8,7 @@ on the hot path).  ``cal_map`` keeps the reference's label handling, including i
 label values that occur in the evaluated set (utils.py:56-60, called with assumes_starts_zero=False).
 """
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 import torch.nn.functional as F
@@ -93,12 +94,64 @@ def cal_map(output, old_test_y):
     return ap.mean() * 100, ap * 100
 
 
+class _Prefetcher:
+    """Batches of this rank's shard, one ahead: batch i+1 is stacked into pinned host memory and copied to the GPU on a
+    side stream while batch i computes (the reference stacks in DataLoader workers and copies synchronously with
+    ``.cuda()``, main_dist.py:329-331).  On a CPU device it degrades to plain stacking."""
+
+    def __init__(self, dataset, start, stop, bs, dev):
+        self.ds, self.dev, self.bs = dataset, dev, bs
+        self.los = list(range(start, stop, bs))
+        self.stop = stop
+        self.cuda = dev.type == "cuda"
+        self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
+        self.pinned = [None, None]
+        self.pool = ThreadPoolExecutor(max_workers=8) if self.cuda else None   # large tensor copies release the GIL
+        self.slot = 0
+        self.next = None
+        self._issue(0)
+
+    def _issue(self, i):
+        if i >= len(self.los):
+            self.next = None
+            return
+        lo = self.los[i]
+        items = [self.ds[j] for j in range(lo, min(lo + self.bs, self.stop))]
+        tgt = torch.stack([it[1] for it in items])
+        if not self.cuda:
+            self.next = (torch.stack([it[0] for it in items]).to(self.dev), tgt, None)
+            return
+        first = items[0][0]
+        shape = (len(items),) + tuple(first.shape)
+        buf = self.pinned[self.slot]
+        if buf is None or buf.shape[1:] != shape[1:] or buf.shape[0] < shape[0] or buf.dtype != first.dtype:
+            buf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype).pin_memory()
+            self.pinned[self.slot] = buf
+        host = buf[:shape[0]]
+        list(self.pool.map(lambda jt: host[jt[0]].copy_(jt[1][0]), enumerate(items)))
+        with torch.cuda.stream(self.stream):
+            devt = host.to(self.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.slot ^= 1
+        self.next = (devt, tgt, ev)
+
+    def __iter__(self):
+        for i in range(len(self.los)):
+            images, tgt, ev = self.next
+            if ev is not None:
+                torch.cuda.current_stream(self.dev).wait_event(ev)
+                images.record_stream(torch.cuda.current_stream(self.dev))
+            yield i, images, tgt, (lambda n=i + 1: self._issue(n))
+
+
 @torch.no_grad()
 def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
     """Stage-3 evaluation (main_dist.py:307-422, branch :367-371) over this rank's shard of `dataset`
-    (indexable -> (images (T*3,H,W) fp32 | uint8 stacked clip, target (L,) int64)).  Every rank returns the
-    metrics of the WHOLE set: logits and targets are all-gathered once at the end.
-    Returns (top1, top5, mAP, logs)."""
+    (indexable -> (images, target (L,) int64) with images either the reference's normalised fp32 ``(T*3,H,W)`` clip or
+    the loader's stacked uint8 ``(H,W,T*3)`` clip, which is normalised on the GPU -- row f1).  Every rank returns the
+    metrics of the WHOLE set: logits and targets are all-gathered once at the end.  The next batch is staged and copied
+    while the current one computes.  Returns (top1, top5, mAP, logs)."""
     bs = batch_size or args.batch_size
     start, stop = shard_range(len(dataset), rank, world)
     nb = (stop - start + bs - 1) // bs
@@ -109,13 +162,16 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
     dev = device or next(model.parameters()).device
     logs, preds, step_logits, targets = [], [], [], []
     end = time.time()
-    for bi, lo in enumerate(range(start, stop, bs)):
-        items = [dataset[i] for i in range(lo, min(lo + bs, stop))]
-        images = torch.stack([it[0] for it in items]).to(dev)
-        target_full = torch.stack([it[1] for it in items])
+    for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
         target = target_full[:, 0].to(dev)
         b = images.shape[0]
-        outputs, pred = model(input=images, scan=images, training=False, backbone_pred=False, one_step=True, gpu=args.gpu)
+        if images.dtype == torch.uint8:
+            from .transforms import ingest_uint8
+            frames = ingest_uint8(images, args.num_segments)
+            outputs, pred = model.offline_forward_nhwc4(frames, b, args.num_segments)[:2]
+        else:
+            outputs, pred = model(input=images, scan=images, training=False, backbone_pred=False, one_step=True, gpu=args.gpu)
+        stage_next()          # host-side stacking + H2D of the next batch run under this batch's kernels
         loss = criterion(outputs, target.view(b, -1).expand(b, args.num_segments).reshape(-1))
         acc1, acc5 = accuracy(pred, target, topk=(1, 5))
         losses.update(loss.item(), b)

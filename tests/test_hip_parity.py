@@ -472,6 +472,36 @@ def test_validate_loop_real_model_on_gpu(dev):
     assert logs[-1].startswith(" * Acc@1")
 
 
+def test_validate_loop_uint8_clips_equal_fp32_clips(dev, O):
+    """The eval loop fed with the loader's stacked uint8 clips (normalised on the GPU, prefetched one batch ahead on a
+    copy stream) must report the metrics of the same clips normalised on the host as the reference does."""
+    from adafocus_amd import evaluate as E
+    m, _ = _act_model(dev)
+    gen = np.random.Generator(np.random.PCG64([17, 3]))
+    u8 = gen.integers(0, 256, size=(5, 224, 224, 24), dtype=np.uint8)
+    f32 = torch.stack([O.ingest_uint8(u8[i]) for i in range(5)])
+    labels = torch.tensor([[3], [150], [7], [199], [42]], dtype=torch.int64)
+
+    class DS:
+        def __init__(self, x):
+            self.x = x
+
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return self.x[i], labels[i]
+
+    class A:
+        num_segments, num_classes, batch_size, gpu, dataset = 8, 200, 2, 0, "actnet"
+
+    with torch.no_grad():
+        r8 = E.validate(DS(torch.from_numpy(u8)), m, torch.nn.CrossEntropyLoss(), A(), quiet=True)
+        r32 = E.validate(DS(f32), m, torch.nn.CrossEntropyLoss(), A(), quiet=True)
+    assert r8[:3] == r32[:3], (r8[:3], r32[:3])
+    assert [ln.split("Loss")[1] for ln in r8[3][:3]] == [ln.split("Loss")[1] for ln in r32[3][:3]]
+
+
 # ------------------------------------------------------------------------------------ end to end (STH)
 def _sth_model(dev):
     from adafocus_amd.gfv_net_sth import GFV
