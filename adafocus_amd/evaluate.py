@@ -106,6 +106,7 @@ class _Prefetcher:
         self.cuda = dev.type == "cuda"
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
         self.pinned = [None, None]
+        self.copied = [None, None]          # event of the last H2D copy out of each pinned slot
         self.pool = ThreadPoolExecutor(max_workers=8) if self.cuda else None   # large tensor copies release the GIL
         self.slot = 0
         self.next = None
@@ -123,6 +124,8 @@ class _Prefetcher:
             return
         first = items[0][0]
         shape = (len(items),) + tuple(first.shape)
+        if self.copied[self.slot] is not None:
+            self.copied[self.slot].synchronize()        # the previous copy out of this slot has left the host buffer
         buf = self.pinned[self.slot]
         if buf is None or buf.shape[1:] != shape[1:] or buf.shape[0] < shape[0] or buf.dtype != first.dtype:
             buf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype).pin_memory()
@@ -133,6 +136,7 @@ class _Prefetcher:
             devt = host.to(self.dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self.copied[self.slot] = ev
         self.slot ^= 1
         self.next = (devt, tgt, ev)
 
@@ -162,6 +166,17 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
     dev = device or next(model.parameters()).device
     logs, preds, step_logits, targets = [], [], [], []
     end = time.time()
+    def finish(item):     # host side of a batch: the three scalars, the meters, the log line
+        nonlocal end
+        bi_, b_, loss_, acc1_, acc5_ = item
+        losses.update(loss_.item(), b_)
+        top1.update(acc1_[0].item(), b_)
+        top5.update(acc5_[0].item(), b_)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        logs.append(progress.print(bi_, quiet=quiet or rank != 0))
+
+    pending = None        # batch i's scalars are read back after batch i+1 has been enqueued: the GPU never idles on them
     for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
         target = target_full[:, 0].to(dev)
         b = images.shape[0]
@@ -174,15 +189,14 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
         stage_next()          # host-side stacking + H2D of the next batch run under this batch's kernels
         loss = criterion(outputs, target.view(b, -1).expand(b, args.num_segments).reshape(-1))
         acc1, acc5 = accuracy(pred, target, topk=(1, 5))
-        losses.update(loss.item(), b)
-        top1.update(acc1[0].item(), b)
-        top5.update(acc5[0].item(), b)
         preds.append(pred)
         step_logits.append(outputs.reshape(b, args.num_segments, -1))
         targets.append(target_full.to(dev))
-        batch_time.update(time.time() - end)
-        end = time.time()
-        logs.append(progress.print(bi, quiet=quiet or rank != 0))
+        if pending is not None:
+            finish(pending)
+        pending = (bi, b, loss, acc1, acc5)
+    if pending is not None:
+        finish(pending)
     ncls = args.num_classes
     empty = torch.zeros((0, ncls), device=dev)
     all_pred = gather_variable(torch.cat(preds) if preds else empty).cpu()
