@@ -11,6 +11,7 @@ struct adaf_handle {
     int device = 0;
     int cus = 256;
     float* zeros = nullptr;  // device, 256 bytes of zeros
+    int gru_persistent = 1;  // GRU scans as one persistent kernel where the shape allows (gru_scan.hip)
     std::string err;
 };
 
@@ -68,6 +69,11 @@ struct MbStemArgs {       // fused stem -> block 1 (t = 1: depthwise + project) 
 void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s);
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
+
+// gru_scan.hip
+bool adaf_gru_scan_persistent_ok(int batch, int hidden, int cus);
+void adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, float* hs, unsigned* bar, int batch,
+                                     int steps, hipStream_t s);
 
 // conv_gemm.hip
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0

@@ -102,6 +102,11 @@ int adaf_destroy(adaf_handle* h) {
 
 const char* adaf_last_error(const adaf_handle* h) { return h ? h->err.c_str() : "null handle"; }
 int adaf_device_cus(const adaf_handle* h) { return h ? h->cus : 0; }
+int adaf_set_gru_persistent(adaf_handle* h, int on) {
+    if (!h) return ADAF_E_BADARG;
+    h->gru_persistent = on ? 1 : 0;
+    return ADAF_OK;
+}
 
 // ---- crop ------------------------------------------------------------------------------
 int adaf_crop_gather_f32(adaf_handle* h, const float* frames, int n_frames, int channels, int height, int width,
@@ -571,6 +576,11 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
     int rc;
     // all input projections at once: gi[b*T+t, :] = W_ih x[b,t] + b_ih
     if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
+    if (h->gru_persistent && adaf_gru_scan_persistent_ok(batch, hidden, h->cus)) {
+        // the whole recurrence in one kernel; `gh` only lends its first `steps` words to the grid barrier
+        adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, hs, reinterpret_cast<unsigned*>(gh), batch, steps, st);
+        return ADAF_OK;
+    }
     for (int t = 0; t < steps; ++t) {
         const float* hprev = t ? hs + (size_t)(t - 1) * hidden : nullptr;
         if (t) {  // gh = W_hh h_{t-1}; rows are strided views into hs

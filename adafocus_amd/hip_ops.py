@@ -279,6 +279,13 @@ class ResNet50Trunk:
         L.check(self._lib.adaf_resnet50_set_math(self._net, int(code)), self._h)
 
 
+def set_gru_persistent(on, device=None):
+    """GRU scans as one persistent kernel (default) or two launches per step (include/adafocus.h)."""
+    dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+    h = L.handle(dev)
+    L.check(L.load_library().adaf_set_gru_persistent(h, 1 if on else 0), h)
+
+
 def pack_dw_weight(w_c133):
     """PyTorch depthwise weight [C,1,3,3] -> [3,3,C]."""
     L.need_gpu_f32(w_c133)

@@ -56,6 +56,9 @@ int adaf_destroy(adaf_handle* h);
 const char* adaf_last_error(const adaf_handle* h);
 /* Number of compute units of the bound device (256 on MI355X). */
 int adaf_device_cus(const adaf_handle* h);
+/* GRU scans (classifier a7, policy a11) as one persistent kernel with a grid barrier per step when hidden == 1024 and
+ * batch <= 64 (default on); off = two launches per step.  Both forms are deterministic; they differ in summation order. */
+int adaf_set_gru_persistent(adaf_handle* h, int on);
 
 /* ---- a1: patch gather -------------------------------------------------------------------
  * Replaces get_patch(images, action_sequence, patch_size) -- ACT/models/utils.py:37-51

@@ -379,6 +379,31 @@ def test_gru_classifier_golden_and_oracle(dev, ops, O):
     assert (last.cpu() - rlast).abs().max().item() < 1e-4
 
 
+def test_gru_scan_persistent_kernel_vs_per_step_launches(dev, ops, O):
+    """gru_scan.hip (whole recurrence in one kernel, grid barrier per step, W_hh in registers) against the two-launches-
+    per-step form and the oracle: batch sizes that fill one tile, straddle two, and the benchmark's 64 x 16."""
+    sd = synth_sd("ACT", 606, "classifier.", keep_prefix=False)
+    d = {k: v.to(dev) for k, v in sd.items()}
+    args = (d["gru.weight_ih_l0"], d["gru.weight_hh_l0"], d["gru.bias_ih_l0"], d["gru.bias_hh_l0"])
+    try:
+        for b, t in ((5, 3), (33, 8), (64, 16), (1, 1)):
+            x = rnd((b, t, 3328), 160 + b, 0.5).to(dev)
+            ops.set_gru_persistent(True, dev)
+            hp = ops.gru_seq_forward(x, *args).clone()
+            ops.set_gru_persistent(False, dev)
+            hl = ops.gru_seq_forward(x, *args).clone()
+            assert torch.isfinite(hp).all()
+            assert (hp - hl).abs().max().item() < 2e-5, (b, t)
+            assert not torch.equal(hp, hl) or t == 1      # the persistent kernel really ran (different summation order)
+            if b == 5:
+                with torch.no_grad():
+                    ref = O.gru_seq(sd, "gru.", x.cpu()) if hasattr(O, "gru_seq") else None
+                if ref is not None:
+                    assert (hp.cpu() - ref).abs().max().item() < 1e-4
+    finally:
+        ops.set_gru_persistent(True, dev)
+
+
 def test_fc_meanpool_vs_oracle(dev, ops, O):
     sd = {"weight": rnd((174, 2048), 71, 0.02), "bias": rnd((174,), 72, 0.05)}
     feat = rnd((3 * 8, 2048), 73)
