@@ -343,6 +343,27 @@ def test_resnet50_trunk_error_vs_fp64_split_same_order(dev, O):
     assert e_split <= 2.0 * e_native + 1e-8, (e_native, e_split)
 
 
+def test_tsm_trunk_clip_invariance_full_size(dev):
+    """BASELINE config 4 size (64 clips x 8 frames of 128^2): with the temporal shift fused into conv1 a clip's features
+    may depend only on that clip's own frames, whatever else is in the batch -- bit-identical when two clips are
+    recomputed alone (different tile choices, same fma chains, shift confined to the clip)."""
+    net, _ = _trunk(dev, 4004)
+    net.tsm_segments = 8
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn((512, 128, 128, 4), generator=gen)
+    x[..., 3] = 0
+    x = x.to(dev)
+    with torch.no_grad():
+        big = net.features_nhwc4(x).clone()
+        small = net.features_nhwc4(x[40:56].contiguous()).clone()      # clips 5 and 6
+    assert torch.isfinite(big).all() and big.abs().max().item() > 0.1
+    assert torch.equal(big[40:56], small)
+    # and the shift is really on: the same frames in a different clip position give different features
+    with torch.no_grad():
+        rolled = net.features_nhwc4(x[41:57].contiguous())
+    assert not torch.equal(rolled[:15], big[41:56])
+
+
 def test_resnet50_batch_invariance_full_size(dev):
     """BASELINE size (N = 1024 patches of 96^2): the tile choice changes with the problem size but
     the fp32 fma chain per output does not, so a patch's feature must be bit-identical whether it
