@@ -488,6 +488,28 @@ def test_act_full_forward_golden(dev):
         pytest.xfail("policy argmax flipped on a near-tie (different fp32 summation order); forced-action parity passed")
 
 
+def test_hot_path_concurrent_streams_deterministic(dev):
+    """48 hot-path steps round-robined over 4 HIP streams (as bench.py pipelines its batches): every step owns its
+    workspaces, the persistent GRU scans of different streams share the device through their grid barriers -- each result
+    must be bit-identical to a run on its own."""
+    m, _ = _act_model(dev)
+    b, t = 8, 8
+    frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=9)).to(dev).view(b * t, 3, 224, 224)
+    _, act = synth.synth_actions(b * t, 7, seed=4)
+    actions = torch.from_numpy(act).to(dev)
+    gvec = rnd((b, t, 1280), 33).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    with torch.no_grad():
+        ref = m.hot_path(frames, gvec, actions, b, t)[0].clone()
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(48):
+            with torch.cuda.stream(streams[i % 4]):
+                outs.append(m.hot_path(frames, gvec, actions, b, t)[0])
+        torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+
+
 def test_validate_loop_real_model_on_gpu(dev):
     """evaluate.validate (stage-3 loop, ACT/main_dist.py:307-422) driving the real GFV on the GPU over a 5-clip set
     with a ragged last batch: its summary must equal the metrics of the model's own per-clip logits."""
