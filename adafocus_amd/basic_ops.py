@@ -1,35 +1,48 @@
-"""Host mirror of STH/ops/basic_ops.py: ``ConsensusModule('avg')`` = temporal mean with keepdim
-(:17-26).  Stand-alone it is a plain reduction; on the model path it is fused with the classifier FC in
-``adaf_fc_meanpool_forward_f32``."""
+"""Host mirror of STH/ops/basic_ops.py (:17-26): the temporal-consensus module the STH model applies to its per-frame
+logits.  Only two behaviours exist in the reference -- 'avg' (mean over the segment axis, kept as a size-1 axis) and
+'identity' (also what 'rnn' maps to); anything else yields None there, and here.  Stand-alone this is a plain reduction;
+on the model path the mean is fused with the classifier FC in ``adaf_fc_meanpool_forward_f32``."""
 import torch
+from torch import nn
 
 __all__ = ["ConsensusModule", "SegmentConsensus", "Identity"]
 
+_REDUCERS = {
+    "avg": lambda x, axis: torch.mean(x, axis, keepdim=True),
+    "identity": lambda x, axis: x,
+}
 
-class Identity(torch.nn.Module):
-    def forward(self, input):
-        return input
+
+def _consensus(kind, x, axis):
+    fn = _REDUCERS.get(kind)
+    return fn(x, axis) if fn is not None else None
 
 
-class SegmentConsensus(torch.nn.Module):
+class Identity(nn.Module):
+    """Pass-through (same name as the reference's helper)."""
+
+    def forward(self, x):
+        return x
+
+
+class SegmentConsensus(nn.Module):
+    """Reduction over the segment axis selected by name."""
+
     def __init__(self, consensus_type, dim=1):
         super().__init__()
-        self.consensus_type = consensus_type
-        self.dim = dim
+        self.consensus_type, self.dim = consensus_type, dim
 
-    def forward(self, input_tensor):
-        if self.consensus_type == "avg":
-            return input_tensor.mean(dim=self.dim, keepdim=True)
-        if self.consensus_type == "identity":
-            return input_tensor
-        return None
+    def forward(self, x):
+        return _consensus(self.consensus_type, x, self.dim)
 
 
-class ConsensusModule(torch.nn.Module):
+class ConsensusModule(nn.Module):
+    """Constructor-compatible with the reference: ``ConsensusModule('avg')(logits[B, T, C]) -> [B, 1, C]``."""
+
     def __init__(self, consensus_type, dim=1):
         super().__init__()
-        self.consensus_type = consensus_type if consensus_type != "rnn" else "identity"
+        self.consensus_type = "identity" if consensus_type == "rnn" else consensus_type
         self.dim = dim
 
-    def forward(self, input):
-        return SegmentConsensus(self.consensus_type, self.dim)(input)
+    def forward(self, x):
+        return _consensus(self.consensus_type, x, self.dim)
