@@ -219,6 +219,19 @@ def test_conv_split_error_vs_fp64_not_worse_than_fp32(dev, ops):
     assert err[43][1] < 1e-4 and err[33][1] < 1e-4, err
 
 
+def test_option_setters_validate_their_arguments(dev):
+    from adafocus_amd._lib import AdafError
+    net, _ = _trunk(dev, 1007)
+    trunk = net._sync()
+    with pytest.raises(AdafError):
+        trunk.set_math(7)
+    with pytest.raises(AdafError):
+        trunk.set_tiles([0] * 52)          # one entry per conv launch (53)
+    with pytest.raises(AdafError):
+        trunk.set_tiles([0] * 52 + [1234])
+    trunk.set_math("f32")
+
+
 def test_conv_rejects_bad_arguments(dev, ops):
     from adafocus_amd._lib import AdafError
     x = torch.zeros((1, 4, 4, 6), device=dev)
