@@ -129,8 +129,8 @@ def cpu_baseline(sd, t, p, clips, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--patch", type=int, default=96)
