@@ -12,6 +12,11 @@ struct adaf_handle {
     int cus = 256;
     float* zeros = nullptr;  // device, 256 bytes of zeros
     int gru_persistent = 1;  // GRU scans as one persistent kernel where the shape allows (gru_scan.hip)
+    // At most ADAF_SCAN_SLOTS persistent scans may execute at once (their grid barriers need every block resident and
+    // the device holds four scans' worth): launch i waits for the completion event of launch i - ADAF_SCAN_SLOTS.
+    hipEvent_t scan_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool scan_used[4] = {false, false, false, false};
+    int scan_next = 0;
     std::string err;
 };
 

@@ -88,6 +88,7 @@ int adaf_create(int device, adaf_handle** out) {
     (void)hipSetDevice(device);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->zeros), 256);
     if (e == hipSuccess) e = hipMemset(h->zeros, 0, 256);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->scan_done[i], hipEventDisableTiming);
     (void)hipSetDevice(cur);
     if (e != hipSuccess) { delete h; return ADAF_E_NOMEM; }
     *out = h;
@@ -96,6 +97,9 @@ int adaf_create(int device, adaf_handle** out) {
 
 int adaf_destroy(adaf_handle* h) {
     if (h && h->zeros) (void)hipFree(h->zeros);
+    if (h)
+        for (int i = 0; i < 4; ++i)
+            if (h->scan_done[i]) (void)hipEventDestroy(h->scan_done[i]);
     delete h;
     return ADAF_OK;
 }
@@ -578,7 +582,12 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
     if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
     if (h->gru_persistent && adaf_gru_scan_persistent_ok(batch, hidden, h->cus)) {
         // the whole recurrence in one kernel; `gh` only lends its first `steps` words to the grid barrier
+        const int slot = h->scan_next;
+        h->scan_next = (slot + 1) & 3;
+        if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan four launches ago has finished
         adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, hs, reinterpret_cast<unsigned*>(gh), batch, steps, st);
+        (void)hipEventRecord(h->scan_done[slot], st);
+        h->scan_used[slot] = true;
         return ADAF_OK;
     }
     for (int t = 0; t < steps; ++t) {
