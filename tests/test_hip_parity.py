@@ -502,22 +502,23 @@ def test_act_full_forward_golden(dev):
 
 
 def test_hot_path_concurrent_streams_deterministic(dev):
-    """48 hot-path steps round-robined over 4 HIP streams (as bench.py pipelines its batches): every step owns its
-    workspaces, the persistent GRU scans of different streams share the device through their grid barriers -- each result
-    must be bit-identical to a run on its own."""
+    """48 hot-path steps round-robined over 6 HIP streams (bench.py pipelines its batches the same way): every step owns
+    its workspaces; the persistent GRU scans of different streams share the device through their grid barriers, and with
+    more streams than the four scan slots the launcher's event ring has to serialise the surplus -- each result must be
+    bit-identical to a run on its own."""
     m, _ = _act_model(dev)
     b, t = 8, 8
     frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=9)).to(dev).view(b * t, 3, 224, 224)
     _, act = synth.synth_actions(b * t, 7, seed=4)
     actions = torch.from_numpy(act).to(dev)
     gvec = rnd((b, t, 1280), 33).to(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(6)]
     with torch.no_grad():
         ref = m.hot_path(frames, gvec, actions, b, t)[0].clone()
         torch.cuda.synchronize()
         outs = []
         for i in range(48):
-            with torch.cuda.stream(streams[i % 4]):
+            with torch.cuda.stream(streams[i % 6]):
                 outs.append(m.hot_path(frames, gvec, actions, b, t)[0])
         torch.cuda.synchronize()
     assert all(torch.equal(o, ref) for o in outs)
