@@ -343,6 +343,18 @@ def main():
                     table = model.focuser.action_table(dev)
                     pol_ms, _ = timed(lambda: model.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table))
                     full_ms, _ = timed(lambda: model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t), 3)
+                # the same forward with consecutive batches round-robined over the streams, as the timed hot path is
+                with torch.no_grad():
+                    for i in range(len(streams)):
+                        with torch.cuda.stream(streams[i]):
+                            model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(9):
+                        with torch.cuda.stream(streams[i % len(streams)]):
+                            model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t)
+                    torch.cuda.synchronize()
+                    piped_ms = (time.perf_counter() - t1) / 9 * 1e3
                 ing_bytes = float(b * t * 224 * 224 * (3 + 16))
                 gl_bytes = float(b * t) * 4.0 * (2 * 6.68e6 + 224 * 224 * 4)      # 6.68 M conv-output elements/frame
                 res["next_rows"] = {
@@ -355,6 +367,8 @@ def main():
                     "f2_policy": {"ms": round(pol_ms, 3), "note": "1x1 conv + FC over all B*T frames, GRU scan over T, arg-max + grid lookup"},
                     "full_forward_from_uint8": {"value": round(b / full_ms * 1e3, 1), "unit": "clips/s", "ms": round(full_ms, 3),
                                                 "note": "ingest + glancer + policy + hot path (GFV.offline_forward_nhwc4), serial on one stream"},
+                    "full_forward_from_uint8_pipelined": {"value": round(b / piped_ms * 1e3, 1), "unit": "clips/s", "ms": round(piped_ms, 3),
+                                                          "note": "same, consecutive batches round-robined over %d streams" % len(streams)},
                 }
                 del u8, fr4, fmap, fvec
             except Exception as exc:  # upstream of the timed path; never fail the bench on it
