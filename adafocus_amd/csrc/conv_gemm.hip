@@ -799,8 +799,14 @@ __global__ void conv_naive_kernel(const ConvArgs a) {
 
 struct TileShape { int bm, bn; float eff; };
 // eff: relative MFMA efficiency of the main loop; refined from profiles/ measurements.
-// Tiles 1..4 are the production shapes; higher ids are variants reachable only through the
-// explicit `tile` override (tools/conv_probe.py).  Ids 21.. use the direct-to-LDS kernel.
+// Tile ids (adaf_conv_params.tile / adaf_resnet50_set_tiles):
+//    1..5   register-staged kernel: 128x128, 128x64, 64x64, 64x128, 256x128 (the fallback for shapes the DMA form cannot take)
+//   21..27  direct-to-LDS kernel, DMA issued at the top of a slice (kept for A/B)
+//   31..37  direct-to-LDS kernel, DMA issued between the MFMA groups  <- what the cost model picks (id + 30)
+//   40      automatic choice among the split tiles; 41..47 split (6 products), operands split on the fly; 51..54 9 products
+//   61..67  split (6 products) with the weights pre-split at load time (ConvArgs::wsp; trunk only)
+//   71..74  fp32 pipe with the barrier between steps 2 and 3 of a slice (measured variant, not the default)
+// Everything above 4 is reachable only through an explicit override (tools/conv_probe.py, tests).
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
     {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.02f}, {64, 64, 0.98f}, {64, 128, 0.99f}};
 
