@@ -94,6 +94,9 @@ def cal_map(output, old_test_y):
     return ap.mean() * 100, ap * 100
 
 
+_PINNED = {}     # (slot, batch size, item shape, dtype) -> pinned staging buffer, reused across validate() calls
+
+
 class _Prefetcher:
     """Batches of this rank's shard, one ahead: batch i+1 is stacked into pinned host memory and copied to the GPU on a
     side stream while batch i computes (the reference stacks in DataLoader workers and copies synchronously with
@@ -106,6 +109,8 @@ class _Prefetcher:
         self.cuda = dev.type == "cuda"
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
         self.pinned = [None, None]
+        self.devbuf = [None, None]          # device-side landing buffers, reused (no allocator traffic per batch)
+        self.consumed = [None, None]        # event: the forward that read a device slot has been enqueued ... and finishes
         self.copied = [None, None]          # event of the last H2D copy out of each pinned slot
         self.pool = ThreadPoolExecutor(max_workers=8) if self.cuda else None   # large tensor copies release the GIL
         self.slot = 0
@@ -120,7 +125,7 @@ class _Prefetcher:
         items = [self.ds[j] for j in range(lo, min(lo + self.bs, self.stop))]
         tgt = torch.stack([it[1] for it in items])
         if not self.cuda:
-            self.next = (torch.stack([it[0] for it in items]).to(self.dev), tgt, None)
+            self.next = (torch.stack([it[0] for it in items]).to(self.dev), tgt, None, 0)
             return
         first = items[0][0]
         shape = (len(items),) + tuple(first.shape)
@@ -128,25 +133,51 @@ class _Prefetcher:
             self.copied[self.slot].synchronize()        # the previous copy out of this slot has left the host buffer
         buf = self.pinned[self.slot]
         if buf is None or buf.shape[1:] != shape[1:] or buf.shape[0] < shape[0] or buf.dtype != first.dtype:
-            buf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype).pin_memory()
+            key = (self.slot, self.bs, tuple(first.shape), first.dtype)
+            buf = _PINNED.get(key)
+            if buf is None:       # page-locking ~150-600 MB costs tens of milliseconds: do it once per process
+                buf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype).pin_memory()
+                _PINNED[key] = buf
             self.pinned[self.slot] = buf
         host = buf[:shape[0]]
         list(self.pool.map(lambda jt: host[jt[0]].copy_(jt[1][0]), enumerate(items)))
+        dbuf = self.devbuf[self.slot]
+        if dbuf is None or dbuf.shape[1:] != shape[1:] or dbuf.dtype != first.dtype:
+            dbuf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype, device=self.dev)
+            self.devbuf[self.slot] = dbuf
+        devt = dbuf[:shape[0]]
+        # the labels ride along: a pageable .to(device) inside the loop would block the host until the stream drains
+        tkey = ("tgt", self.slot, self.bs, tuple(tgt.shape[1:]), tgt.dtype)
+        tpin = _PINNED.get(tkey)
+        if tpin is None:
+            tpin = torch.empty((self.bs,) + tuple(tgt.shape[1:]), dtype=tgt.dtype).pin_memory()
+            _PINNED[tkey] = tpin
+        tpin[:shape[0]].copy_(tgt)
         with torch.cuda.stream(self.stream):
-            devt = host.to(self.dev, non_blocking=True)
+            if self.consumed[self.slot] is not None:
+                self.stream.wait_event(self.consumed[self.slot])   # the batch that last used this slot has been computed
+            devt.copy_(host, non_blocking=True)
+            tgt_dev = tpin[:shape[0]].to(self.dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.copied[self.slot] = ev
+        self.next = (devt, tgt_dev, ev, self.slot)
         self.slot ^= 1
-        self.next = (devt, tgt, ev)
 
     def __iter__(self):
         for i in range(len(self.los)):
-            images, tgt, ev = self.next
+            images, tgt, ev, slot = self.next
             if ev is not None:
                 torch.cuda.current_stream(self.dev).wait_event(ev)
-                images.record_stream(torch.cuda.current_stream(self.dev))
-            yield i, images, tgt, (lambda n=i + 1: self._issue(n))
+                tgt.record_stream(torch.cuda.current_stream(self.dev))
+
+            def stage_next(n=i + 1, slot=slot):
+                if self.cuda:      # called right after this batch's forward was enqueued: marks the end of its reads
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.dev))
+                    self.consumed[slot] = done
+                self._issue(n)
+            yield i, images, tgt, stage_next
 
 
 @torch.no_grad()
@@ -178,7 +209,8 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
 
     pending = None        # batch i's scalars are read back after batch i+1 has been enqueued: the GPU never idles on them
     for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
-        target = target_full[:, 0].to(dev)
+        target_full = target_full.to(dev)      # already there (and asynchronous) on the GPU path
+        target = target_full[:, 0]
         b = images.shape[0]
         if images.dtype == torch.uint8:
             from .transforms import ingest_uint8
@@ -191,7 +223,7 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
         acc1, acc5 = accuracy(pred, target, topk=(1, 5))
         preds.append(pred)
         step_logits.append(outputs.reshape(b, args.num_segments, -1))
-        targets.append(target_full.to(dev))
+        targets.append(target_full)
         if pending is not None:
             finish(pending)
         pending = (bi, b, loss, acc1, acc5)
