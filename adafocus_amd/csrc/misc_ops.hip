@@ -155,29 +155,32 @@ __global__ void pack_dw_weight_kernel(const float* __restrict__ w, int c, float*
 // HBM/L2-bound VALU work (no contraction across channels, so the matrix cores have nothing to do): taps are
 // aligned 16-byte loads that neighbouring lanes (adjacent channel groups) coalesce; a thread that owns PX
 // horizontally adjacent outputs loads each input column once (stride 1: PX+2 columns instead of 3*PX).
-template <int PX, int S>
-__global__ void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow,
+template <int PX, int S, int RY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow,
                                  const float* __restrict__ wt, const float* __restrict__ scale,
                                  const float* __restrict__ bias, float lo, float hi, float* __restrict__ o) {
+    // a thread owns PX horizontally adjacent outputs of RY consecutive output rows: the S*(RY-1)+3 input rows and
+    // S*(PX-1)+3 input columns they touch are loaded once
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int owg = (ow + PX - 1) / PX;
-    const long long total = (long long)n * oh * owg * c4;
+    const int owg = (ow + PX - 1) / PX, ohg = (oh + RY - 1) / RY;
+    const long long total = (long long)n * ohg * owg * c4;
     if (idx >= total) return;
     const int cq = (int)(idx % c4);
     long long t = idx / c4;
     const int oxg = (int)(t % owg);
     t /= owg;
-    const int oy = (int)(t % oh);
-    const int img = (int)(t / oh);
+    const int oy0 = (int)(t % ohg) * RY;
+    const int img = (int)(t / ohg);
     const int c = 4 * c4;
     const int ox0 = oxg * PX;
     constexpr int NC = S * (PX - 1) + 3;   // input columns the PX outputs touch
+    constexpr int NR = S * (RY - 1) + 3;   // input rows the RY output rows touch
     // every tap is loaded unconditionally from a clamped (always valid) address and zeroed by a select, so
-    // the 3 x NC loads of a thread are independent and issue back to back (no branch, no wait in between)
-    f32x4 v[3][NC];
+    // the NR x NC loads of a thread are independent and issue back to back (no branch, no wait in between)
+    f32x4 v[NR][NC];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * S - 1 + ky;
+    for (int ky = 0; ky < NR; ++ky) {
+        const int iy = oy0 * S - 1 + ky;
         const bool rv = (unsigned)iy < (unsigned)h;
         const float* row = x + (((size_t)img * h + min(max(iy, 0), h - 1)) * w) * (size_t)c + 4 * cq;
 #pragma unroll
@@ -188,35 +191,43 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int 
             v[ky][ci] = ok ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    f32x4 acc[PX];
+    f32x4 acc[RY][PX];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[r][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const f32x4 k = *reinterpret_cast<const f32x4*>(wt + (ky * 3 + kx) * c + 4 * cq);
 #pragma unroll
-            for (int p = 0; p < PX; ++p) {
-                const f32x4 a = v[ky][p * S + kx];
-                acc[p].x = fmaf(a.x, k.x, acc[p].x);
-                acc[p].y = fmaf(a.y, k.y, acc[p].y);
-                acc[p].z = fmaf(a.z, k.z, acc[p].z);
-                acc[p].w = fmaf(a.w, k.w, acc[p].w);
-            }
+            for (int r = 0; r < RY; ++r)
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const f32x4 a = v[r * S + ky][p * S + kx];
+                    acc[r][p].x = fmaf(a.x, k.x, acc[r][p].x);
+                    acc[r][p].y = fmaf(a.y, k.y, acc[r][p].y);
+                    acc[r][p].z = fmaf(a.z, k.z, acc[r][p].z);
+                    acc[r][p].w = fmaf(a.w, k.w, acc[r][p].w);
+                }
         }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
     const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
-        const int ox = ox0 + p;
-        if (ox < ow) {
-            f32x4 r;
-            r.x = fminf(fmaxf(fmaf(acc[p].x, sc.x, bi.x), lo), hi);
-            r.y = fminf(fmaxf(fmaf(acc[p].y, sc.y, bi.y), lo), hi);
-            r.z = fminf(fmaxf(fmaf(acc[p].z, sc.z, bi.z), lo), hi);
-            r.w = fminf(fmaxf(fmaf(acc[p].w, sc.w, bi.w), lo), hi);
-            *reinterpret_cast<f32x4*>(o + ((((size_t)img * oh + oy) * ow + ox) * (size_t)c + 4 * cq)) = r;
+    for (int rr = 0; rr < RY; ++rr) {
+        const int oy = oy0 + rr;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int ox = ox0 + p;
+            if (ox < ow && oy < oh) {
+                f32x4 r;
+                r.x = fminf(fmaxf(fmaf(acc[rr][p].x, sc.x, bi.x), lo), hi);
+                r.y = fminf(fmaxf(fmaf(acc[rr][p].y, sc.y, bi.y), lo), hi);
+                r.z = fminf(fmaxf(fmaf(acc[rr][p].z, sc.z, bi.z), lo), hi);
+                r.w = fminf(fmaxf(fmaf(acc[rr][p].w, sc.w, bi.w), lo), hi);
+                *reinterpret_cast<f32x4*>(o + ((((size_t)img * oh + oy) * ow + ox) * (size_t)c + 4 * cq)) = r;
+            }
         }
     }
 }
@@ -314,13 +325,13 @@ void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int strid
     const int oh = (h + 2 - 3) / stride + 1, ow = (w + 2 - 3) / stride + 1;
     const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
     const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
-    if (stride == 1) {   // 4 outputs share 6 input columns
-        const long long total = (long long)n * oh * ((ow + 3) / 4) * (c / 4);
-        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
+    if (stride == 1) {   // 4 x 2 outputs share 6 input columns x 4 input rows (24 loads for 8 outputs instead of 36)
+        const long long total = (long long)n * ((oh + 1) / 2) * ((ow + 3) / 4) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 2>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
                            scale, bias, lo, hi, o);
     } else {             // 2 outputs share 5 input columns (more would spill the tap registers)
         const long long total = (long long)n * oh * ((ow + 1) / 2) * (c / 4);
-        hipLaunchKernelGGL((dwconv3x3_kernel<2, 2>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
+        hipLaunchKernelGGL((dwconv3x3_kernel<2, 2, 1>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
                            scale, bias, lo, hi, o);
     }
 }
