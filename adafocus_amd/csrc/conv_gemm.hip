@@ -802,7 +802,8 @@ struct TileShape { int bm, bn; float eff; };
 // Tile ids (adaf_conv_params.tile / adaf_resnet50_set_tiles):
 //    1..5   register-staged kernel: 128x128, 128x64, 64x64, 64x128, 256x128 (the fallback for shapes the DMA form cannot take)
 //   21..27  direct-to-LDS kernel, DMA issued at the top of a slice (kept for A/B)
-//   31..37  direct-to-LDS kernel, DMA issued between the MFMA groups  <- what the cost model picks (id + 30)
+//   31..39  direct-to-LDS kernel, DMA issued between the MFMA groups  <- what the cost model picks (id + 30);
+//           38 / 39 = 128x32 / 256x32 for cout <= 32 (MobileNetV2 project convs)
 //   40      automatic choice among the split tiles; 41..47 split (6 products), operands split on the fly; 51..54 9 products
 //   61..67  split (6 products) with the weights pre-split at load time (ConvArgs::wsp; trunk only)
 //   71..74  fp32 pipe with the barrier between steps 2 and 3 of a slice (measured variant, not the default)
@@ -870,7 +871,10 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
     if (tile > 60 && tile < 70 && !bsp_ok) tile = tile >= 65 ? 41 : tile - 20;
     if (tile <= 0) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
-        if (adaf_conv_glds_ok(a)) tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
+        if (adaf_conv_glds_ok(a)) {
+            tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
+            if (a.N <= 32 && (long long)((a.M + 127) / 128) >= cus) tile = 38;   // narrow outputs: no MFMA columns wasted on padding
+        }
     }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     if (tile > 70 && !adaf_conv_glds_ok(a)) tile -= 70;
@@ -895,6 +899,8 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 33: launch_glds<64, 64, 2, 2, true>(a, dense, s); break;
         case 34: launch_glds<64, 128, 2, 2, true>(a, dense, s); break;
         case 37: launch_glds<256, 256, 2, 4, true>(a, dense, s); break;
+        case 38: launch_glds<128, 32, 4, 1, true>(a, dense, s); break;    // narrow outputs (cout <= 32): four waves of 32x32
+        case 39: launch_glds<256, 32, 4, 1, true>(a, dense, s); break;    // narrow outputs: four waves of 64x32
         // 7x: fp32 pipe with the barrier between steps 2 and 3 of a slice (next slice's first fragments prefetched)
         case 71: launch_glds<128, 128, 2, 2, 2>(a, dense, s); break;
         case 72: launch_glds<128, 64, 2, 2, 2>(a, dense, s); break;
