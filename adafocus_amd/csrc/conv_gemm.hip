@@ -873,7 +873,10 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus);
         if (adaf_conv_glds_ok(a)) {
             tile += 30;   // direct-to-LDS, DMA issued between MFMA groups
-            if (a.N <= 32 && (long long)((a.M + 127) / 128) >= cus) tile = 38;   // narrow outputs: no MFMA columns wasted on padding
+            // 32-wide column tiles when 64-wide ones would spend >= 20 % of the MFMA columns on padding (cout = 16, 24, 32,
+            // 96, 160: MobileNetV2's project convs) and there are enough row tiles to fill the device
+            const int pad64 = ((a.N + 63) / 64) * 64;
+            if ((pad64 - a.N) * 5 >= a.N && (long long)((a.M + 127) / 128) >= cus) tile = 38;
         }
     }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
