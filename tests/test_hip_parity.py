@@ -2,6 +2,7 @@
 golden vectors.  Bit-exact for crop indices / payload / temporal shift; fp32 results within
 abs 1e-3 (north-star tolerance; most checks are far tighter and say so)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -230,6 +231,18 @@ def test_option_setters_validate_their_arguments(dev):
     with pytest.raises(AdafError):
         trunk.set_tiles([0] * 52 + [1234])
     trunk.set_math("f32")
+
+
+def test_conv_engine_randomised_shapes():
+    """80 random (n, hw, cin, cout, k, stride, pad, act, residual, fused shift) cases x 5 tile choices against the naive
+    on-device kernel (tools/conv_fuzz.py, fixed seed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "80", "7"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "MISMATCH" not in out.stdout and "cases x 5 tiles done" in out.stdout, out.stdout[-1500:]
 
 
 def test_conv_rejects_bad_arguments(dev, ops):
