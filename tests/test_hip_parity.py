@@ -103,6 +103,33 @@ def test_crop_edge_cases(dev, ops, O):
         ops.crop_gather(fr, a, 32)                            # CPU tensors: no fallback
 
 
+def test_crop_randomised_shapes(dev, ops, O):
+    """60 random (N, C, H = W, P, frames-per-action, layout) cases, actions drawn from [0, 1] including both ends: every
+    layout bit-exact against the oracle's get_patch, coordinates against floor(a * (H - P)) in fp32."""
+    rng = np.random.default_rng(11)
+    for case in range(60):
+        c = int(rng.choice([1, 3, 3, 4, 24]))
+        hw = int(rng.integers(8, 120))
+        p = int(rng.integers(1, hw + 1))
+        fpa = int(rng.choice([1, 1, 2, 4]))
+        m = int(rng.integers(1, 9))
+        n = m * fpa
+        fr = torch.from_numpy(rng.standard_normal((n, c, hw, hw), dtype=np.float32))
+        a = torch.from_numpy(rng.random((m, 2), dtype=np.float32))
+        a[rng.integers(0, m)] = torch.tensor([1.0, 0.0])
+        a[rng.integers(0, m)] = torch.tensor([0.0, 1.0])
+        ref = O.get_patch(fr.view(m, fpa * c, hw, hw), a, p).view(n, c, p, p)
+        got, coords = ops.crop_gather(fr.to(dev), a.to(dev), p, fpa, return_coords=True)
+        assert torch.equal(got.cpu(), ref), (case, n, c, hw, p, fpa)
+        assert torch.equal(coords.cpu(), torch.floor(a * (hw - p)).int()), case
+        if c <= 16:        # the pixel-major outputs are defined for up to 16 channels
+            nhwc = ops.crop_gather(fr.to(dev), a.to(dev), p, fpa, ops.LAYOUT_NHWC).cpu()
+            assert torch.equal(nhwc, ref.permute(0, 2, 3, 1)), case
+        if c == 3:
+            n4 = ops.crop_gather(fr.to(dev), a.to(dev), p, fpa, ops.LAYOUT_NHWC4).cpu()
+            assert torch.equal(n4[..., :3], ref.permute(0, 2, 3, 1)) and float(n4[..., 3].abs().max()) == 0.0, case
+
+
 def test_crop_full_size_roundtrip(dev, ops):
     """BASELINE size (B=64, T=16, P=96): each patch equals the slice it was cut from (checked on
     the device with plain indexing) and the patch checksum equals the checksum of the windows."""
