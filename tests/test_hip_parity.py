@@ -687,7 +687,10 @@ def test_tsm_glancer_shift_kernel(dev, O):
 
 # ------------------------------------------------------------------------------------ glancer + policy on the engine
 def test_depthwise_conv_vs_torch(dev, ops):
-    for (n, h, w, c, stride) in [(2, 16, 16, 32, 1), (3, 15, 17, 96, 2), (2, 7, 7, 960, 1), (1, 56, 56, 144, 2)]:
+    rng = np.random.default_rng(5)
+    extra = [(int(rng.integers(1, 5)), int(rng.integers(1, 30)), int(rng.integers(1, 30)), 4 * int(rng.integers(1, 40)), int(rng.choice([1, 2])))
+             for _ in range(24)]      # odd extents, 1-pixel maps, widths that are not multiples of the 4x2 / 2x1 thread tiles
+    for (n, h, w, c, stride) in [(2, 16, 16, 32, 1), (3, 15, 17, 96, 2), (2, 7, 7, 960, 1), (1, 56, 56, 144, 2)] + extra:
         g = np.random.Generator(np.random.PCG64([n, h, c, stride]))
         x = torch.from_numpy(g.standard_normal((n, c, h, w), dtype=np.float32))
         wt = torch.from_numpy(g.standard_normal((c, 1, 3, 3), dtype=np.float32) * np.float32(0.3))
