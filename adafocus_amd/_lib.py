@@ -29,7 +29,7 @@ SYMBOLS = (
     "adaf_pack_dw_weight_f32", "adaf_dwconv3x3_bn_act_f32", "adaf_mobilenetv2_create", "adaf_mobilenetv2_destroy",
     "adaf_mobilenetv2_set_param", "adaf_mobilenetv2_finalize", "adaf_mobilenetv2_workspace_bytes",
     "adaf_mobilenetv2_forward", "adaf_mobilenetv2_set_fusion", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
-    "adaf_crop_gather_nhwc4_f32", "adaf_ingest_u8_f32",
+    "adaf_crop_gather_nhwc4_f32", "adaf_ingest_u8_f32", "adaf_crop_resize_f32", "adaf_resize_nearest_f32",
 )
 
 
@@ -97,9 +97,11 @@ def load_library():
     lib.adaf_mobilenetv2_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, C.c_size_t, vp]
     lib.adaf_mobilenetv2_set_fusion.argtypes = [vp, ip]
     lib.adaf_grid_actions_f32.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp]
-    lib.adaf_gru_seq_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.adaf_gru_seq_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.adaf_crop_gather_nhwc4_f32.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, vp]
     lib.adaf_ingest_u8_f32.argtypes = [vp, vp, ip, ip, ip, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]
+    lib.adaf_crop_resize_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, ip, ip, vp, ip, ip, vp, ip, vp, vp]
+    lib.adaf_resize_nearest_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp, ip, vp]
     _lib = lib
     return lib
 
@@ -132,6 +134,16 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def on_current_device(*tensors):
+    """Kernels are launched on the CURRENT device's current stream: refuse tensors that live elsewhere (a launch on
+    the wrong device would be an invalid-handle error at best, unsynchronised peer access at worst)."""
+    cur = torch.cuda.current_device()
+    for t in tensors:
+        if t is not None and t.is_cuda and t.device.index != cur:
+            raise AdafError("adafocus_amd: tensor on cuda:%d but the current device is cuda:%d -- wrap the call in "
+                            "torch.cuda.device(%d) (one process per GPU is the supported mode)" % (t.device.index, cur, t.device.index))
+
+
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -145,3 +157,4 @@ def need_gpu_f32(*tensors):
             raise AdafError("adafocus_amd runs on MI355X only: got a %s tensor (no CPU fallback exists)" % t.device)
         if t.dtype != torch.float32:
             raise AdafError("adafocus_amd computes in fp32: got %s" % t.dtype)
+    on_current_device(*tensors)

@@ -11,12 +11,15 @@ struct adaf_handle {
     int device = 0;
     int cus = 256;
     float* zeros = nullptr;  // device, 256 bytes of zeros
-    int gru_persistent = 1;  // GRU scans as one persistent kernel where the shape allows (gru_scan.hip)
-    // At most ADAF_SCAN_SLOTS persistent scans may execute at once (their grid barriers need every block resident and
-    // the device holds four scans' worth): launch i waits for the completion event of launch i - ADAF_SCAN_SLOTS.
+    int gru_persistent = 1;  // GRU scans as one persistent kernel where the shape allows (gru_scan.hip): 0 off, 1 on, 2 on + cooperative launch
+    // At most scan_slots persistent scans may execute at once (their grid barriers need every block resident; how many
+    // fit is ASKED of the runtime at adaf_create: scan_resident = blocks per CU x CUs): launch i waits for the
+    // completion event of launch i - scan_slots.
     hipEvent_t scan_done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool scan_used[4] = {false, false, false, false};
     int scan_next = 0;
+    int scan_resident = 0;   // scan blocks the device can hold at once (occupancy query)
+    int scan_slots = 1;      // min(4, scan_resident / blocks per scan)
     std::string err;
 };
 
@@ -76,18 +79,26 @@ bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
 
 // gru_scan.hip
-bool adaf_gru_scan_persistent_ok(int batch, int hidden, int cus);
-void adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, float* hs, unsigned* bar, int batch,
-                                     int steps, hipStream_t s);
+int adaf_gru_scan_blocks_per_cu();
+bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int resident_blocks);
+hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
+                                           unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
+                                           float* logits, float* last, int classes, bool cooperative, hipStream_t s);
 
 // conv_gemm.hip
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0
 int adaf_pick_conv_tile(int M, int N, int K, int cus);
+bool adaf_conv_tile_exists(int tile);   // is `tile` an id adaf_launch_conv_gemm has a kernel for
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
 
 // crop.hip
 hipError_t adaf_launch_crop(const float* frames, int nf, int C, int H, int W, const float* act, int fpa, int P,
                             float* out, int layout, int32_t* coords, hipStream_t s);
+
+hipError_t adaf_launch_crop_resize(const float* frames, int in4, int nf, int C, int H, int W, const float* act, const int32_t* sizes,
+                                   int size_default, int fpa, int P, float* out, int layout, int32_t* coords, hipStream_t s);
+hipError_t adaf_launch_resize_nearest(const float* frames, int in4, int nf, int C, int H, int W, int OH, int OW, float* out,
+                                      int layout, hipStream_t s);
 
 // misc_ops.hip
 void adaf_launch_split_weight(const float* w, size_t count, unsigned short* planes, hipStream_t s);

@@ -89,6 +89,11 @@ int adaf_create(int device, adaf_handle** out) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->zeros), 256);
     if (e == hipSuccess) e = hipMemset(h->zeros, 0, 256);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->scan_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) {
+        h->scan_resident = adaf_gru_scan_blocks_per_cu() * h->cus;
+        const int slots = h->scan_resident / 128;
+        h->scan_slots = slots < 1 ? 1 : (slots > 4 ? 4 : slots);
+    }
     (void)hipSetDevice(cur);
     if (e != hipSuccess) { delete h; return ADAF_E_NOMEM; }
     *out = h;
@@ -108,7 +113,8 @@ const char* adaf_last_error(const adaf_handle* h) { return h ? h->err.c_str() : 
 int adaf_device_cus(const adaf_handle* h) { return h ? h->cus : 0; }
 int adaf_set_gru_persistent(adaf_handle* h, int on) {
     if (!h) return ADAF_E_BADARG;
-    h->gru_persistent = on ? 1 : 0;
+    if (on < 0 || on > 2) return fail(h, ADAF_E_BADARG, "set_gru_persistent: mode %d (0 off, 1 on, 2 on + cooperative launch)", on);
+    h->gru_persistent = on;
     return ADAF_OK;
 }
 
@@ -153,6 +159,57 @@ int adaf_crop_gather_nhwc4_f32(adaf_handle* h, const float* frames_nhwc4, int n_
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "crop_nhwc4 launch");
 }
 
+int adaf_crop_resize_f32(adaf_handle* h, const float* frames, int in_layout, int n_frames, int channels, int height, int width,
+                         const float* action_yx, int n_actions, int frames_per_action, const int32_t* size_px,
+                         int size_default, int patch, float* out, int out_layout, int32_t* coords_out, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (n_frames == 0) return ADAF_OK;
+    if (!frames || !action_yx || !out) return fail(h, ADAF_E_BADARG, "crop_resize: null pointer");
+    if (n_frames < 0 || channels <= 0 || height <= 0 || width <= 0 || patch <= 0 || frames_per_action <= 0)
+        return fail(h, ADAF_E_BADARG, "crop_resize: non-positive extent");
+    if (width < height) return fail(h, ADAF_E_BADARG, "crop_resize: width < height (the reference scales both axes by H-S)");
+    if ((long long)n_actions * frames_per_action != n_frames)
+        return fail(h, ADAF_E_BADARG, "crop_resize: n_actions*frames_per_action != n_frames");
+    if (!size_px && (size_default < 1 || size_default > height))
+        return fail(h, ADAF_E_BADARG, "crop_resize: window size %d outside [1, height=%d]", size_default, height);
+    if (in_layout != ADAF_LAYOUT_NCHW && in_layout != ADAF_LAYOUT_NHWC4) return fail(h, ADAF_E_LAYOUT, "crop_resize: frames must be NCHW or NHWC4");
+    if (out_layout < ADAF_LAYOUT_NCHW || out_layout > ADAF_LAYOUT_NHWC4) return fail(h, ADAF_E_LAYOUT, "crop_resize: unknown output layout");
+    if ((in_layout == ADAF_LAYOUT_NHWC4 || out_layout == ADAF_LAYOUT_NHWC4) && channels != 3) return fail(h, ADAF_E_LAYOUT, "crop_resize: NHWC4 needs 3 channels");
+    if (out_layout == ADAF_LAYOUT_NHWC && channels > 16) return fail(h, ADAF_E_LAYOUT, "crop_resize: NHWC output supports <= 16 channels");
+    if ((in_layout == ADAF_LAYOUT_NHWC4 && !aligned16(frames)) || (out_layout == ADAF_LAYOUT_NHWC4 && !aligned16(out)))
+        return fail(h, ADAF_E_LAYOUT, "crop_resize: 16-byte alignment required for pixel-major buffers");
+    hipStream_t st = (hipStream_t)stream;
+    if (!size_px && size_default == patch) {
+        // scale 1: the resample IS the slice copy -- run the gather itself (bit-exact by construction)
+        if (in_layout == ADAF_LAYOUT_NCHW)
+            return adaf_crop_gather_f32(h, frames, n_frames, channels, height, width, action_yx, n_actions, frames_per_action, patch, out,
+                                        out_layout, coords_out, stream);
+        if (out_layout == ADAF_LAYOUT_NHWC4)
+            return adaf_crop_gather_nhwc4_f32(h, frames, n_frames, height, width, action_yx, n_actions, frames_per_action, patch, out,
+                                              coords_out, stream);
+    }
+    hipError_t e = adaf_launch_crop_resize(frames, in_layout == ADAF_LAYOUT_NHWC4, n_frames, channels, height, width, action_yx, size_px,
+                                           size_default, frames_per_action, patch, out, out_layout, coords_out, st);
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "crop_resize launch");
+}
+
+int adaf_resize_nearest_f32(adaf_handle* h, const float* frames, int in_layout, int n_frames, int channels, int height, int width,
+                            int out_h, int out_w, float* out, int out_layout, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (n_frames == 0) return ADAF_OK;
+    if (!frames || !out) return fail(h, ADAF_E_BADARG, "resize_nearest: null pointer");
+    if (n_frames < 0 || channels <= 0 || height <= 0 || width <= 0 || out_h <= 0 || out_w <= 0)
+        return fail(h, ADAF_E_BADARG, "resize_nearest: non-positive extent");
+    if (in_layout != ADAF_LAYOUT_NCHW && in_layout != ADAF_LAYOUT_NHWC4) return fail(h, ADAF_E_LAYOUT, "resize_nearest: frames must be NCHW or NHWC4");
+    if (out_layout < ADAF_LAYOUT_NCHW || out_layout > ADAF_LAYOUT_NHWC4) return fail(h, ADAF_E_LAYOUT, "resize_nearest: unknown output layout");
+    if ((in_layout == ADAF_LAYOUT_NHWC4 || out_layout == ADAF_LAYOUT_NHWC4) && channels != 3) return fail(h, ADAF_E_LAYOUT, "resize_nearest: NHWC4 needs 3 channels");
+    if ((in_layout == ADAF_LAYOUT_NHWC4 && !aligned16(frames)) || (out_layout == ADAF_LAYOUT_NHWC4 && !aligned16(out)))
+        return fail(h, ADAF_E_LAYOUT, "resize_nearest: 16-byte alignment required for pixel-major buffers");
+    hipError_t e = adaf_launch_resize_nearest(frames, in_layout == ADAF_LAYOUT_NHWC4, n_frames, channels, height, width, out_h, out_w, out,
+                                              out_layout, (hipStream_t)stream);
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "resize_nearest launch");
+}
+
 int adaf_ingest_u8_f32(adaf_handle* h, const uint8_t* clips_hwc, int n_clips, int frames, int height, int width,
                        const float* mean3, const float* std3, float* out_nhwc4, void* stream) {
     if (!h) return ADAF_E_BADARG;
@@ -174,7 +231,8 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > 80) return fail(h, ADAF_E_BADARG, "conv: tile %d out of range", p->tile);
+    if (p->tile < 0 || p->tile > 80 || (p->tile && !adaf_conv_tile_exists(p->tile)))
+        return fail(h, ADAF_E_BADARG, "conv: no kernel variant with tile id %d", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv launch");
@@ -350,6 +408,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
         mark(2.0 * macs, bytes, 0);
         const int used = adaf_launch_conv_gemm(a, p.tile, h->cus, st);
+        if (used < 0) return fail(h, ADAF_E_LAUNCH, "resnet50: no kernel for tile id %d (conv launch %d)", p.tile, li);
         if (info && !info->empty()) info->back().tile = used;
         *oh = a.OH; *ow = a.OW;
         ++li;
@@ -537,7 +596,8 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
     if (!net || !tile || count != (int)net->convs.size()) return ADAF_E_BADARG;
     for (int i = 0; i < count; ++i) {
-        if (tile[i] < 0 || tile[i] > 80) return fail(net->h, ADAF_E_BADARG, "set_tiles: tile %d out of range", tile[i]);
+        if (tile[i] < 0 || tile[i] > 80 || (tile[i] && !adaf_conv_tile_exists(tile[i])))
+            return fail(net->h, ADAF_E_BADARG, "set_tiles: no kernel variant with id %d", tile[i]);
         net->tiles[i] = tile[i];
     }
     return ADAF_OK;
@@ -569,51 +629,63 @@ static int linear_launch(adaf_handle* h, const float* x, int rows, int ldx, int 
     ConvArgs a;
     int rc = make_conv_args(h, &p, x, w, nullptr, bias, nullptr, out, &a);
     if (rc) return rc;
-    adaf_launch_conv_gemm(a, 0, h->cus, st);
+    if (adaf_launch_conv_gemm(a, 0, h->cus, st) < 0) return fail(h, ADAF_E_LAUNCH, "linear: no kernel for this shape");
     return ADAF_OK;
 }
 
-// h_t for every step: hs[b, t, :] (row stride ldh between steps of one clip = hidden, between clips = T*hidden)
+// h_t for every step: hs[b, t, :] (row stride between steps of one clip = hidden, between clips = T*hidden); with fc_w the
+// per-step classifier rides along (logits_all [B*T, C], last [B, C]).
 static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
-                    const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* gi, float* gh,
-                    float* hs, hipStream_t st) {
+                    const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* h0, float* gi,
+                    float* gh, float* hs, const float* fc_w, const float* fc_b, int classes, float* logits_all, float* last,
+                    hipStream_t st) {
     int rc;
     // all input projections at once: gi[b*T+t, :] = W_ih x[b,t] + b_ih
     if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
-    if (h->gru_persistent && adaf_gru_scan_persistent_ok(batch, hidden, h->cus)) {
-        // the whole recurrence in one kernel; `gh` only lends its first `steps` words to the grid barrier
+    if (h->gru_persistent && steps + 1 <= batch * 3 * hidden &&
+        adaf_gru_scan_persistent_ok(batch, hidden, fc_w ? classes : 0, h->scan_resident)) {
+        // the whole recurrence (+ classifier) in one kernel; `gh` only lends its first steps+1 words to the grid barrier
         const int slot = h->scan_next;
-        h->scan_next = (slot + 1) & 3;
-        if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan four launches ago has finished
-        adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, hs, reinterpret_cast<unsigned*>(gh), batch, steps, st);
+        h->scan_next = (slot + 1) % h->scan_slots;
+        if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan scan_slots launches ago has finished
+        hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), batch, steps, fc_w,
+                                                       fc_b, logits_all, last, classes, h->gru_persistent == 2, st);
+        if (e != hipSuccess) return hip_fail(h, e, "gru scan launch");
         (void)hipEventRecord(h->scan_done[slot], st);
         h->scan_used[slot] = true;
         return ADAF_OK;
     }
     for (int t = 0; t < steps; ++t) {
-        const float* hprev = t ? hs + (size_t)(t - 1) * hidden : nullptr;
-        if (t) {  // gh = W_hh h_{t-1}; rows are strided views into hs
-            if ((rc = linear_launch(h, hprev, batch, steps * hidden, hidden, 3 * hidden, w_hh, nullptr, gh, 0, st))) return rc;
+        const float* hprev = t ? hs + (size_t)(t - 1) * hidden : h0;
+        const int ldprev = t ? steps * hidden : hidden;
+        if (hprev) {  // gh = W_hh h_{t-1}; rows are strided views into hs
+            if ((rc = linear_launch(h, hprev, batch, ldprev, hidden, 3 * hidden, w_hh, nullptr, gh, 0, st))) return rc;
         }
-        adaf_launch_gru_gates(gi + (size_t)t * 3 * hidden, steps * 3 * hidden, t ? gh : nullptr, b_hh, hprev, steps * hidden,
+        adaf_launch_gru_gates(gi + (size_t)t * 3 * hidden, steps * 3 * hidden, hprev ? gh : nullptr, b_hh, hprev, ldprev,
                               hs + (size_t)t * hidden, steps * hidden, batch, hidden, st);
+    }
+    if (fc_w) {   // logits for every step, then the last step's rows
+        if ((rc = linear_launch(h, hs, batch * steps, hidden, hidden, classes, fc_w, fc_b, logits_all, 0, st))) return rc;
+        if (last) adaf_launch_copy2d(logits_all + (size_t)(steps - 1) * classes, steps * classes, last, classes, batch, classes, st);
     }
     return ADAF_OK;
 }
 
 int adaf_gru_seq_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
-                             const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* hs,
-                             void* ws, size_t ws_bytes, void* stream) {
+                             const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* h0,
+                             float* hs, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return ADAF_E_BADARG;
     if (batch == 0) return ADAF_OK;
     if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !hs || !ws) return fail(h, ADAF_E_BADARG, "gru_seq: null pointer");
     if (batch < 0 || steps <= 0 || feat <= 0 || hidden <= 0) return fail(h, ADAF_E_BADARG, "gru_seq: non-positive extent");
     if (ldx == 0) ldx = feat;
     if (feat % 4 || hidden % 4 || ldx % 4) return fail(h, ADAF_E_LAYOUT, "gru_seq: feat, hidden, ldx must be multiples of 4");
+    if (h0 && !aligned16(h0)) return fail(h, ADAF_E_LAYOUT, "gru_seq: h0 must be 16-byte aligned");
     if (ws_bytes < adaf_gru_cls_workspace_bytes(batch, steps, hidden)) return fail(h, ADAF_E_NOMEM, "gru_seq: workspace too small");
     float* gi = static_cast<float*>(ws);
     float* gh = gi + (size_t)batch * steps * 3 * hidden;
-    int rc = gru_scan(h, x, ldx, batch, steps, feat, hidden, w_ih, w_hh, b_ih, b_hh, gi, gh, hs, (hipStream_t)stream);
+    int rc = gru_scan(h, x, ldx, batch, steps, feat, hidden, w_ih, w_hh, b_ih, b_hh, h0, gi, gh, hs, nullptr, nullptr, 0, nullptr,
+                      nullptr, (hipStream_t)stream);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "gru_seq forward");
@@ -635,11 +707,9 @@ int adaf_gru_cls_forward_f32(adaf_handle* h, const float* x, int ldx, int batch,
     float* gi = static_cast<float*>(ws);
     float* gh = gi + (size_t)batch * steps * 3 * hidden;
     float* hs = gh + (size_t)batch * 3 * hidden;  // [B, T, H]
-    int rc = gru_scan(h, x, ldx, batch, steps, feat, hidden, w_ih, w_hh, b_ih, b_hh, gi, gh, hs, st);
+    int rc = gru_scan(h, x, ldx, batch, steps, feat, hidden, w_ih, w_hh, b_ih, b_hh, nullptr, gi, gh, hs, fc_w, fc_b, classes,
+                      logits_all, last, st);
     if (rc) return rc;
-    // logits for every step, then the last step's rows
-    if ((rc = linear_launch(h, hs, batch * steps, hidden, hidden, classes, fc_w, fc_b, logits_all, 0, st))) return rc;
-    adaf_launch_copy2d(logits_all + (size_t)(steps - 1) * classes, steps * classes, last, classes, batch, classes, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "gru_cls forward");
 }
@@ -690,7 +760,8 @@ int adaf_grid_actions_f32(adaf_handle* h, const float* logits, int rows, int n_a
                           int64_t* idx_out, float* action_out, void* stream) {
     if (!h) return ADAF_E_BADARG;
     if (rows == 0) return ADAF_OK;
-    if (!logits || !table_yx || !action_out || rows < 0 || n_actions <= 0) return fail(h, ADAF_E_BADARG, "grid_actions: bad arguments");
+    if (!logits || rows < 0 || n_actions <= 0 || (!action_out && !idx_out) || (action_out && !table_yx))
+        return fail(h, ADAF_E_BADARG, "grid_actions: bad arguments");
     adaf_launch_grid_actions(logits, rows, n_actions, table_yx, reinterpret_cast<long long*>(idx_out), action_out, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "grid_actions launch");

@@ -856,6 +856,21 @@ bool adaf_conv_glds_ok(const ConvArgs& a) {
     return true;
 }
 
+bool adaf_conv_tile_exists(int tile) {
+    switch (tile) {
+        case 1: case 2: case 3: case 4: case 5:
+        case 21: case 22: case 23: case 24: case 25: case 26: case 27:
+        case 31: case 32: case 33: case 34: case 37: case 38: case 39:
+        case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47:
+        case 51: case 52: case 53: case 54:
+        case 61: case 62: case 63: case 64: case 65: case 66: case 67:
+        case 71: case 72: case 73: case 74:
+            return true;
+        default:
+            return false;
+    }
+}
+
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
     const bool bsp_ok = a.wsp != nullptr && (a.K & 31) == 0 && adaf_conv_glds_ok(a);
     if (tile == 40) {   // split tiles, automatic: the bigger the wave tile the fewer split instructions per product

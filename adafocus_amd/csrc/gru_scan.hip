@@ -1,16 +1,24 @@
 // The T-sequential part of a GRU (ACT/models/gfv_net.py:427-435 classifier, ACT/models/ppo.py:67-96 policy) as ONE
-// persistent kernel instead of 2 launches per step.  The input projections gi = W_ih x + b_ih of all
-// steps are computed beforehand by one GEMM; what is sequential is  h_t = GRU(gi_t, W_hh h_{t-1}).
+// persistent kernel instead of 2 launches per step, with the classifier's per-step nn.Linear
+// (gfv_net.py:433) riding in the same matrix products.  The input projections gi = W_ih x + b_ih of all steps are
+// computed beforehand by one GEMM; what is sequential is  h_t = GRU(gi_t, W_hh h_{t-1}).
 //
-//   grid  = H / 8 blocks; block j owns hidden units [8j, 8j+8) = 24 rows of W_hh (gates r, z, n).
-//   W_hh  : those 24 rows stay in REGISTERS for the whole scan (wave w holds the k range [w*H/4, (w+1)*H/4) as MFMA
-//           B fragments: 32 x f32x4 per lane), so the 12.6 MB of W_hh are read from HBM once, not T times.
-//   step  : every wave multiplies h_{t-1}[B x H/4] (A fragments straight from global/L2) with its slice on the fp32
-//           matrix pipe, the four partial [B x 24] products meet in LDS, 256 threads apply the gate math and write h_t.
+//   grid  = H / 8 blocks; block j owns hidden units [8j, 8j+8) = 24 rows of W_hh (gates r, z, n) -- 24 of the 32
+//           columns of its MFMA B operand.  The 8 spare columns carry rows of the classifier weight: block j also owns
+//           classes [cpb*j, cpb*j + cpb) (cpb = ceil(C / gridDim) <= 8), so the product  h_{t-1} x [W_hh rows | fc rows]^T
+//           of step t yields the gates of step t AND the logits of step t-1; one extra pass after the last step emits
+//           logits_{T-1} (= `last`).  No separate FC GEMM, no copy kernel.
+//   W_hh  : the block's 24 (+cpb) rows stay in REGISTERS for the whole scan (wave w holds the k range [w*H/4, (w+1)*H/4)
+//           as MFMA B fragments: 32 x f32x4 per lane), so the 12.6 MB of W_hh are read from HBM once, not T times.
+//   step  : every wave multiplies h_{t-1}[64 x H/4] (A fragments straight from global/L2) with its slice on the fp32
+//           matrix pipe, the four partial [64 x 32] products meet in LDS, 256 threads apply the gate math and write h_t;
+//           batches above 64 clips are walked in chunks of 64 inside the step.
 //   sync  : one grid-wide barrier per step (agent-scope release/acquire around a global counter; h_t crosses XCDs, whose
-//           L2s are not coherent without it).  All H/8 = 128 blocks must be co-resident: a block needs 34 KB of LDS and
-//           ~200 VGPRs, so two fit per CU and four scans can be in flight on different streams without blocking each
-//           other out; the spin is bounded, a block that times out poisons its outputs with NaN instead of hanging.
+//           L2s are not coherent without it).  All H/8 = 128 blocks must be co-resident.  The launcher does not assume
+//           that: it asks the runtime (hipOccupancyMaxActiveBlocksPerMultiprocessor) how many blocks fit per CU, bounds
+//           the number of scans in flight by it, and can launch with hipLaunchCooperativeKernel (mode 2), which makes
+//           the runtime itself refuse a grid that cannot be co-resident.  The spin is bounded anyway; a block that
+//           times out poisons its outputs with NaN instead of hanging the device.
 #include "adaf_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,74 +28,119 @@ namespace {
 
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
+struct GruScanArgs {
+    const float* gi;     // [B, T, 3H] input projections (+ b_ih)
+    const float* whh;    // [3H, H]
+    const float* bhh;    // [3H]
+    const float* h0;     // [B, H] initial state or nullptr (= 0)
+    float* hs;           // [B, T, H]
+    unsigned* bar;       // >= T + 1 zeroed counters
+    int B, T;
+    const float* fcw;    // [C, H] or nullptr
+    const float* fcb;    // [C]
+    float* logits;       // [B*T, C]
+    float* last;         // [B, C] or nullptr
+    int C, cpb;          // classes, classes per block
+};
+
 template <int H, int JB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
-                                                       const float* __restrict__ bhh, float* hs, unsigned* bar, int B, int T) {
-    constexpr int KQ = H / 4, NKK = KQ / 8;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_scan_kernel(const GruScanArgs a) {
+    constexpr int KQ = H / 4, NKK = KQ / 8, G3 = 3 * JB;
     __shared__ float red[4][2][32][33];
     __shared__ int timed_out;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, nl = lane & 31;
     const int j0 = blockIdx.x * JB;
+    const int c0 = blockIdx.x * a.cpb;                 // first class of this block
+    const int B = a.B, T = a.T;
     if (tid == 0) timed_out = 0;
 
     f32x4 wreg[NKK];
     {
-        const int g = nl / JB, jj = nl - g * JB;
-        const bool valid = nl < 3 * JB;
-        const float* wrow = whh + ((size_t)(valid ? g * H + j0 + jj : 0)) * H + wave * KQ + 4 * half;
+        const float* wrow = nullptr;
+        if (nl < G3) {
+            const int g = nl / JB, jj = nl - g * JB;
+            wrow = a.whh + (size_t)(g * H + j0 + jj) * H;
+        } else if (a.fcw && nl - G3 < a.cpb && c0 + nl - G3 < a.C) {
+            wrow = a.fcw + (size_t)(c0 + nl - G3) * H;
+        }
+        const bool valid = wrow != nullptr;
+        const float* src = (valid ? wrow : a.whh) + wave * KQ + 4 * half;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 8 * kk);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * kk);
             wreg[kk] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const int mt = (B + 31) >> 5;
     __syncthreads();
 
-    for (int t = 0; t < T; ++t) {
-        if (t > 0) {
-            for (int m = 0; m < mt; ++m) {
-                f32x16 acc;
+    const bool fc = a.fcw != nullptr;
+    const int steps_total = T + (fc ? 1 : 0);
+    const int nchunk = (B + 63) >> 6;
+    for (int t = 0; t < steps_total; ++t) {
+        const bool have_prev = t > 0 || a.h0 != nullptr;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int b0 = ch << 6;
+            const int rows = B - b0 < 64 ? B - b0 : 64;
+            if (have_prev) {
+                const int mt = (rows + 31) >> 5;
+                for (int m = 0; m < mt; ++m) {
+                    f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const int brow = 32 * m + nl;
-                const float* arow = hs + ((size_t)(brow < B ? brow : B - 1) * T + (t - 1)) * H + wave * KQ + 4 * half;
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    int brow = b0 + 32 * m + nl;
+                    if (brow >= B) brow = B - 1;
+                    const float* arow = (t > 0 ? a.hs + ((size_t)brow * T + (t - 1)) * H : a.h0 + (size_t)brow * H) + wave * KQ + 4 * half;
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * kk);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, wreg[kk].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, wreg[kk].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, wreg[kk].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, wreg[kk].w, acc, 0, 0, 0);
+                    for (int kk = 0; kk < NKK; ++kk) {
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * kk);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, wreg[kk].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, wreg[kk].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, wreg[kk].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, wreg[kk].w, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[wave][m][(r & 3) + 8 * (r >> 2) + 4 * half][nl] = acc[r];
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave][m][(r & 3) + 8 * (r >> 2) + 4 * half][nl] = acc[r];
+                __syncthreads();
             }
-            __syncthreads();
-        }
-        for (int idx = tid; idx < B * JB; idx += 256) {
-            const int b = idx / JB, jj = idx - b * JB, j = j0 + jj;
-            float hr = bhh[j], hz = bhh[H + j], hn = bhh[2 * H + j], hp = 0.f;
-            if (t > 0) {
-                const int m = b >> 5, row = b & 31;
-                hr += (red[0][m][row][jj] + red[1][m][row][jj]) + (red[2][m][row][jj] + red[3][m][row][jj]);
-                hz += (red[0][m][row][JB + jj] + red[1][m][row][JB + jj]) + (red[2][m][row][JB + jj] + red[3][m][row][JB + jj]);
-                hn += (red[0][m][row][2 * JB + jj] + red[1][m][row][2 * JB + jj]) + (red[2][m][row][2 * JB + jj] + red[3][m][row][2 * JB + jj]);
-                hp = hs[((size_t)b * T + (t - 1)) * H + j];
+            if (t < T) {
+                for (int idx = tid; idx < rows * JB; idx += 256) {
+                    const int bl = idx / JB, jj = idx - bl * JB, j = j0 + jj, b = b0 + bl;
+                    float hr = a.bhh[j], hz = a.bhh[H + j], hn = a.bhh[2 * H + j], hp = 0.f;
+                    if (have_prev) {
+                        const int m = bl >> 5, row = bl & 31;
+                        hr += (red[0][m][row][jj] + red[1][m][row][jj]) + (red[2][m][row][jj] + red[3][m][row][jj]);
+                        hz += (red[0][m][row][JB + jj] + red[1][m][row][JB + jj]) + (red[2][m][row][JB + jj] + red[3][m][row][JB + jj]);
+                        hn += (red[0][m][row][2 * JB + jj] + red[1][m][row][2 * JB + jj]) + (red[2][m][row][2 * JB + jj] + red[3][m][row][2 * JB + jj]);
+                        hp = t > 0 ? a.hs[((size_t)b * T + (t - 1)) * H + j] : a.h0[(size_t)b * H + j];
+                    }
+                    const float* gir = a.gi + ((size_t)b * T + t) * 3 * H;
+                    const float r = sigm(gir[j] + hr);
+                    const float z = sigm(gir[H + j] + hz);
+                    const float nn = tanhf(gir[2 * H + j] + r * hn);
+                    a.hs[((size_t)b * T + t) * H + j] = (1.f - z) * nn + z * hp;
+                }
             }
-            const float* gir = gi + ((size_t)b * T + t) * 3 * H;
-            const float r = sigm(gir[j] + hr);
-            const float z = sigm(gir[H + j] + hz);
-            const float nn = tanhf(gir[2 * H + j] + r * hn);
-            hs[((size_t)b * T + t) * H + j] = (1.f - z) * nn + z * hp;
+            if (fc && t > 0) {   // logits of step t-1 came out of the same product (columns 3*JB ..)
+                for (int idx = tid; idx < rows * a.cpb; idx += 256) {
+                    const int bl = idx / a.cpb, ci = idx - bl * a.cpb, cls = c0 + ci, b = b0 + bl;
+                    if (cls < a.C) {
+                        const int m = bl >> 5, row = bl & 31, col = G3 + ci;
+                        const float v = a.fcb[cls] + ((red[0][m][row][col] + red[1][m][row][col]) + (red[2][m][row][col] + red[3][m][row][col]));
+                        a.logits[((size_t)b * T + (t - 1)) * a.C + cls] = v;
+                        if (t == T && a.last) a.last[(size_t)b * a.C + cls] = v;
+                    }
+                }
+            }
+            if (ch + 1 < nchunk) __syncthreads();   // `red` is rewritten by the next chunk
         }
-        if (t + 1 < T) {
+        if (t + 1 < steps_total) {
             __syncthreads();
             if (tid == 0) {
                 __threadfence();                      // release: this block's h_t is visible device-wide
-                atomicAdd(bar + t, 1u);
+                atomicAdd(a.bar + t, 1u);
                 unsigned spins = 0;
-                while (__hip_atomic_load(bar + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                while (__hip_atomic_load(a.bar + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
                     __builtin_amdgcn_s_sleep(4);
                     if (++spins > (1u << 23)) { timed_out = 1; break; }
                 }
@@ -95,21 +148,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
             __syncthreads();
             if (timed_out) {   // never observed; refuses to hang the device if the grid cannot become co-resident
+                const float nan = __builtin_nanf("");
                 for (int idx = tid; idx < B * JB; idx += 256)
-                    for (int tt = t + 1; tt < T; ++tt)
-                        hs[((size_t)(idx / JB) * T + tt) * H + j0 + idx % JB] = __builtin_nanf("");
+                    for (int tt = t + 1; tt < T; ++tt) a.hs[((size_t)(idx / JB) * T + tt) * H + j0 + idx % JB] = nan;
+                if (fc)
+                    for (int idx = tid; idx < B * a.cpb; idx += 256) {
+                        const int b = idx / a.cpb, cls = c0 + idx % a.cpb;
+                        if (cls < a.C) {
+                            for (int tt = t; tt < T; ++tt) a.logits[((size_t)b * T + tt) * a.C + cls] = nan;
+                            if (a.last) a.last[(size_t)b * a.C + cls] = nan;
+                        }
+                    }
                 return;
             }
         }
     }
 }
 
+constexpr int kH = 1024, kJB = 8, kGrid = kH / kJB;
+
 }  // namespace
 
-bool adaf_gru_scan_persistent_ok(int batch, int hidden, int cus) { return hidden == 1024 && batch >= 1 && batch <= 64 && cus * 2 >= hidden / 8; }
+// How many scan blocks the runtime says fit on one CU (0 if the query fails): asked, not assumed.
+int adaf_gru_scan_blocks_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_scan_kernel<kH, kJB>, 256, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return nb;
+}
 
-void adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, float* hs, unsigned* bar, int batch,
-                                     int steps, hipStream_t s) {
-    (void)hipMemsetAsync(bar, 0, sizeof(unsigned) * steps, s);
-    hipLaunchKernelGGL((gru_scan_kernel<1024, 8>), dim3(1024 / 8), dim3(256), 0, s, gi, whh, bhh, hs, bar, batch, steps);
+bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int resident_blocks) {
+    return hidden == kH && batch >= 1 && batch <= 256 && classes <= 8 * kGrid && resident_blocks >= kGrid;
+}
+
+hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
+                                           unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
+                                           float* logits, float* last, int classes, bool cooperative, hipStream_t s) {
+    GruScanArgs a;
+    a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;
+    a.fcw = fcw; a.fcb = fcb; a.logits = logits; a.last = last; a.C = fcw ? classes : 0;
+    a.cpb = fcw ? (classes + kGrid - 1) / kGrid : 0;
+    hipError_t e = hipMemsetAsync(bar, 0, sizeof(unsigned) * (steps + 1), s);
+    if (e != hipSuccess) return e;
+    if (cooperative) {
+        void* params[] = {&a};
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel<kH, kJB>), dim3(kGrid), dim3(256), params, 0, s);
+    }
+    hipLaunchKernelGGL((gru_scan_kernel<kH, kJB>), dim3(kGrid), dim3(256), 0, s, a);
+    return hipGetLastError();
 }

@@ -245,8 +245,10 @@ __global__ void grid_actions_kernel(const float* __restrict__ logits, int rows, 
     for (int i = 1; i < a; ++i)
         if (p[i] > bv) { bv = p[i]; best = i; }
     if (idx_out) idx_out[r] = best;
-    act_out[2 * r] = table[2 * best];
-    act_out[2 * r + 1] = table[2 * best + 1];
+    if (act_out) {
+        act_out[2 * r] = table[2 * best];
+        act_out[2 * r + 1] = table[2 * best + 1];
+    }
 }
 
 __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows,

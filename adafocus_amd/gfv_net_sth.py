@@ -44,6 +44,7 @@ class GFV(nn.Module):
         policy_params = dict(feature_dim=args.feature_map_channels * tg,
                              state_dim=args.feature_map_channels * tg * cells * cells, action_dim=args.action_dim,
                              hidden_state_dim=args.hidden_state_dim, policy_conv=args.policy_conv, gpu=args.gpu,
+                             frame_channels=args.feature_map_channels,
                              ppo_continuous=args.ppo_continuous, gamma=args.gamma, policy_lr=args.policy_lr,
                              action_std=args.action_std, with_bn=args.actorcritic_with_bn)
         base = dict(num_segments=args.num_segments_focuser, modality=args.modality, base_model=args.base_model,
@@ -73,7 +74,7 @@ class GFV(nn.Module):
 
     @torch.no_grad()
     def _stage(self, focuser_image, global_feat_map, global_feat_logit, step, args, prev_local_patch, with_baseline,
-               forced_action=None):
+               forced_action=None, baseline_action=None):
         if self.training:
             raise RuntimeError("adafocus_amd: eval mode only")
         nfg = args.num_segments_glancer // args.video_div
@@ -82,10 +83,11 @@ class GFV(nn.Module):
         cur = focuser_image[:, step * nff:(step + 1) * nff].reshape(b * nff, c, hh, ww)
         fb, _, fc_, fh, fw = global_feat_map.shape
         seg = global_feat_map[:, step * nfg:(step + 1) * nfg]
-        if step == 0 and self.focuser.ppo_continuous:
-            # pixel-major view of the map (free when it came from glance()) -> policy on the engine
+        if self.focuser.ppo_continuous:
+            # pixel-major view of the map (free when it came from glance()) -> policy on the engine; the GRU state of
+            # step i-1 is carried in focuser.memory.hidden for video_div > 1 (STH/evaluate.py:198, ppo_continuous.py:81-94)
             nhwc = seg.permute(0, 1, 3, 4, 2).contiguous().view(fb * nfg, fh, fw, fc_)
-            action = self.focuser.policy.policy_old.act_nhwc(nhwc, fb, nfg)
+            action = self.focuser.policy.policy_old.act_nhwc(nhwc, fb, nfg, self.focuser.memory, restart_batch=(step == 0))
         else:
             action = self.focuser.act(seg.reshape(fb, -1, fh, fw), restart_batch=(step == 0))
         if forced_action is not None:
@@ -100,7 +102,8 @@ class GFV(nn.Module):
             main4 = nchw_to_nhwc4(local_patch.reshape(b * frames_total, 3, p, p))
         groups = [main4]
         if with_baseline:
-            rand_action = torch.rand(b, 2).to(cur.device)           # Focuser.random_patching, gfv_net.py:424-427
+            # Focuser.random_patching, gfv_net.py:424-427 (`baseline_action` injects the draw for parity tests)
+            rand_action = baseline_action.to(cur.device) if baseline_action is not None else torch.rand(b, 2).to(cur.device)
             base_cur = get_patch(cur.view(b, nff * c, hh, ww), rand_action, p).view(b, nff, 3, p, p)
             base_patch = base_cur if prev_local_patch is None else torch.cat([prev_local_patch, base_cur], dim=1)
             groups.append(nchw_to_nhwc4(base_patch.reshape(b * frames_total, 3, p, p)))
@@ -114,12 +117,12 @@ class GFV(nn.Module):
         return logits, local_patch, action
 
     def action_stage2(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
-                      prev_local_patch=None, training=True, with_baseline=True, forced_action=None):
+                      prev_local_patch=None, training=True, with_baseline=True, forced_action=None, baseline_action=None):
         """STH/models/gfv_net.py:136-188 -> (total_logit, baseline_logit, local_patch)."""
         if training:
             raise NotImplementedError("stage-2 policy training is out of scope; call with training=False")
         logits, local_patch, _ = self._stage(focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
-                                             prev_local_patch, with_baseline, forced_action)
+                                             prev_local_patch, with_baseline, forced_action, baseline_action)
         return logits[0], (logits[1] if with_baseline else None), local_patch
 
     def action_stage3(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
@@ -203,6 +206,8 @@ class Focuser(nn.Module):
                 self.policy = PPO_Continuous(pp["feature_dim"], pp["state_dim"], pp["hidden_state_dim"], pp["policy_conv"],
                                              pp["gpu"], gamma=pp["gamma"], lr=pp["policy_lr"],
                                              action_std=pp["action_std"], with_bn=pp["with_bn"])
+                for pol in (self.policy.policy, self.policy.policy_old):
+                    pol.frame_channels = pp.get("frame_channels")
             else:
                 self.policy = PPO(pp["feature_dim"], pp["state_dim"], pp["action_dim"], pp["hidden_state_dim"],
                                   pp["policy_conv"], pp["gpu"], gamma=pp["gamma"], lr=pp["policy_lr"])

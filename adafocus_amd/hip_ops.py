@@ -189,6 +189,29 @@ def copy2d(src, dst_view):
     return dst_view
 
 
+class _StreamScratch:
+    """One scratch tensor per HIP stream: passes enqueued on different streams (pipelined batches) must not share
+    intermediates.  Each tensor is allocated while its stream is current, so the caching allocator only ever reuses
+    its memory in that stream's order; the least recently used entries are dropped beyond `cap` streams (short-lived
+    streams would otherwise pin gigabytes each)."""
+
+    def __init__(self, device, cap=6):
+        self.device, self.cap, self._ws = device, cap, {}
+
+    def get(self, need_bytes):
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.pop(key, None)
+        if ws is None or ws.numel() * 4 < need_bytes:
+            ws = torch.empty(max(need_bytes // 4, 1), device=self.device, dtype=torch.float32)
+        self._ws[key] = ws                       # (re)insert as most recently used
+        while len(self._ws) > self.cap:
+            self._ws.pop(next(iter(self._ws)))
+        return ws
+
+    def __len__(self):
+        return len(self._ws)
+
+
 class ResNet50Trunk:
     """adaf_resnet50: the whole local CNN (stem ... layer4, avgpool) as ~55 back-to-back launches on
     one stream, weights packed / BN folded once.  Replaces ResNet.get_featmap(x, pooled=True)
@@ -201,7 +224,7 @@ class ResNet50Trunk:
         net = C.c_void_p()
         L.check(self._lib.adaf_resnet50_create(self._h, C.byref(net)), self._h)
         self._net = net
-        self._ws = None
+        self._scratch = _StreamScratch(self.device)
         self.n_launches = self._lib.adaf_resnet50_launch_count(net)
 
     def __del__(self):
@@ -230,13 +253,7 @@ class ResNet50Trunk:
         """One scratch buffer per HIP stream: passes enqueued on different streams (pipelined batches)
         must not share intermediates."""
         need = self._lib.adaf_resnet50_workspace_bytes(self._net, n, patch)
-        key = torch.cuda.current_stream().cuda_stream
-        if self._ws is None:
-            self._ws = {}
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() * 4 < need:
-            ws = self._ws[key] = torch.empty(need // 4, device=self.device, dtype=torch.float32)
-        return ws, need
+        return self._scratch.get(need), need
 
     def forward(self, patches_nhwc4, tsm_segments=0, tsm_div=8, out=None):
         """patches (N,P,P,4) -> (N,2048); `out` may be a (N,2048) row-strided view (e.g. the tail of
@@ -279,11 +296,12 @@ class ResNet50Trunk:
         L.check(self._lib.adaf_resnet50_set_math(self._net, int(code)), self._h)
 
 
-def set_gru_persistent(on, device=None):
-    """GRU scans as one persistent kernel (default) or two launches per step (include/adafocus.h)."""
+def set_gru_persistent(mode, device=None):
+    """GRU scans: 0/False = two launches per step, 1/True = one persistent kernel (default), 2 = persistent kernel via
+    hipLaunchCooperativeKernel (include/adafocus.h)."""
     dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
     h = L.handle(dev)
-    L.check(L.load_library().adaf_set_gru_persistent(h, 1 if on else 0), h)
+    L.check(L.load_library().adaf_set_gru_persistent(h, int(mode)), h)
 
 
 def pack_dw_weight(w_c133):
@@ -323,9 +341,22 @@ def grid_actions(logits, table):
     return idx, act
 
 
-def gru_seq_forward(x, w_ih, w_hh, b_ih, b_hh):
-    """nn.GRU(batch_first=True, h0=0): x (B,T,F) -> hidden states (B,T,H)."""
-    L.need_gpu_f32(x, w_ih, w_hh, b_ih, b_hh)
+def argmax_rows(logits):
+    """First-maximum arg-max of every row (ActorCritic.act's `.max(1)[1]`, ACT/models/ppo.py:94) -> int64 (rows,)."""
+    L.need_gpu_f32(logits)
+    logits = logits.contiguous()
+    rows, a = logits.shape
+    idx = torch.empty((rows,), device=logits.device, dtype=torch.int64)
+    h = _h(logits)
+    L.check(L.load_library().adaf_grid_actions_f32(h, L.ptr(logits), rows, a, None, L.ptr(idx), None, L.stream_ptr()), h)
+    return idx
+
+
+def gru_seq_forward(x, w_ih, w_hh, b_ih, b_hh, h0=None):
+    """nn.GRU(batch_first=True): x (B,T,F), h0 (B,H) or None (= zeros) -> hidden states (B,T,H)."""
+    L.need_gpu_f32(x, w_ih, w_hh, b_ih, b_hh, h0)
+    if h0 is not None:
+        h0 = h0.contiguous()
     b, t, f = x.shape
     if x.stride(2) != 1 or x.stride(0) != t * x.stride(1):
         x = x.contiguous()
@@ -337,7 +368,7 @@ def gru_seq_forward(x, w_ih, w_hh, b_ih, b_hh):
     h = _h(x)
     L.check(lib.adaf_gru_seq_forward_f32(h, L.ptr(x), x.stride(1), b, t, f, hid, L.ptr(w_ih.contiguous()),
                                          L.ptr(w_hh.contiguous()), L.ptr(b_ih.contiguous()), L.ptr(b_hh.contiguous()),
-                                         L.ptr(hs), L.ptr(ws), ws_bytes, L.stream_ptr()), h)
+                                         L.ptr(h0), L.ptr(hs), L.ptr(ws), ws_bytes, L.stream_ptr()), h)
     return hs
 
 
@@ -351,7 +382,7 @@ class MobileNetV2Net:
         net = C.c_void_p()
         L.check(self._lib.adaf_mobilenetv2_create(self._h, C.byref(net)), self._h)
         self._net = net
-        self._ws = None
+        self._scratch = _StreamScratch(self.device)
 
     def __del__(self):
         try:
@@ -387,10 +418,9 @@ class MobileNetV2Net:
         fmap = torch.empty((n, fs, fs, 1280), device=x.device, dtype=torch.float32)
         fvec = torch.empty((n, 1280), device=x.device, dtype=torch.float32) if want_vec else None
         need = self._lib.adaf_mobilenetv2_workspace_bytes(self._net, n, s, int(tsm_segments))
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = torch.empty(need // 4, device=self.device, dtype=torch.float32)
+        ws = self._scratch.get(need)     # per stream: consecutive batches' glancer passes may overlap
         L.check(self._lib.adaf_mobilenetv2_forward(self._net, L.ptr(x), n, s, int(tsm_segments), int(tsm_div), L.ptr(fmap),
-                                                   L.ptr(fvec), 1280, L.ptr(self._ws), need, L.stream_ptr()), self._h)
+                                                   L.ptr(fvec), 1280, L.ptr(ws), need, L.stream_ptr()), self._h)
         return fmap, fvec
 
 
@@ -399,6 +429,7 @@ def ingest_u8(clips_hwc_u8, frames, mean, std):
     (B*T, H, W, 4) fp32 normalised pixel-major frames (lane 3 = 0)."""
     if not clips_hwc_u8.is_cuda or clips_hwc_u8.dtype != torch.uint8:
         raise L.AdafError("ingest_u8: a uint8 tensor on the GPU is required")
+    L.on_current_device(clips_hwc_u8)
     x = clips_hwc_u8.contiguous()
     b, hh, ww, c = x.shape
     if c != 3 * frames:
@@ -425,3 +456,56 @@ def crop_gather_nhwc4(frames_nhwc4, actions, patch, frames_per_action=1, return_
                                                         int(frames_per_action), p, L.ptr(out), L.ptr(coords),
                                                         L.stream_ptr()), h)
     return (out, coords) if return_coords else out
+
+
+def _out_shape(n, c, oh, ow, layout):
+    return {LAYOUT_NCHW: (n, c, oh, ow), LAYOUT_NHWC: (n, oh, ow, c), LAYOUT_NHWC4: (n, oh, ow, 4)}[layout]
+
+
+def crop_resize(frames, actions, patch, size=None, frames_per_action=1, layout=LAYOUT_NCHW, return_coords=False):
+    """(y, x, size) -> patch x patch: window of `size` pixels at floor(action * (H - size)), bilinear (align_corners=False)
+    resample to patch x patch (include/adafocus.h adaf_crop_resize_f32).  frames (N,3,H,W) planar or (N,H,W,4) pixel-major;
+    size: None (= patch: the plain gather), an int, or an int32 tensor (M,) of per-action sizes."""
+    L.need_gpu_f32(frames, actions)
+    frames = frames.contiguous()
+    actions = actions.contiguous()
+    in4 = frames.shape[-1] == 4 and frames.shape[1] != 3
+    if in4:
+        n, hh, ww, _ = frames.shape
+        c = 3
+    else:
+        n, c, hh, ww = frames.shape
+    p = int(patch)
+    sizes, sdef = None, p
+    if isinstance(size, torch.Tensor):
+        if size.dtype != torch.int32 or not size.is_cuda or size.numel() != actions.shape[0]:
+            raise ValueError("crop_resize: per-action sizes must be an int32 GPU tensor of shape (n_actions,)")
+        sizes = size.contiguous()
+    elif size is not None:
+        sdef = int(size)
+    out = torch.empty(_out_shape(n, c, p, p, layout), device=frames.device, dtype=torch.float32)
+    coords = torch.empty((actions.shape[0], 2), device=frames.device, dtype=torch.int32) if return_coords else None
+    h = _h(frames)
+    L.check(L.load_library().adaf_crop_resize_f32(h, L.ptr(frames), LAYOUT_NHWC4 if in4 else LAYOUT_NCHW, n, c, hh, ww, L.ptr(actions),
+                                                  actions.shape[0], int(frames_per_action), L.ptr(sizes), sdef, p, L.ptr(out), layout,
+                                                  L.ptr(coords), L.stream_ptr()), h)
+    return (out, coords) if return_coords else out
+
+
+def resize_nearest(frames, out_hw, layout=LAYOUT_NCHW):
+    """F.interpolate(frames, out_hw) with the default nearest mode (ACT/main_dist.py:331-332), bit-exact.
+    frames (N,C,H,W) planar or (N,H,W,4) pixel-major -> `layout`."""
+    L.need_gpu_f32(frames)
+    frames = frames.contiguous()
+    in4 = frames.shape[-1] == 4 and frames.shape[1] != 3
+    if in4:
+        n, hh, ww, _ = frames.shape
+        c = 3
+    else:
+        n, c, hh, ww = frames.shape
+    oh, ow = (int(out_hw), int(out_hw)) if isinstance(out_hw, int) else (int(out_hw[0]), int(out_hw[1]))
+    out = torch.empty(_out_shape(n, c, oh, ow, layout), device=frames.device, dtype=torch.float32)
+    h = _h(frames)
+    L.check(L.load_library().adaf_resize_nearest_f32(h, L.ptr(frames), LAYOUT_NHWC4 if in4 else LAYOUT_NCHW, n, c, hh, ww, oh, ow,
+                                                     L.ptr(out), layout, L.stream_ptr()), h)
+    return out

@@ -8,7 +8,8 @@ and out of scope.
 policy input is only the glancer feature map and its own hidden state (ppo.py:67-96), so all T
 actions are computed before any patch is cropped -- 1x1 conv + Linear over all B*T frames at once,
 one GRU scan, one actor GEMM, arg-max + table lookup in one small kernel.  ``act`` (one step,
-reference signature) stays a few PyTorch-ROCm ops for API parity.
+reference signature, hidden state carried in ``memory.hidden``) runs the same kernels with T = 1 and
+``h0`` = the previous step's state; nothing on this surface is an ATen / MIOpen op.
 """
 import torch
 from torch import nn
@@ -47,14 +48,24 @@ class ActorCritic(nn.Module):
         """One step, eval branch of ppo.py:67-96 (argmax of the actor's softmax)."""
         if training:
             raise NotImplementedError("adafocus_amd implements the inference branch of the policy only")
+        if not self.policy_conv:
+            raise NotImplementedError("adafocus_amd policy: policy_conv=True (the shipped configs) only")
         if restart_batch:
             del memory.hidden[:]
-            memory.hidden.append(torch.zeros(1, state_ini.size(0), self.hidden_state_dim, device=state_ini.device))
-        state = state_ini if self.policy_conv else state_ini.flatten(1)
-        state = self.state_encoder(state)
-        state, hidden = self.gru(state.view(1, state.size(0), state.size(1)), memory.hidden[-1])
-        memory.hidden.append(hidden)
-        return self.actor(state[0]).max(1)[1]
+        b = state_ini.size(0)
+        # (B, C, h, w) reference layout -> pixel-major; free when `state_ini` is a permuted view of the HIP glancer's map
+        nhwc = state_ini.permute(0, 2, 3, 1).contiguous()
+        hw = nhwc.shape[1] * nhwc.shape[2]
+        w_enc, w_lin = self._hip_weights(hw)
+        lin, g, actor = self.state_encoder[3], self.gru, self.actor[0]
+        e = hip_ops.conv2d_bn_act(nhwc, w_enc, act=hip_ops.ACT_RELU)
+        e = hip_ops.linear(e.view(b, -1), w_lin, lin.bias.detach(), act=hip_ops.ACT_RELU)
+        h0 = memory.hidden[-1].view(b, -1) if memory.hidden else None       # restart: h0 = 0 (ppo.py:70-73)
+        hs = hip_ops.gru_seq_forward(e.view(b, 1, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
+                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach(), h0=h0)
+        memory.hidden.append(hs.view(1, b, -1))
+        logits = hip_ops.linear(hs.view(b, -1), actor.weight.detach(), actor.bias.detach())
+        return hip_ops.argmax_rows(logits)
 
     def _hip_weights(self, hw):
         """Engine-layout views of the parameters (cached on the parameter versions)."""

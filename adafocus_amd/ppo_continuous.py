@@ -1,7 +1,9 @@
 """Continuous patch-location policy, inference branch (STH/models/ppo_continuous.py:27-109,142-163):
-encoder -> GRU step -> Linear(2)+Sigmoid; eval returns the action mean.  A PyTorch-ROCm producer of
-the (y,x) fractions the HIP gather consumes.  PPO update / sampling are training
-code and absent."""
+encoder -> GRU step -> Linear(2)+Sigmoid; eval returns the action mean.  The producer of the (y,x)
+fractions the HIP gather consumes, on the conv engine + the GRU kernel; the hidden
+state is carried across ``video_div`` steps in ``memory.hidden`` like the reference does.  PPO update /
+sampling are training code and absent (the reference's eval branch still draws ``dist.sample()`` and
+discards it, ppo_continuous.py:98,107 -- it only advances the global RNG)."""
 import torch
 from torch import nn
 
@@ -30,13 +32,14 @@ class ActorCritic(nn.Module):
         self.actor = nn.Sequential(nn.Linear(hidden_state_dim, 2), nn.Sigmoid())
         self.critic = nn.Sequential(nn.Linear(hidden_state_dim, 1))
         self.hidden_state_dim, self.policy_conv, self.feature_dim = hidden_state_dim, policy_conv, feature_dim
+        self.frame_channels = None       # channels of ONE glancer frame (set by the Focuser); feature_dim = Tg * that
 
     @torch.no_grad()
-    def act_nhwc(self, featmap_nhwc, b, tg):
+    def act_nhwc(self, featmap_nhwc, b, tg, memory=None, restart_batch=True):
         """Clip-level action from the HIP glancer's map (B*Tg, h, w, C): the 1x1 conv over the
         channel-concatenated state (B, Tg*C, h, w) is a (Tg x 1) convolution over the (Tg, h*w) grid of
-        the pixel-major map -- no concatenated tensor is built.  First step only (h0 = 0), which is all
-        video_div = 1 evaluation uses."""
+        the pixel-major map -- no concatenated tensor is built.  `memory.hidden` carries the GRU state
+        across the video_div steps exactly as act() does (reset when restart_batch)."""
         if not self.policy_conv:
             raise NotImplementedError("adafocus_amd policy: policy_conv=True (the shipped configs) only")
         n, hh, ww, ch = featmap_nhwc.shape
@@ -57,22 +60,30 @@ class ActorCritic(nn.Module):
         e = hip_ops.conv2d_bn_act(x, w_enc, sc1, bi1, act=hip_ops.ACT_RELU)    # (b, 1, hw, cmid)
         e = hip_ops.conv2d_bn_act(e.view(b, 1, 1, hw * cmid), w_lin.view(-1, 1, 1, hw * cmid), sc2, bi2, act=hip_ops.ACT_RELU)
         g = self.gru
+        h0 = None
+        if memory is not None:
+            if restart_batch:
+                del memory.hidden[:]
+            elif memory.hidden:
+                h0 = memory.hidden[-1].view(b, -1)
         hs = hip_ops.gru_seq_forward(e.view(b, 1, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
-                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach())
+                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach(), h0=h0)
+        if memory is not None:
+            memory.hidden.append(hs.view(1, b, -1))
         a = self.actor[0]
         return hip_ops.linear(hs.view(b, -1), a.weight.detach(), a.bias.detach(), act=hip_ops.ACT_SIGMOID)
 
     @torch.no_grad()
     def act(self, state_ini, memory, restart_batch=False, training=False):
+        """Reference signature (ppo_continuous.py:78-109): state_ini (B, Tg*C, h, w), the glancer maps of one video_div
+        segment concatenated on the channel axis.  Re-laid out pixel-major (glue) and run on the engine."""
         if training:
             raise NotImplementedError("adafocus_amd implements the inference branch of the policy only")
-        if restart_batch:
-            del memory.hidden[:]
-            memory.hidden.append(torch.zeros(1, state_ini.size(0), self.hidden_state_dim, device=state_ini.device))
-        state = self.state_encoder(state_ini if self.policy_conv else state_ini.flatten(1))
-        state, hidden = self.gru(state.view(1, state.size(0), state.size(1)), memory.hidden[-1])
-        memory.hidden.append(hidden)
-        return self.actor(state[0]).detach()
+        b, tc, hh, ww = state_ini.shape
+        ch = self.frame_channels or (1280 if tc % 1280 == 0 else tc)    # channels per glancer frame (feature_map_channels)
+        tg = tc // ch
+        nhwc = state_ini.view(b, tg, ch, hh, ww).permute(0, 1, 3, 4, 2).contiguous().view(b * tg, hh, ww, ch)
+        return self.act_nhwc(nhwc, b, tg, memory, restart_batch)
 
 
 class PPO_Continuous:

@@ -1,0 +1,118 @@
+"""Algorithmic work of the hot path's pieces: the figures `bench.py`'s roofline
+entries are priced with.  Pure arithmetic on layer tables -- no tensors, no device.
+
+"Algorithmic" = what the computation needs if every tensor crosses HBM exactly once per kernel that
+must see it: FLOP = 2 x MAC over the real (un-padded) channels; bytes = inputs + outputs (+ residual)
++ weights of each LAUNCH of the plan that actually runs, so a fused plan is priced against fused bytes.
+"""
+
+__all__ = ["resnet50_macs_per_patch", "crop_bytes_per_patch", "gru_cls_macs_per_clip", "mobilenetv2_bytes_per_frame",
+           "mobilenetv2_macs_per_frame", "hot_path_flops_per_clip"]
+
+_STAGE_BLOCKS = (3, 4, 6, 3)
+_STAGE_PLANES = (64, 128, 256, 512)
+# (t, c, n, s) of ACT/models/mobilenet.py:85-93 (= STH/models/mobilenetv2.py:75-83)
+_MBV2 = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+def _out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def resnet50_macs_per_patch(patch):
+    """MACs of ResNet.get_featmap (ACT/models/resnet.py:211-225) for one patch x patch input:
+    0.7507 G at 96, 1.3346 G at 128."""
+    hw = _out(patch, 7, 2, 3)
+    macs = hw * hw * 64 * 147
+    hw = _out(hw, 3, 2, 1)
+    inplanes = 64
+    for s, (nb, planes) in enumerate(zip(_STAGE_BLOCKS, _STAGE_PLANES)):
+        for b in range(nb):
+            stride = 2 if (b == 0 and s > 0) else 1
+            ohw = _out(hw, 3, stride, 1)
+            macs += hw * hw * inplanes * planes                 # conv1 1x1
+            macs += ohw * ohw * planes * planes * 9             # conv2 3x3 (stride here, resnet.py:86)
+            macs += ohw * ohw * planes * planes * 4             # conv3 1x1
+            if b == 0:
+                macs += ohw * ohw * inplanes * planes * 4       # downsample 1x1 (+stride)
+            inplanes = planes * 4
+            hw = ohw
+    return macs
+
+
+def crop_bytes_per_patch(patch, channels=3, elem=4):
+    """Window read + patch write: 221 184 B at P = 96 fp32."""
+    return 2 * channels * patch * patch * elem
+
+
+def gru_cls_macs_per_clip(steps, feat=3328, hidden=1024, classes=200):
+    """RecurrentClassifier (ACT/models/gfv_net.py:413-435): 3 gates x (input + recurrent) + FC per step."""
+    return steps * (3 * hidden * (feat + hidden) + hidden * classes)
+
+
+def hot_path_flops_per_clip(steps, patch):
+    return 2.0 * (steps * resnet50_macs_per_patch(patch) + gru_cls_macs_per_clip(steps))
+
+
+def _mbv2_blocks(size):
+    hw = _out(size, 3, 2, 1)
+    cin = 32
+    for t, c, n, s in _MBV2:
+        for i in range(n):
+            stride = s if i == 0 else 1
+            yield dict(inp=cin, oup=c, t=t, stride=stride, hw=hw, ohw=_out(hw, 3, stride, 1))
+            hw = _out(hw, 3, stride, 1)
+            cin = c
+
+
+def mobilenetv2_macs_per_frame(size=224):
+    hw = _out(size, 3, 2, 1)
+    macs = hw * hw * 32 * 27
+    last = None
+    for b in _mbv2_blocks(size):
+        hid = b["inp"] * b["t"]
+        if b["t"] != 1:
+            macs += b["hw"] ** 2 * b["inp"] * hid
+        macs += b["ohw"] ** 2 * hid * 9
+        macs += b["ohw"] ** 2 * hid * b["oup"]
+        last = b
+    macs += last["ohw"] ** 2 * last["oup"] * 1280
+    return macs
+
+
+def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False):
+    """HBM bytes per frame of the glancer's launch plan (csrc/mobilenetv2.hip): every launch's activation inputs +
+    outputs (+ residual), fp32, weights ignored (2.2 M parameters shared by >= 512 frames per launch).
+    fused=True: stem + block 1 are one kernel and the expand -> depthwise pairs of the blocks with cin <= 32 on maps
+    >= 28^2 are one kernel each (csrc/mbconv.hip), so their wide intermediates never reach HBM.
+    fused_tail=True: additionally expand -> depthwise -> project of the 14^2 / 7^2 blocks are one kernel each."""
+    hw = _out(size, 3, 2, 1)
+    elems = size * size * 4                                  # pixel-major NHWC4 frames, read once
+    first = True
+    last = None
+    for b in _mbv2_blocks(size):
+        hid = b["inp"] * b["t"]
+        hin, hout = b["hw"] ** 2, b["ohw"] ** 2
+        res = b["stride"] == 1 and b["inp"] == b["oup"]
+        if first:
+            first = False
+            if fused:
+                elems += hout * b["oup"]                     # stem + dw + project in one kernel: only its output is written
+            else:
+                elems += hw * hw * 32 + (hin * hid + hout * hid) + (hout * hid + hout * b["oup"])
+            last = b
+            continue
+        pair_fused = fused and b["inp"] <= 32 and b["hw"] >= 28
+        if fused_tail and b["hw"] <= 14:
+            elems += hin * b["inp"] + hout * b["oup"]        # whole block in one kernel (residual = its own input)
+        else:
+            if pair_fused:
+                elems += hin * b["inp"] + hout * hid
+            else:
+                elems += (hin * b["inp"] + hin * hid) + (hin * hid + hout * hid)
+            elems += hout * hid + hout * b["oup"] + (hout * b["oup"] if res else 0)
+        last = b
+    ohw = last["ohw"] ** 2
+    elems += ohw * last["oup"] + ohw * 1280                   # head 1x1
+    elems += ohw * 1280 + 1280                                # mean-pooled vector
+    return 4 * elems

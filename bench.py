@@ -2,7 +2,11 @@
 """Headline benchmark: clips/s of the AdaFocus offline-inference hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 from a bare shell: bench.py re-executes itself under `python -m torch.distributed.run --nnodes=1
+  --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one rank per GPU, RCCL), the counterpart of the
+  reference's own `mp.spawn` + `init_process_group` (ACT/main_dist.py:59,79-80); launched under torchrun already
+  (WORLD_SIZE set), it just joins.  `--dry-run` exercises the same launch / barrier / max-over-ranks / gather / JSON
+  path on CPU tensors over gloo with a stand-in step (tests/test_bench_launch.py) -- its `value` is meaningless.
 
 A "step" = one pass of the hot path over one batch of B clips per GPU, inputs resident in HBM:
 batched patch gather of B*T windows from (B*T,3,224,224) frames -> ResNet-50 local CNN over the
@@ -20,6 +24,8 @@ Prints ONE JSON line (rank 0) with the contract fields plus:
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -67,63 +73,129 @@ def load_traffic(t, p, b):
     return None
 
 
-def cpu_baseline(sd, t, p, clips, threads):
-    """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host.
-    oneDNN convs on this box peak at a modest thread count and batch (measured: 8 threads beat 128 by 5x),
-    so a small sweep over (clips per call, threads) is run and the BEST rate is reported with its settings."""
+def host_cpu():
+    """(model string, physical cores, logical CPUs) of the host, from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or None), (os.cpu_count() or 1)
+
+
+def cpu_baseline(sd, t, p, threads):
+    """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host, SURVEY.md §8(d)
+    protocol: fp32, `torch.set_num_threads(n)`, 2 warm-ups + the MEDIAN of 7 runs with `time.perf_counter`, at B = 2
+    (BASELINE config 1's batch) and B = 8, batched structure and the reference's per-step loop structure, for the
+    metric's (T, P) and for the other ResNet-50 configurations.  oneDNN convs on the GPU boxes' hosts peak at a modest
+    thread count (measured: 8 threads beat 128 by 5x), so n is chosen first by a short sweep at B = 8 and stated."""
     from adafocus_amd import synth
     from oracle import ref_model as O
-    ncpu = os.cpu_count() or 1
-    thr_sweep = [threads] if threads > 0 else sorted({min(c, ncpu) for c in (8, 16, 32)})
-    clip_sweep = sorted({max(1, clips // 4), clips})
-    best = (0.0, 0, 0, 0.0)
-    log = []
-    with torch.no_grad():
-        for nc in clip_sweep:
-            frames = torch.from_numpy(synth.synth_frames(nc, t, 224, seed=1)).view(nc * t, 3, 224, 224)
-            _, actions = synth.synth_actions(nc * t, 7, seed=2)
-            gvec = torch.randn(nc, t, 1280)
-            for th in thr_sweep:
-                torch.set_num_threads(th)
-                times = []
-                for i in range(3):
-                    t0 = time.perf_counter()
-                    O.act_hot_path(sd, frames, gvec, torch.from_numpy(actions), p)
-                    times.append(time.perf_counter() - t0)
-                sec = min(times[1:])
-                log.append("%d clips/%d thr: %.2f" % (nc, th, nc / sec))
-                if nc / sec > best[0]:
-                    best = (nc / sec, th, nc, sec)
-    # the reference's own loop structure (ACT/models/gfv_net.py:110-121: one crop + one local-CNN call per time step with
-    # batch B, then the GRU) at the best setting found above, for the record
-    per_step = None
-    try:
-        with torch.no_grad():
-            nc, th = best[2], best[1]
-            torch.set_num_threads(th)
-            frames = torch.from_numpy(synth.synth_frames(nc, t, 224, seed=1)).view(nc, t, 3, 224, 224)
-            _, actions = synth.synth_actions(nc * t, 7, seed=2)
-            act = torch.from_numpy(actions).view(nc, t, 2)
-            gvec = torch.randn(nc, t, 1280)
+    model, phys, ncpu = host_cpu()
 
-            def ref_structured():
-                feats = []
-                for ti in range(t):
-                    patch = O.get_patch(frames[:, ti].contiguous(), act[:, ti].contiguous(), p)
-                    feats.append(O.resnet50_trunk(sd, "focuser.net.", patch).view(nc, 1, -1))
-                return O.recurrent_classifier(sd, "classifier.", torch.cat([gvec, torch.cat(feats, dim=1)], dim=2))
-            ref_structured()
+    def inputs(nc, tt):
+        frames = torch.from_numpy(synth.synth_frames(nc, tt, 224, seed=1)).view(nc * tt, 3, 224, 224)
+        _, actions = synth.synth_actions(nc * tt, 7, seed=2)
+        return frames, torch.from_numpy(actions), torch.randn(nc, tt, 1280)
+
+    def batched(nc, tt, pp):
+        frames, act, gvec = inputs(nc, tt)
+        return lambda: O.act_hot_path(sd, frames, gvec, act, pp)
+
+    def per_step(nc, tt, pp):
+        # the reference's own loop (ACT/models/gfv_net.py:110-121): one crop + one local-CNN call per time step, then the GRU
+        frames, act, gvec = inputs(nc, tt)
+        fr, ac = frames.view(nc, tt, 3, 224, 224), act.view(nc, tt, 2)
+
+        def run():
+            feats = []
+            for ti in range(tt):
+                patch = O.get_patch(fr[:, ti].contiguous(), ac[:, ti].contiguous(), pp)
+                feats.append(O.resnet50_trunk(sd, "focuser.net.", patch).view(nc, 1, -1))
+            return O.recurrent_classifier(sd, "classifier.", torch.cat([gvec, torch.cat(feats, dim=1)], dim=2))
+        return run
+
+    def median_rate(fn, nc, warm=2, runs=7):
+        for _ in range(warm):
+            fn()
+        times = []
+        for _ in range(runs):
             t0 = time.perf_counter()
-            ref_structured()
-            per_step = round(nc / (time.perf_counter() - t0), 3)
-    except Exception:  # noqa: BLE001 - reporting only
-        per_step = None
-    batched = round(best[0], 3)
-    return {"value": max(batched, per_step or 0.0), "unit": "clips/s", "cores": best[1], "kind": "port",
-            "batched_value": batched, "reference_loop_structure_value": per_step,
-            "value_is": "reference loop structure" if (per_step or 0.0) > batched else "batched",
-            "sample": "oracle.act_hot_path (batched crop -> ResNet-50 -> GRU), %d clips x T=%d per call, P=%d, fp32, best of 2 after "
-                      "1 warm-up, %.2f s/iter; sweep (clips/s) on %d logical CPUs: %s" % (best[2], t, p, best[3], ncpu, "; ".join(log))}
+            fn()
+            times.append(time.perf_counter() - t0)
+        med = statistics.median(times)
+        return round(nc / med, 3), round(med, 4)
+
+    rows = []
+    with torch.no_grad():
+        sweep = {}
+        if threads > 0:
+            best_thr = threads
+        else:
+            fn = batched(8, t, p)
+            for th in sorted({min(c, ncpu) for c in (8, 16, 32, (phys or ncpu))}):
+                torch.set_num_threads(th)
+                sweep[th] = median_rate(fn, 8, warm=1, runs=3)[0]
+            best_thr = max(sweep, key=sweep.get)
+        torch.set_num_threads(best_thr)
+        for tt, pp in ((t, p),) + tuple(c for c in ((8, 96), (16, 128)) if c != (t, p)):
+            for nc in (2, 8):
+                rate, med = median_rate(batched(nc, tt, pp), nc)
+                rows.append({"T": tt, "P": pp, "B": nc, "structure": "batched", "clips_per_s": rate, "median_s": med})
+                if (tt, pp) == (t, p):
+                    rate, med = median_rate(per_step(nc, tt, pp), nc)
+                    rows.append({"T": tt, "P": pp, "B": nc, "structure": "reference loop (per time step)", "clips_per_s": rate,
+                                 "median_s": med})
+    head = [r for r in rows if (r["T"], r["P"]) == (t, p)]
+    best = max(head, key=lambda r: r["clips_per_s"])
+    return {"value": best["clips_per_s"], "unit": "clips/s", "cores": best_thr, "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": ncpu, "threads": best_thr,
+            "thread_sweep_B8_clips_per_s": sweep or None, "value_is": "B=%d, %s" % (best["B"], best["structure"]),
+            "rows": rows,
+            "sample": "oracle.act_hot_path (crop -> ResNet-50 -> GRU; torch-CPU fp32 restatement of the reference, pinned by "
+                      "tests/golden), T=%d P=%d, B=2 and B=8 clips per call, %d threads, 2 warm-ups + median of 7 runs; `value` = the "
+                      "best of those rows; other configs in `rows`" % (t, p, best_thr)}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: become `torch.distributed.run` with N local ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+class DryModel:
+    """Stand-in for the GPU step in --dry-run: a deterministic CPU function with the hot path's output shape, so the
+    launcher, the collective and the timing protocol can be tested in a container without a GPU."""
+
+    def __init__(self, b, t, classes=200):
+        self.w = torch.linspace(-1, 1, 64 * classes).view(64, classes)
+        self.b, self.t = b, t
+
+    def hot_path(self, frames, gvec, actions, b, t):
+        last = torch.tanh(frames.view(b, -1)[:, :64] @ self.w)
+        return last.repeat_interleave(t, 0), last, None
 
 
 def main():
@@ -134,86 +206,123 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--patch", type=int, default=96)
-    ap.add_argument("--cpu-clips", type=int, default=16, help="clips in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the CPU baseline leg")
+    ap.add_argument("--cpu-clips", type=int, default=None, help="(deprecated) 0 = skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=2, help="extra per-launch HIP-event passes for the roofline")
+    ap.add_argument("--sustained-steps", type=int, default=240, help="extra soak after the timed region (>= 3 s); 0 = skip")
     ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy + hot path)")
     ap.add_argument("--math", choices=["f32", "split_bf16"], default="f32",
                     help="conv arithmetic: f32 = fp32 matrix pipe (default, the reported configuration); split_bf16 = opt-in, "
                          "fp32 operands as three exact bf16 parts on the bf16 matrix pipe, fp32 accumulate")
     ap.add_argument("--tiles", type=str, default="", help="comma list of per-conv tile overrides (tuning)")
+    ap.add_argument("--fuse", type=int, default=-1, help="trunk layer fusion: -1 = library default, 0 = off, 1 = on")
     ap.add_argument("--skip-extras", action="store_true", help="only the timed steps + roofline pass (for rocprofv3 runs)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the steps are round-robined over (batch i+1's "
                     "trunk overlaps batch i's latency-bound GRU scan); 1 = strictly serial steps")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in for the step: tests the launcher and the protocol")
     a = ap.parse_args()
+    if a.cpu_clips is not None and a.cpu_clips <= 0:
+        a.cpu_baseline = 0
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)                       # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    dry = a.dry_run
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)              # rank i <-> GPU i of this node
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from adafocus_amd import synth
-    from adafocus_amd.gfv_net import GFV
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    from adafocus_amd import synth, workload
     from adafocus_amd.parallel import gather_logits
 
     b, t, p = a.batch, a.frames, a.patch
-    model = GFV(act_args(t, p, b)).eval()
-    sd = synth_model_state(model, 1007)
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev)
-
-    # synthetic inputs, resident in HBM before the timed region (per-rank shard of the clip set)
-    frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=100 + rank)).to(dev).view(b * t, 3, 224, 224)
-    _, act_np = synth.synth_actions(b * t, 7, seed=2 + rank)
-    actions = torch.from_numpy(act_np).to(dev)
-    gvec = torch.randn((b, t, 1280), device=dev)
-    model.focuser.net.set_math(a.math)
-    trunk = model.focuser.net._sync()
-    if a.tiles:
-        trunk.set_tiles([int(v) for v in a.tiles.split(",")])
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(a.streams, 1))]
+    if dry:
+        model, sd, trunk = DryModel(b, t), None, None
+        frames = torch.randn(b * t, 3, 8, 8)
+        actions = torch.rand(b * t, 2)
+        gvec = torch.randn(b, t, 1280)
+        streams = [None] * max(a.streams, 1)
+    else:
+        from adafocus_amd.gfv_net import GFV
+        model = GFV(act_args(t, p, b)).eval()
+        sd = synth_model_state(model, 1007)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dev)
+        # synthetic inputs, resident in HBM before the timed region (per-rank shard of the clip set)
+        frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=100 + rank)).to(dev).view(b * t, 3, 224, 224)
+        _, act_np = synth.synth_actions(b * t, 7, seed=2 + rank)
+        actions = torch.from_numpy(act_np).to(dev)
+        gvec = torch.randn((b, t, 1280), device=dev)
+        model.focuser.net.set_math(a.math)
+        trunk = model.focuser.net._sync()
+        if a.tiles:
+            trunk.set_tiles([int(v) for v in a.tiles.split(",")])
+        if a.fuse >= 0:
+            trunk.set_fusion(a.fuse)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(a.streams, 1))]
 
     def step(i):
         # consecutive batches are independent: enqueue them on alternating streams (software pipelining of
         # the eval loop); every step still does all of its work, and the timed region ends with a device sync
+        if dry:
+            last = model.hot_path(frames, gvec, actions, b, t)[1]
+            return gather_logits(last) if world > 1 else last
         with torch.no_grad(), torch.cuda.stream(streams[i % len(streams)]):
             logits, last, _ = model.hot_path(frames, gvec, actions, b, t)
             if world > 1:
                 last = gather_logits(last)
         return last
 
+    def timed_steps(n):
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(n):
+            out = step(i)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        mine = time.perf_counter() - t0
+        every = [mine]
+        if world > 1:
+            tt = torch.tensor([mine], device=dev, dtype=torch.float64)
+            allt = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            every = [float(x.item()) for x in allt]
+        return max(every), every, out
+
     for i in range(a.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, per_rank_s, out = timed_steps(a.steps)
     assert torch.isfinite(out).all()
+    if world > 1:
+        assert out.shape[0] == world * b, out.shape      # the gathered logits of every rank's shard
 
-    clips_total = b * world * a.steps
-    value = clips_total / elapsed
+    value = b * world * a.steps / elapsed
     res = {
         "metric": "clips/sec (T=%d, patch=%d^2, ResNet-50 local)" % (t, p), "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
@@ -225,13 +334,24 @@ def main():
                                % (t, p, b, b * t),
                    "global_batch": b * world, "frames": t, "patch": p, "parallelism": "dp%d" % world,
                    "streams": len(streams)},
+        "ranks": world, "backend": ("gloo" if dry else "nccl (RCCL)") if world > 1 else None,
+        "rccl_ranks": (dist.get_world_size() if (world > 1 and not dry) else (1 if not dry else 0)),
+        "per_rank_clips_per_s": [round(b * a.steps / s, 1) for s in per_rank_s],
+        "gflop_per_clip": round(workload.hot_path_flops_per_clip(t, p) / 1e9, 2),
     }
+    if dry:
+        res["dry_run"] = True
 
-    if rank == 0:
+    if a.sustained_steps > 0 and not a.skip_extras:
+        # the same step for >= 3 s: the 30-step figure above is a ~0.4 s sample
+        s_el, _, _ = timed_steps(a.sustained_steps)
+        res["sustained"] = {"value": round(b * world * a.sustained_steps / s_el, 2), "unit": "clips/s", "steps": a.sustained_steps,
+                            "seconds": round(s_el, 3), "ms_per_step": round(1e3 * s_el / a.sustained_steps, 3)}
+
+    if rank == 0 and not dry:
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -------------
         conv_ms = conv_fl = tot_ms = 0.0
         nconv = 0
-        patches = model.focuser.net  # noqa: F841
         from adafocus_amd.utils import get_patch_nhwc4
         x4 = get_patch_nhwc4(frames, actions, p)
         per_launch = None
@@ -261,11 +381,11 @@ def main():
         b2b = (conv_fl / nps) / ((wall_ms - other_ms) * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": load_traffic(t, p, b),
-                           "kernel": "conv_gemm_kernel (implicit-GEMM conv+BN+ReLU, v_mfma_f32_32x32x2_f32), %d launches/step"
-                                     % (nconv // max(a.profile_steps, 1)),
+                           "kernel": "conv engine (implicit-GEMM conv+BN+ReLU on v_mfma_f32_32x32x2_f32: conv_gemm_glds_kernel, "
+                                     "the fused stage-1 / stem kernels), %d launches/step" % (nconv // nps),
                            "avg_launch_ms": round(conv_ms / max(nconv, 1), 4),
                            "flop_per_launch": round(conv_fl / max(nconv, 1), 1),
-                           "trunk_ms_per_step": round(tot_ms / max(a.profile_steps, 1), 3),
+                           "trunk_ms_per_step": round(tot_ms / nps, 3),
                            "back_to_back": {"trunk_ms": round(wall_ms, 3), "achieved": round(b2b, 2),
                                             "frac": round(b2b / MFMA_F32_PEAK_TFLOPS, 4),
                                             "note": "two events around whole trunk passes, pooling time subtracted; achieved/frac "
@@ -281,10 +401,10 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         crop_ms = ev0.elapsed_time(ev1) / 20
-        crop_bytes = 2.0 * 3 * p * p * 4 * b * t
+        crop_bytes = float(workload.crop_bytes_per_patch(p)) * b * t
         res["gather"] = {"bound": "hbm", "achieved": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(crop_bytes / (crop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "ms": round(crop_ms, 4), "bytes_per_patch": 2 * 3 * p * p * 4}
+                         "ms": round(crop_ms, 4), "bytes_per_patch": workload.crop_bytes_per_patch(p)}
         # BASELINE.json configs[1] (same model at T=8, N=512 patches per step), for reference
         t8 = t // 2 if not a.skip_extras else 0
         if t8 > 0:
@@ -343,34 +463,39 @@ def main():
                     table = model.focuser.action_table(dev)
                     pol_ms, _ = timed(lambda: model.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table))
                     full_ms, _ = timed(lambda: model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t), 3)
-                # the same forward with consecutive batches round-robined over the streams, as the timed hot path is
-                with torch.no_grad():
-                    for i in range(len(streams)):
-                        with torch.cuda.stream(streams[i]):
-                            model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t)
+                    # consecutive batches pipelined inside the model (its own streams + events), as evaluate.validate runs it
+                    u8s = [u8, u8.clone(), u8.clone()]
+                    for i in range(3):
+                        model.offline_forward_pipelined(u8s[i % 3], t)
+                    model.pipeline_flush()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     for i in range(9):
-                        with torch.cuda.stream(streams[i % len(streams)]):
-                            model.offline_forward_nhwc4(ingest_uint8(u8, t), b, t)
+                        model.offline_forward_pipelined(u8s[i % 3], t)
+                    model.pipeline_flush()
                     torch.cuda.synchronize()
                     piped_ms = (time.perf_counter() - t1) / 9 * 1e3
                 ing_bytes = float(b * t * 224 * 224 * (3 + 16))
-                gl_bytes = float(b * t) * 4.0 * (2 * 6.68e6 + 224 * 224 * 4)      # 6.68 M conv-output elements/frame
+                gl_bytes = float(b * t) * workload.mobilenetv2_bytes_per_frame(224, fused=True, fused_tail=model.glancer.net.fused_tail())
+                gl_flop = 2.0 * workload.mobilenetv2_macs_per_frame(224)
                 res["next_rows"] = {
                     "f1_ingest_u8": {"bound": "hbm", "ms": round(ing_ms, 4), "achieved": round(ing_bytes / ing_ms / 1e6, 1),
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ing_bytes / ing_ms / 1e6 / HBM_PEAK_GBS, 4),
                                      "bytes_per_pixel": 19},
                     "f2_glancer_mobilenetv2": {"bound": "hbm", "ms": round(gl_ms, 3), "achieved": round(gl_bytes / gl_ms / 1e6, 1),
                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gl_bytes / gl_ms / 1e6 / HBM_PEAK_GBS, 4),
-                                               "gflop_per_frame": 0.599, "tflops": round(0.599e9 * b * t / gl_ms / 1e9, 1)},
+                                               "bytes_per_frame": int(gl_bytes / (b * t)),
+                                               "bytes_are": "activations in + out of every launch of the FUSED plan that runs "
+                                                            "(adafocus_amd/workload.py:mobilenetv2_bytes_per_frame)",
+                                               "gflop_per_frame": round(gl_flop / 1e9, 3), "tflops": round(gl_flop * b * t / gl_ms / 1e9, 1)},
                     "f2_policy": {"ms": round(pol_ms, 3), "note": "1x1 conv + FC over all B*T frames, GRU scan over T, arg-max + grid lookup"},
                     "full_forward_from_uint8": {"value": round(b / full_ms * 1e3, 1), "unit": "clips/s", "ms": round(full_ms, 3),
                                                 "note": "ingest + glancer + policy + hot path (GFV.offline_forward_nhwc4), serial on one stream"},
                     "full_forward_from_uint8_pipelined": {"value": round(b / piped_ms * 1e3, 1), "unit": "clips/s", "ms": round(piped_ms, 3),
-                                                          "note": "same, consecutive batches round-robined over %d streams" % len(streams)},
+                                                          "note": "GFV.offline_forward_pipelined: batch i+1's ingest + glancer + policy on the "
+                                                                  "model's front stream while batch i's hot path runs on its back stream"},
                 }
-                del u8, fr4, fmap, fvec
+                del u8, u8s, fr4, fmap, fvec
             except Exception as exc:  # upstream of the timed path; never fail the bench on it
                 res["next_rows"] = {"error": repr(exc)[:300]}
         if os.environ.get("ADAF_BENCH_LAUNCHES"):
@@ -390,8 +515,9 @@ def main():
                                        "note": "GFV.offline_forward: glancer (adaf_mobilenetv2) + policy on the engine + hot path, 3 iterations"}
             except Exception as exc:  # upstream of the timed path; never fail the bench on it
                 res["full_forward"] = {"error": repr(exc)[:200]}
-        if world == 1 and a.cpu_clips > 0 and not a.skip_extras:
-            res["cpu_baseline"] = cpu_baseline(sd, t, p, a.cpu_clips, a.cpu_threads)
+        if world == 1 and a.cpu_baseline and not a.skip_extras:
+            res["cpu_baseline"] = cpu_baseline(sd, t, p, a.cpu_threads)
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

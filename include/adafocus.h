@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ADAF_VERSION 100
+#define ADAF_VERSION 200
 
 enum {
     ADAF_OK = 0,
@@ -56,9 +56,12 @@ int adaf_destroy(adaf_handle* h);
 const char* adaf_last_error(const adaf_handle* h);
 /* Number of compute units of the bound device (256 on MI355X). */
 int adaf_device_cus(const adaf_handle* h);
-/* GRU scans (classifier a7, policy a11) as one persistent kernel with a grid barrier per step when hidden == 1024 and
- * batch <= 64 (default on); off = two launches per step.  Both forms are deterministic; they differ in summation order. */
-int adaf_set_gru_persistent(adaf_handle* h, int on);
+/* GRU scans (classifier a7, policy a11) as one persistent kernel with a grid barrier per step when hidden == 1024,
+ * batch <= 256 and the runtime's occupancy query says the whole grid can be co-resident.
+ *   mode 0 = two launches per step (+ a GEMM for the classifier), 1 = persistent kernel (default),
+ *   mode 2 = persistent kernel launched with hipLaunchCooperativeKernel (the runtime itself guarantees co-residency).
+ * All forms are deterministic; they differ in summation order. */
+int adaf_set_gru_persistent(adaf_handle* h, int mode);
 
 /* ---- a1: patch gather -------------------------------------------------------------------
  * Replaces get_patch(images, action_sequence, patch_size) -- ACT/models/utils.py:37-51
@@ -86,6 +89,27 @@ int adaf_crop_gather_f32(adaf_handle* h, const float* frames, int n_frames, int 
 int adaf_crop_gather_nhwc4_f32(adaf_handle* h, const float* frames_nhwc4, int n_frames, int height, int width,
                                const float* action_yx, int n_actions, int frames_per_action, int patch, float* out_nhwc4,
                                int32_t* coords_out, void* stream);
+
+/* ---- N1: crop-and-resize ---------------------------------------------------------------------
+ * (y, x, size) per action -> a patch x patch tensor: the window [y0, y0+S) x [x0, x0+S) with
+ * (y0, x0) = floor(action * (height - S)) -- get_patch's expression (ACT/models/utils.py:40-42) with patch_size = S --
+ * resampled to patch x patch by the bilinear rule of torchvision.transforms.Resize on tensors
+ * (= F.interpolate(mode='bilinear', align_corners=False)), the transform the reference CONSTRUCTS as `self.down`
+ * (ACT/models/gfv_net.py:58, STH/models/gfv_net.py:69) but never calls on its evaluation path; the live crop is the
+ * fixed-size slice above.  With S == patch the result is bit-identical to adaf_crop_gather_f32 (all interpolation
+ * weights are exactly 0 / 1 and zero-weight taps are not read).
+ *   frames      in_layout NCHW [n_frames, channels, height, width] or NHWC4 [n_frames, height, width, 4]
+ *   size_px     [n_actions] int32 DEVICE array of window sizes (clamped to [1, height]) or NULL -> size_default for all
+ *   out         out_layout as adaf_crop_gather_f32;  coords_out optional [n_actions, 2] int32 (y0, x0) */
+int adaf_crop_resize_f32(adaf_handle* h, const float* frames, int in_layout, int n_frames, int channels, int height, int width,
+                         const float* action_yx, int n_actions, int frames_per_action, const int32_t* size_px,
+                         int size_default, int patch, float* out, int out_layout, int32_t* coords_out, void* stream);
+
+/* Nearest-neighbour resize of whole frames: F.interpolate(images, (glance_size, glance_size)) with the default mode --
+ * the glancer's input when glance_size != input_size (ACT/main_dist.py:331-332, STH/evaluate.py:188).
+ * src = min(int(floorf(dst * (float)in / out)), in - 1) (ATen's rule); a copy, hence bit-exact.  Layouts as above. */
+int adaf_resize_nearest_f32(adaf_handle* h, const float* frames, int in_layout, int n_frames, int channels, int height, int width,
+                            int out_h, int out_w, float* out, int out_layout, void* stream);
 
 /* ---- f1: frame ingest ---------------------------------------------------------------------
  * Stack + ToTorchFormatTensor + GroupNormalize -- ACT/ops/transforms.py:305-336,64-77 -- fused:
@@ -220,20 +244,25 @@ int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
 /* ---- a11: policy head -------------------------------------------------------------------
  * idx = argmax_a logits[row, a] (first maximum), action = table_yx[idx] -- the eval branch of
  * ActorCritic.act (ACT/models/ppo.py:94: action_probs.max(1)[1]; softmax is monotone) followed by
- * Focuser._get_standard_action (ACT/models/gfv_net.py:345-347).  idx_out (int64) may be NULL. */
+ * Focuser._get_standard_action (ACT/models/gfv_net.py:345-347).  idx_out (int64) may be NULL; action_out and
+ * table_yx may both be NULL when only the index is wanted (the one-step act() of the reference signature). */
 int adaf_grid_actions_f32(adaf_handle* h, const float* logits, int rows, int n_actions, const float* table_yx,
                           int64_t* idx_out, float* action_out, void* stream);
-/* nn.GRU (batch_first, h0 = 0) over a whole sequence: hs[b, t, :] for every step -- the recurrent part
- * of the policy (ACT/models/ppo.py:78-79 applied T times) and of the classifier.  Workspace as
- * adaf_gru_cls_workspace_bytes. */
+/* nn.GRU (batch_first) over a whole sequence: hs[b, t, :] for every step -- the recurrent part of the policy
+ * (ACT/models/ppo.py:78-79 applied T times; steps = 1 with h0 = the previous call's state is one call of
+ * ActorCritic.act with restart_batch=False, ppo.py:70-79) and of the classifier.  h0 [batch, hidden] or NULL (= zeros,
+ * restart_batch=True).  Workspace as adaf_gru_cls_workspace_bytes. */
 int adaf_gru_seq_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
-                             const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* hs,
-                             void* ws, size_t ws_bytes, void* stream);
+                             const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* h0,
+                             float* hs, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a7: GRU classifier ----------------------------------------------------------------
  * RecurrentClassifier.forward -- ACT/models/gfv_net.py:427-435 (nn.GRU batch_first, gate order
  * r,z,n; h0 = 0; dropout = identity in eval; nn.Linear on every step).
- *   x [B, T, F] with row stride ldx (0 = F); logits_all [B*T, C]; last [B, C] */
+ *   x [B, T, F] with row stride ldx (0 = F); logits_all [B*T, C]; last [B, C]
+ * Two launches after the input-projection GEMM's: a memset of the barrier words and ONE persistent kernel that runs the
+ * recurrence, the per-step nn.Linear (its rows ride in spare MFMA columns of the recurrent product) and the last-step
+ * copy (csrc/gru_scan.hip). */
 size_t adaf_gru_cls_workspace_bytes(int batch, int steps, int hidden);
 int adaf_gru_cls_forward_f32(adaf_handle* h, const float* x, int ldx, int batch, int steps, int feat, int hidden,
                              int classes, const float* w_ih, const float* w_hh, const float* b_ih,

@@ -1,0 +1,40 @@
+"""`python bench.py --gpus N` from a bare shell must spawn its own N ranks (the reference does the same with
+mp.spawn + init_process_group, ACT/main_dist.py:59,79-80).  The GPU step needs an MI355X; `--dry-run` swaps in a
+CPU stand-in and gloo so the launcher, the barrier / max-over-ranks timing, the logits all-gather and the
+one-JSON-line contract are exercised here."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1",
+                          "--sustained-steps", "4", "--batch", "4", "--frames", "2"] + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_from_a_bare_shell():
+    r = _run(["--gpus", "2"])
+    assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["backend"] == "gloo" and r["dry_run"] is True
+    assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2"
+    assert len(r["per_rank_clips_per_s"]) == 2 and all(v > 0 for v in r["per_rank_clips_per_s"])
+    # value = clips of ALL ranks / max-over-ranks time
+    assert abs(r["value"] - 8 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 0.01
+    assert r["value"] <= 2 * min(r["per_rank_clips_per_s"]) * 1.01
+    assert r["sustained"]["steps"] == 4 and r["sustained"]["value"] > 0
+
+
+def test_bench_single_rank_dry_run_contract():
+    r = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["ranks"] == 1 and r["steps"] == 3 and r["warmup"] == 1
