@@ -208,17 +208,12 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
         logs.append(progress.print(bi_, quiet=quiet or rank != 0))
 
     pending = None        # batch i's scalars are read back after batch i+1 has been enqueued: the GPU never idles on them
-    for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
-        target_full = target_full.to(dev)      # already there (and asynchronous) on the GPU path
-        target = target_full[:, 0]
-        b = images.shape[0]
-        if images.dtype == torch.uint8:
-            from .transforms import ingest_uint8
-            frames = ingest_uint8(images, args.num_segments)
-            outputs, pred = model.offline_forward_nhwc4(frames, b, args.num_segments)[:2]
-        else:
-            outputs, pred = model(input=images, scan=images, training=False, backbone_pred=False, one_step=True, gpu=args.gpu)
-        stage_next()          # host-side stacking + H2D of the next batch run under this batch's kernels
+    lagging = None        # uint8 path: batch i's loss / accuracy kernels are enqueued after batch i+1's forward
+
+    def score(outputs, pred, target, target_full, b, bi, done=None):
+        nonlocal pending
+        if done is not None:
+            torch.cuda.current_stream(dev).wait_event(done)
         loss = criterion(outputs, target.view(b, -1).expand(b, args.num_segments).reshape(-1))
         acc1, acc5 = accuracy(pred, target, topk=(1, 5))
         preds.append(pred)
@@ -227,6 +222,32 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
         if pending is not None:
             finish(pending)
         pending = (bi, b, loss, acc1, acc5)
+
+    for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
+        target_full = target_full.to(dev)      # already there (and asynchronous) on the GPU path
+        target = target_full[:, 0]
+        b = images.shape[0]
+        if images.dtype == torch.uint8:
+            # the model's own two-stream pipeline: this batch's ingest + glancer + policy overlap the previous batch's
+            # hot path; its scores are enqueued one batch late so the consumer stream never stalls the front half
+            outputs, pred, _, done, handoff = model.offline_forward_pipelined(images, args.num_segments)
+            torch.cuda.current_stream(dev).wait_event(handoff)     # the clip buffer is free once the front half has read it
+            stage_next()
+            if lagging is not None:
+                score(*lagging)
+            lagging = (outputs, pred, target, target_full, b, bi, done)
+            continue
+        # input_prime = F.interpolate(images, (glance_size, glance_size)), main_dist.py:331-332 (identity at 224)
+        g = getattr(args, "glance_size", images.shape[-1])
+        scan = images
+        if g != images.shape[-1]:
+            from . import hip_ops
+            scan = hip_ops.resize_nearest(images.reshape(-1, 1, images.shape[2], images.shape[3]), g).view(b, -1, g, g)
+        outputs, pred = model(input=images, scan=scan, training=False, backbone_pred=False, one_step=True, gpu=args.gpu)
+        stage_next()          # host-side stacking + H2D of the next batch run under this batch's kernels
+        score(outputs, pred, target, target_full, b, bi)
+    if lagging is not None:
+        score(*lagging)
     if pending is not None:
         finish(pending)
     ncls = args.num_classes

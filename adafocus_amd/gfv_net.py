@@ -46,6 +46,8 @@ class GFV(nn.Module):
         self.input_mean = [0.485, 0.456, 0.406]
         self.input_std = [0.229, 0.224, 0.225]
         self.with_glancer = args.with_glancer
+        self.glance_size = getattr(args, "glance_size", args.input_size)
+        self._pipe = None                      # (front stream, back stream) of offline_forward_pipelined
         self.glancer = Glancer(num_classes=self.num_class)
         cells = math.ceil(args.glance_size / 32)
         policy_params = dict(feature_dim=args.feature_map_channels, state_dim=args.feature_map_channels * cells * cells,
@@ -98,17 +100,81 @@ class GFV(nn.Module):
         return self.hot_path(images.view(b * t, 3, hh, ww), fvec.view(b, t, -1) if self.with_glancer else None, actions,
                              b, t) + (idx,)
 
+    def glancer_input(self, images):
+        """`input_prime = F.interpolate(images, (glance_size, glance_size))` of the reference's drivers (nearest mode,
+        ACT/main_dist.py:331-332): the identity when glance_size equals the frame size (every shipped config), else one
+        bit-exact resize launch.  images (B, T*3, H, W) planar or (B*T, H, W, 4) pixel-major; same layout back."""
+        if images.shape[-1] == 4 and images.shape[1] != 3:
+            if images.shape[1] == self.glance_size:
+                return images
+            return hip_ops.resize_nearest(images, self.glance_size, hip_ops.LAYOUT_NHWC4)
+        if images.shape[-1] == self.glance_size:
+            return images
+        b, tc, hh, ww = images.shape
+        g = self.glance_size
+        return hip_ops.resize_nearest(images.reshape(b * tc, 1, hh, ww), g, hip_ops.LAYOUT_NCHW).view(b, tc, g, g)
+
     @torch.no_grad()
     def offline_forward_nhwc4(self, frames_nhwc4, b, t, forced_action_idx=None):
         """Same as offline_forward for frames that are already normalised pixel-major (B*T,H,W,4)
         (``transforms.ingest_uint8``): the glancer and the gather read them directly."""
-        fmap, fvec = self.glancer.net.features_from_nhwc4(frames_nhwc4)
+        fmap, fvec = self.glancer.net.features_from_nhwc4(self.glancer_input(frames_nhwc4))
         table = self.focuser.action_table(frames_nhwc4.device)
         idx, actions = self.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table)
         if forced_action_idx is not None:
             idx = forced_action_idx.to(idx.device)
             actions = table[idx.reshape(-1)]
         return self.hot_path(frames_nhwc4, fvec.view(b, t, -1) if self.with_glancer else None, actions, b, t) + (idx,)
+
+    @torch.no_grad()
+    def offline_forward_pipelined(self, clips, t, forced_action_idx=None):
+        """One batch of the full forward with the two halves on the model's own streams, so consecutive calls overlap BY
+        CONSTRUCTION: ingest + glancer + policy of batch i+1 (HBM-bound depthwise work) on the front stream while the hot
+        path of batch i (MFMA-bound trunk) runs on the back stream; an event hands the frames / glancer vectors / actions
+        over.  clips: the loader's stacked uint8 clips (B, H, W, T*3) or normalised pixel-major frames (B*T, H, W, 4).
+        Returns (logits, last, idx, done, handoff) -- HIP events: the outputs belong to the back stream until the
+        consumer's stream waits on `done` (``torch.cuda.current_stream().wait_event(done)``) or `pipeline_flush()` is
+        called; `clips` may be overwritten once `handoff` has passed (the front half has consumed it)."""
+        dev = clips.device
+        if self._pipe is None or self._pipe[0].device != dev:
+            self._pipe = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        front, back = self._pipe
+        cur = torch.cuda.current_stream(dev)
+        front.wait_stream(cur)                       # the caller produced `clips` on its stream
+        with torch.cuda.stream(front):
+            if clips.dtype == torch.uint8:
+                from .transforms import ingest_uint8
+                b = clips.shape[0]
+                frames = ingest_uint8(clips, t)
+            else:
+                frames = clips
+                b = frames.shape[0] // t
+            clips.record_stream(front)
+            fmap, fvec = self.glancer.net.features_from_nhwc4(self.glancer_input(frames))
+            table = self.focuser.action_table(dev)
+            idx, actions = self.focuser.policy.policy_old.act_sequence_nhwc(fmap, b, t, table)
+            if forced_action_idx is not None:
+                idx = forced_action_idx.to(dev)
+                actions = table[idx.reshape(-1)]
+            handoff = torch.cuda.Event()
+            handoff.record(front)
+        back.wait_event(handoff)
+        with torch.cuda.stream(back):
+            for x in (frames, fvec, actions):
+                x.record_stream(back)                # allocated on the front stream, read here
+            logits, last, _ = self.hot_path(frames, fvec.view(b, t, -1) if self.with_glancer else None, actions, b, t)
+            done = torch.cuda.Event()
+            done.record(back)
+        for x in (logits, last, idx):
+            x.record_stream(cur)
+        return logits, last, idx, done, handoff
+
+    def pipeline_flush(self):
+        """Make the current stream wait for everything offline_forward_pipelined has enqueued."""
+        if self._pipe is not None:
+            cur = torch.cuda.current_stream(self._pipe[0].device)
+            cur.wait_stream(self._pipe[0])
+            cur.wait_stream(self._pipe[1])
 
     def hot_path(self, frames, global_feat, actions, b, t):
         """Batched crop -> local CNN -> concat -> classifier: the benchmarked slice.

@@ -62,6 +62,7 @@ class GlancerEngine:
         self.module, self.variant = module, variant
         self._net, self._sig = None, None
         self.fusion = True      # expand -> depthwise fused where the shape allows (adaf_mobilenetv2_set_fusion)
+        self.fused_tail = False  # whole inverted-residual blocks of the 14^2 / 7^2 maps in one kernel (not built)
 
     def sync(self):
         sd = {k: v for k, v in self.module.state_dict().items()

@@ -56,6 +56,9 @@ class MobileNetV2(nn.Module):
     def features_from_nhwc4(self, frames_nhwc4):
         return self._engine.features(frames_nhwc4)
 
+    def fused_tail(self):
+        return bool(self._engine.fused_tail)
+
     def forward(self, x):
         lin = self.classifier[-1]
         return hip_ops.linear(self.features_nhwc(x)[1], lin.weight.detach(), lin.bias.detach())

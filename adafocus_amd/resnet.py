@@ -17,6 +17,7 @@ from .utils import nchw_to_nhwc4
 __all__ = ["ResNet", "resnet50", "Bottleneck"]
 
 _STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+DEFAULT_MATH = "f32"      # arithmetic of newly built trunks ("f32" | "split_bf16"); ResNet.set_math overrides per model
 
 
 class Bottleneck(nn.Module):
@@ -78,7 +79,7 @@ class ResNet(nn.Module):
         if self._trunk is None or self._trunk.device != dev or sig != self._sig:
             if self._trunk is None or self._trunk.device != dev:
                 self._trunk = hip_ops.ResNet50Trunk(dev)
-                self._trunk.set_math(getattr(self, "_math", "f32"))
+                self._trunk.set_math(getattr(self, "_math", None) or DEFAULT_MATH)
             self._trunk.load(params)
             self._sig = sig
         return self._trunk

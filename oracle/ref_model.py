@@ -50,6 +50,29 @@ def standard_actions(action_dim):
                         dtype=torch.float64).float()
 
 
+def crop_resize(images, action_sequence, size, patch_size):
+    """N1: (y, x, size) -> patch: get_patch with patch_size = size (ACT/models/utils.py:37-51), then the bilinear
+    resize the reference constructs as `self.down = Resize((P, P), BILINEAR)` (ACT/models/gfv_net.py:58) -- on tensors
+    torchvision's Resize is F.interpolate(mode='bilinear', align_corners=False) (torchvision 0.8
+    transforms/functional_tensor.py:resize; torchvision itself is not installed here).  The reference never calls
+    `self.down` on its evaluation path; with size == patch_size this is get_patch itself.
+    size: int or (N,) ints (per action)."""
+    n = images.shape[0]
+    sizes = [int(size)] * n if not hasattr(size, "__len__") else [int(v) for v in size]
+    outs = []
+    for i in range(n):
+        win = get_patch(images[i:i + 1], action_sequence[i:i + 1], sizes[i])
+        outs.append(win if sizes[i] == patch_size else
+                    F.interpolate(win, size=(patch_size, patch_size), mode="bilinear", align_corners=False))
+    return torch.cat(outs, 0)
+
+
+def glancer_input(images, glance_size):
+    """input_prime = F.interpolate(images, (glance_size, glance_size)) -- default nearest mode
+    (ACT/main_dist.py:331-332, STH/evaluate.py:188)."""
+    return F.interpolate(images, (glance_size, glance_size))
+
+
 # --------------------------------------------------------------------------------------
 # a6: temporal shift
 # --------------------------------------------------------------------------------------
@@ -248,6 +271,29 @@ def fc_consensus(sd, p, feat, batch, global_logit=None):
     return out
 
 
+def linear_classifier(sd, p, feature):
+    """LinearCLassifier.forward -- ACT/models/gfv_net.py:399-407: softmax of FC per step, mean over steps;
+    returns (log(avg), avg).  feature (B,T,F)."""
+    b, t, _ = feature.shape
+    logits = F.linear(feature.reshape(b * t, -1), sd[p + "fc.weight"], sd[p + "fc.bias"])
+    avg = torch.softmax(logits, dim=1).view(b, t, -1).mean(dim=1)
+    return torch.log(avg), avg
+
+
+def backbone_pred(sd, images, which):
+    """GFV.forward(backbone_pred=True) -- ACT/models/gfv_net.py:85-94: per-frame class logits of the glancer
+    (MobileNetV2 + its classifier) or the focuser (ResNet-50 + fc) on FULL frames.  images (B,T*3,H,W) -> (B,T,C)."""
+    b, tc, hh, ww = images.shape
+    x = images.view(b * (tc // 3), 3, hh, ww)
+    if which == "glancer":
+        fm = mobilenetv2_features(sd, "glancer.net.", x, "act")
+        out = F.linear(fm.mean([2, 3]), sd["glancer.net.classifier.1.weight"], sd["glancer.net.classifier.1.bias"])
+    else:
+        f = resnet50_trunk(sd, "focuser.net.", x).flatten(1)
+        out = F.linear(f, sd["focuser.net.fc.weight"], sd["focuser.net.fc.bias"])
+    return out.view(b, tc // 3, -1)
+
+
 # --------------------------------------------------------------------------------------
 # a9: end-to-end compositions
 # --------------------------------------------------------------------------------------
@@ -322,6 +368,37 @@ def sth_forward(sd, glancer_images, focuser_images, patch_size, tg, tf, shift_di
     patch = get_patch(cur, action, patch_size).view(b, tf, 3, patch_size, patch_size)
     feat = resnet50_trunk(sd, net_prefix, patch.view(-1, 3, patch_size, patch_size), tf, shift_div).squeeze()
     return fc_consensus(sd, "classifier.", feat, b, gl), patch, action
+
+
+def sth_stage(sd, glancer_map, glancer_logit, focuser_images, step, video_div, patch_size, tf, hidden, prev_local_patch=None,
+              shift_div=8, forced_action=None, baseline_action=None, net_prefix="focuser.net.base_model."):
+    """One call of GFV.action_stage2(training=False) -- STH/models/gfv_net.py:136-188 -- for any video_div: the policy sees
+    the glancer maps of segment `step` concatenated on the channel axis and carries its GRU state (`hidden`, zeros when
+    step == 0: restart_batch), the new patches are appended to the previous steps' (`prev_local_patch`), and the TSM trunk
+    runs over ALL patches so far with its construction-time n_segment = tf (tsn.py / temporal_shift.py:103).  The reward
+    baseline (random_patching, :153-160,176-186) is evaluated when `baseline_action` (the torch.rand draw) is given.
+    glancer_map (B,Tg,1280,h,w); glancer_logit (B,Tg,C); focuser_images (B,Tf,3,H,W).
+    Returns (total_logit, baseline_logit or None, local_patch, action, hidden)."""
+    b = focuser_images.shape[0]
+    nfg, nff = glancer_map.shape[1] // video_div, tf // video_div
+    cur = focuser_images[:, step * nff:(step + 1) * nff].reshape(b, -1, focuser_images.shape[3], focuser_images.shape[4])
+    state = glancer_map[:, step * nfg:(step + 1) * nfg].reshape(b, -1, glancer_map.shape[3], glancer_map.shape[4])
+    pol = "policy."
+    if hidden is None:
+        hidden = state.new_zeros(b, sd[pol + "gru.weight_hh_l0"].shape[1])
+    action, hidden = policy_act_continuous(sd, pol, state, hidden, with_bn=(pol + "state_encoder.1.running_mean") in sd)
+    if forced_action is not None:
+        action = forced_action
+
+    def branch(act):
+        cur_patch = get_patch(cur, act, patch_size).view(b, nff, 3, patch_size, patch_size)
+        patch = cur_patch if prev_local_patch is None else torch.cat([prev_local_patch, cur_patch], dim=1)
+        feat = resnet50_trunk(sd, net_prefix, patch.reshape(-1, 3, patch_size, patch_size), tf, shift_div).flatten(1)
+        return fc_consensus(sd, "classifier.", feat, b, glancer_logit), patch
+
+    total, local_patch = branch(action)
+    base = branch(baseline_action)[0] if baseline_action is not None else None
+    return total, base, local_patch, action, hidden
 
 
 # --------------------------------------------------------------------------------------

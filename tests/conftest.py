@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", params=["f32", "split_bf16"])
+def trunk_math(request):
+    """The GPU parity modules run twice: with the local CNN's convolutions on the fp32 matrix pipe (the reported
+    configuration) and with the opt-in split-bf16 arithmetic as the default of every ResNet built."""
+    from adafocus_amd import resnet
+    old = resnet.DEFAULT_MATH
+    resnet.DEFAULT_MATH = request.param
+    yield request.param
+    resnet.DEFAULT_MATH = old

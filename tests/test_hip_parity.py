@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from adafocus_amd import synth
 from tests.helpers import golden, rnd, synth_sd
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("trunk_math")]
 
 TOL = 1e-3          # north-star: logits within 1e-3 fp32
 CONV_TOL = 2e-4     # single fused conv vs torch CPU (different summation order only)
@@ -657,7 +657,7 @@ def test_sth_end_to_end_golden(dev):
         pred3, patch3 = m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced)
         pred, _, patch = m.action_stage2(fo, fm, glog, 0, a, prev_local_patch=None, training=False, with_baseline=False)
         act = m.focuser.policy.policy_old.act_nhwc(fm.permute(0, 1, 3, 4, 2).reshape(16, 7, 7, 1280), 2, 8)
-        act_t = m.focuser.act(fm.reshape(2, -1, 7, 7), True)       # one-step reference-signature path (PyTorch-ROCm ops)
+        act_t = m.focuser.act(fm.reshape(2, -1, 7, 7), True)       # one-step reference-signature path (same engine kernels)
     assert patch_f.shape == (2, 8, 3, 128, 128) and base.shape == (2, 174)
     assert np.array_equal(patch_f[:, :, :, :4, :4].cpu().numpy(), g["patch_forced_corner"])
     assert np.abs(pred_f.cpu().numpy() - g["logits_forced"]).max() < TOL
@@ -669,9 +669,11 @@ def test_sth_end_to_end_golden(dev):
     got_xy = np.floor(act.cpu().numpy() * (224 - 128)).astype(np.int32)
     assert np.abs(act.cpu().numpy() - g["policy_action"]).max() < 1e-3
     assert np.abs(act_t.cpu().numpy() - g["policy_action"]).max() < 1e-3
-    if np.array_equal(ref_xy, got_xy):
-        assert np.array_equal(patch[:, :, :, :4, :4].cpu().numpy(), g["patch_corner"])
-        assert np.abs(pred.cpu().numpy() - g["logits"]).max() < TOL
+    if not np.array_equal(ref_xy, got_xy):       # loud, so a skipped value check shows up in the GPU test record
+        pytest.skip("policy action within float noise of a pixel boundary: crop origin %s vs the reference's %s; the "
+                    "forced-action parity above passed" % (got_xy.tolist(), ref_xy.tolist()))
+    assert np.array_equal(patch[:, :, :, :4, :4].cpu().numpy(), g["patch_corner"])
+    assert np.abs(pred.cpu().numpy() - g["logits"]).max() < TOL
 
 
 def test_tsm_glancer_shift_kernel(dev, O):

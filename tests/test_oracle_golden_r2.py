@@ -1,0 +1,100 @@
+"""Pin the round-2 additions of the oracle against vectors produced by the real reference
+(tools/gen_golden_r2.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import torch
+
+from adafocus_amd import synth
+from oracle import ref_model as O
+from tests.helpers import golden, rnd, synth_sd
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_g10_crop_resize_and_nearest():
+    g = golden("g10_resample")
+    fr = rnd((4, 3, 224, 224), 101)
+    act = torch.from_numpy(g["actions"])
+    for s_, p_ in g["cases"].tolist():
+        o = O.crop_resize(fr, act, s_, p_).numpy()
+        assert o.shape == (4, 3, p_, p_)
+        np.testing.assert_allclose(o[:, :, ::7, ::5], g["sub_%d_%d" % (s_, p_)], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(o[:, :, -6:, -6:], g["corner_%d_%d" % (s_, p_)], rtol=0, atol=1e-6)
+        if s_ == p_:    # scale 1: the resample IS the slice copy
+            assert np.array_equal(_sha(o), g["sha_%d_%d" % (s_, p_)])
+            assert np.array_equal(o, O.get_patch(fr, act, p_).numpy())
+    o = O.crop_resize(fr, act, g["mixed_sizes"], 96).numpy()
+    np.testing.assert_allclose(o[:, :, ::7, ::5], g["mixed_sub"], rtol=0, atol=1e-6)
+    fr2 = rnd((2, 6, 224, 224), 102)
+    for gs in (160, 128, 112, 96):
+        assert np.array_equal(_sha(O.glancer_input(fr2, gs).numpy()), g["nearest_sha_%d" % gs])
+    assert np.array_equal(O.glancer_input(fr2, 96).numpy()[:, :, -5:, -5:], g["nearest_corner_96"])
+
+
+def test_g11_per_step_surface():
+    g = golden("g11_act_surface")
+    sd = synth_sd("ACT", 1007)
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=0))
+    fr5 = frames.view(2, 8, 3, 224, 224)
+    table = O.standard_actions(49)
+    with torch.no_grad():
+        fm, _ = O.glancer_act(sd, "glancer.net.", frames.view(16, 3, 224, 224))
+        fm = fm.view(2, 8, *fm.shape[1:])
+        hid = frames.new_zeros(2, 1024)
+        for s in range(3):      # Focuser.forward(input=, state=, restart_batch=s == 0, training=False), gfv_net.py:316-331
+            idx, hid = O.policy_act_discrete(sd, "focuser.policy.policy_old.", fm[:, s], hid)
+            assert np.array_equal(table[idx].numpy(), g["focuser_action_%d" % s])
+            feat = O.resnet50_trunk(sd, "focuser.net.", O.get_patch(fr5[:, s], table[idx], 96)).view(2, -1)
+            np.testing.assert_allclose(feat.numpy(), g["focuser_feat_%d" % s], rtol=1e-4, atol=2e-5)
+        a = torch.from_numpy(g["sample_action"])
+        assert np.array_equal(_sha(O.get_patch(fr5[:, 1], a, 96).numpy()), g["sample_sha"])     # PatchSampler.sample
+        small = frames[:, :6].contiguous()
+        np.testing.assert_allclose(O.backbone_pred(sd, small, "focuser").numpy(), g["pred_focuser"], rtol=1e-4, atol=5e-5)
+        np.testing.assert_allclose(O.backbone_pred(sd, small, "glancer").numpy(), g["pred_glancer"], rtol=1e-4, atol=5e-5)
+        lin_sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict({"fc.weight": (200, 3328), "fc.bias": (200,)}, 707).items()}
+        lg, avg = O.linear_classifier(lin_sd, "", rnd((2, 8, 3328), 71, 0.5))
+    np.testing.assert_allclose(lg.numpy(), g["linear_log"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(avg.numpy(), g["linear_avg"], rtol=1e-5, atol=1e-7)
+
+
+def test_g7_act_config3_shape():
+    g = golden("g7_act_c3")
+    sd = synth_sd("ACT", 1007)
+    frames = torch.from_numpy(synth.synth_frames(2, 16, 224, seed=7))
+    with torch.no_grad():
+        logits, last, idx, _ = O.act_forward(sd, frames, frames, 128, 49, per_step=False, return_aux=True)
+        forced = torch.from_numpy(g["forced_idx"])
+        logits_f, last_f = O.act_forward(sd, frames, frames, 128, 49, forced_action_idx=forced, per_step=False)
+    assert np.array_equal(idx.numpy(), g["policy_idx"])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(logits_f.numpy(), g["logits_forced"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(last_f.numpy(), g["last_forced"], rtol=1e-4, atol=2e-5)
+    assert len(set(g["forced_idx"].reshape(-1).tolist())) > 12
+
+
+def sth_state(vd):
+    sd = synth_sd("STH", 1007)
+    sd.update(synth_sd("STH_POLICY" if vd == 1 else "STH_POLICY_VD2", 1007))
+    return O.canonical_resnet_keys(sd, "focuser.net.base_model.")
+
+
+def test_g12_sth_video_div_and_baseline():
+    g = golden("g12_sth_steps")
+    gl = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=3))
+    fo = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=4)).view(2, 8, 3, 224, 224)
+    for vd in (1, 2):
+        sd = sth_state(vd)
+        with torch.no_grad():
+            fm, glog = O.glancer_sth(sd, "glancer.net.", gl.view(16, 3, 224, 224), 8, 8)
+            fm, glog = fm.view(2, 8, *fm.shape[1:]), glog.view(2, 8, -1)
+            hid, prev = None, None
+            for step in range(vd):
+                rand = torch.from_numpy(g["vd%d_rand_%d" % (vd, step)])
+                total, base, prev, _, hid = O.sth_stage(sd, fm, glog, fo, step, vd, 128, 8, hid, prev, baseline_action=rand)
+                np.testing.assert_allclose(hid.numpy(), g["vd%d_hidden_%d" % (vd, step)], rtol=1e-4, atol=1e-5)
+                assert np.array_equal(prev[:, :, :, :4, :4].numpy(), g["vd%d_patch_corner_%d" % (vd, step)])
+                np.testing.assert_allclose(total.numpy(), g["vd%d_total_%d" % (vd, step)], rtol=1e-4, atol=3e-5)
+                np.testing.assert_allclose(base.numpy(), g["vd%d_base_%d" % (vd, step)], rtol=1e-4, atol=3e-5)
