@@ -90,6 +90,11 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s); 
 int adaf_pick_conv_tile(int M, int N, int K, int cus);
 bool adaf_conv_tile_exists(int tile);   // is `tile` an id adaf_launch_conv_gemm has a kernel for
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
+// conv2 3x3 (64 -> 64) -> conv3 1x1 (+ identity, ReLU) [-> the next block's conv1 1x1] in one launch (stage 1 of the trunk);
+// returns 0 or < 0 when the shape is not eligible
+int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3, const float* b3, const float* res, int ldr,
+                           float* out, int n3, const float* w1n, const float* s1n, const float* b1n, float* out1, int n1,
+                           hipStream_t s);
 
 // crop.hip
 hipError_t adaf_launch_crop(const float* frames, int nf, int C, int H, int W, const float* act, int fpa, int P,
@@ -127,3 +132,6 @@ void adaf_launch_pack_stem_weight(const float* w_oihw, float* wr, hipStream_t s)
 size_t adaf_stem_weight_floats();
 void adaf_launch_stem7x7(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
                          int cus, hipStream_t s);
+bool adaf_stem7x7_pool_pays(int P);     // does the fused stem + max-pool launch beat the two separate ones at this patch size
+void adaf_launch_stem7x7_pool(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
+                              int cus, hipStream_t s);

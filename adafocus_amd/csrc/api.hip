@@ -332,6 +332,8 @@ struct adaf_resnet50 {
     std::vector<ConvLayer> convs;  // [0] = stem, then per block conv1, conv2, conv3, (downsample)
     std::vector<int> tiles;        // per conv launch override
     int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
+    bool fuse = true;              // stage 1: conv2 -> conv3 (-> next conv1) in one launch; stem + max-pool in one launch
+    bool fuse_stem_always = false; // (tests) take the fused stem launch at every patch size, not only where it is faster
     float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
     bool finalized = false;
 };
@@ -417,37 +419,79 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
 
     int hh, ww, rc;
     // stem: conv7x7 s2 + BN + ReLU -> maxpool 3x3 s2
-    if (net->tiles[0] == 0) {   // specialised stem kernel (tile override != 0 runs it on the generic engine instead)
+    if (net->tiles[0] == 0 && net->fuse && (adaf_stem7x7_pool_pays(P) || net->fuse_stem_always)) {   // both in one launch: the conv map never reaches HBM
         const ConvLayer& L = net->convs[0];
         hh = ww = conv_out(P, 7, 2, 3);
-        mark(2.0 * (double)n * hh * ww * 64 * 147, 4.0 * ((double)n * P * P * 3 + (double)n * hh * ww * 64 + 64.0 * 147), 40);
-        adaf_launch_stem7x7(x4, n, P, net->stem_w, L.scale, L.bias, buf[0], h->cus, st);
+        const int ph = conv_out(hh, 3, 2, 1);
+        mark(2.0 * (double)n * hh * ww * 64 * 147, 4.0 * ((double)n * P * P * 3 + (double)n * ph * ph * 64 + 64.0 * 147), 90);
+        adaf_launch_stem7x7_pool(x4, n, P, net->stem_w, L.scale, L.bias, buf[1], h->cus, st);
         ++li;
-    } else if ((rc = conv(x4, P, P, ADAF_ACT_RELU, nullptr, buf[0], 0, &hh, &ww, 0))) return rc;
-    const int ph = conv_out(hh, 3, 2, 1), pw = conv_out(ww, 3, 2, 1);
-    mark(0.0, 4.0 * ((double)n * hh * ww * 64 + (double)n * ph * pw * 64), 0);
-    adaf_launch_maxpool(buf[0], n, hh, ww, 64, buf[1], st);
-    hh = ph; ww = pw;
+        hh = ww = ph;
+    } else {
+        if (net->tiles[0] == 0) {   // specialised stem kernel (tile override != 0 runs it on the generic engine instead)
+            const ConvLayer& L = net->convs[0];
+            hh = ww = conv_out(P, 7, 2, 3);
+            mark(2.0 * (double)n * hh * ww * 64 * 147, 4.0 * ((double)n * P * P * 3 + (double)n * hh * ww * 64 + 64.0 * 147), 40);
+            adaf_launch_stem7x7(x4, n, P, net->stem_w, L.scale, L.bias, buf[0], h->cus, st);
+            ++li;
+        } else if ((rc = conv(x4, P, P, ADAF_ACT_RELU, nullptr, buf[0], 0, &hh, &ww, 0))) return rc;
+        const int ph = conv_out(hh, 3, 2, 1), pw = conv_out(ww, 3, 2, 1);
+        mark(0.0, 4.0 * ((double)n * hh * ww * 64 + (double)n * ph * pw * 64), 0);
+        adaf_launch_maxpool(buf[0], n, hh, ww, 64, buf[1], st);
+        hh = ph; ww = pw;
+    }
     float* cur = buf[1];
     float* nxt = buf[0];
+    float* t1 = buf[2];            // conv1 output
+    float* t2 = buf[3];            // conv2 output (or, after a fused launch, the NEXT block's conv1 output)
+    bool c1_done = false;          // the previous fused launch already produced this block's conv1 output (in t1)
     for (int s = 0; s < 4; ++s) {
         for (int b = 0; b < kStageBlocks[s]; ++b) {
-            int h1, w1, h2, w2, h3, w3;
+            int h1 = hh, w1 = ww, h2, w2, h3, w3;
+            const int i_c2 = li + 1, i_c3 = li + 2, i_ds = li + 3;
+            const int i_next = li + 3 + (b == 0 ? 1 : 0);          // the next block's conv1 (or convs.size())
             // conv1 (1x1, optional fused temporal shift) -> conv2 (3x3, stride) -> conv3 (1x1) + identity
-            if ((rc = conv(cur, hh, ww, ADAF_ACT_RELU, nullptr, buf[2], tsm_T > 0, &h1, &w1, 0))) return rc;
-            if ((rc = conv(buf[2], h1, w1, ADAF_ACT_RELU, nullptr, buf[3], 0, &h2, &w2, 0))) return rc;
+            if (!c1_done) {
+                if ((rc = conv(cur, hh, ww, ADAF_ACT_RELU, nullptr, t1, tsm_T > 0, &h1, &w1, 0))) return rc;
+            } else ++li;
+            c1_done = false;
             const float* identity = cur;
             if (b == 0) {
-                // launch order: conv3's layer index precedes the downsample's in `convs`
-                const int keep = li;
-                li = keep + 1;
+                li = i_ds;
                 int hd, wd;
                 if ((rc = conv(cur, hh, ww, ADAF_ACT_NONE, nullptr, buf[4], 0, &hd, &wd, 0))) return rc;
-                li = keep;
                 identity = buf[4];
             }
-            if ((rc = conv(buf[3], h2, w2, ADAF_ACT_RELU, identity, nxt, 0, &h3, &w3, 0))) return rc;
-            if (b == 0) ++li;  // skip the downsample slot
+            li = i_c2;
+            const ConvLayer& L2 = net->convs[i_c2];
+            const bool fusable = net->fuse && net->math == ADAF_MATH_F32 && L2.cin == 64 && L2.cout == 64 && L2.stride == 1 &&
+                                 !net->tiles[i_c2] && !net->tiles[i_c3];
+            if (fusable) {
+                const ConvLayer& L3 = net->convs[i_c3];
+                adaf_conv_params p;
+                memset(&p, 0, sizeof(p));
+                p.n = n; p.h = h1; p.w = w1; p.cin = L2.cin_pad; p.cout = L2.cout; p.kh = p.kw = L2.k; p.stride = 1; p.pad = L2.pad;
+                p.act = ADAF_ACT_RELU;
+                ConvArgs a2;
+                if ((rc = make_conv_args(h, &p, t1, L2.w, L2.scale, L2.bias, nullptr, t2, &a2))) return rc;
+                // the next block's conv1 rides along unless it carries a temporal shift or a tile override
+                const ConvLayer* Ln = (tsm_T == 0 && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;
+                if (Ln && !(Ln->k == 1 && Ln->stride == 1 && Ln->cin == L3.cout && (Ln->cout == 64 || Ln->cout == 128))) Ln = nullptr;
+                const double M = (double)a2.M;
+                double macs = M * 64 * 9 * 64 + M * L3.cout * 64 + (Ln ? M * Ln->cout * L3.cout : 0.0);
+                double bytes = 4.0 * (M * 64 + 2.0 * M * L3.cout + (Ln ? M * Ln->cout : 0.0) + 64.0 * 576 + 64.0 * L3.cout +
+                                      (Ln ? (double)Ln->cout * L3.cout : 0.0));
+                mark(2.0 * macs, bytes, Ln ? 92 : 91);
+                if (adaf_launch_fused_tail(a2, L3.w, L3.scale, L3.bias, identity, L3.cout, nxt, L3.cout, Ln ? Ln->w : nullptr,
+                                           Ln ? Ln->scale : nullptr, Ln ? Ln->bias : nullptr, t2, Ln ? Ln->cout : 0, st) < 0)
+                    return fail(h, ADAF_E_LAUNCH, "resnet50: fused bottleneck tail rejected the shape");
+                h3 = a2.OH; w3 = a2.OW;
+                if (Ln) { float* t = t1; t1 = t2; t2 = t; c1_done = true; }
+            } else {
+                if ((rc = conv(t1, h1, w1, ADAF_ACT_RELU, nullptr, t2, 0, &h2, &w2, 0))) return rc;
+                if ((rc = conv(t2, h2, w2, ADAF_ACT_RELU, identity, nxt, 0, &h3, &w3, 0))) return rc;
+            }
+            li = i_next;
             hh = h3; ww = w3;
             float* t = cur; cur = nxt; nxt = t;
         }
@@ -579,7 +623,10 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) rc = hip_fail(net->h, e, "resnet50 profiled forward");
     }
-    if (rc == ADAF_OK && ev.size() == info.size() + 1) {
+    if (rc == ADAF_OK && info.size() + 1 <= ev.size()) {
+        for (size_t i = info.size(); i + 1 < ev.size(); ++i) {   // fused plans use fewer launches than the table holds
+            launch_ms[i] = 0.f; launch_flops[i] = 0.0; launch_bytes[i] = 0.0; launch_tile[i] = -1;
+        }
         for (size_t i = 0; i < info.size(); ++i) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
@@ -600,6 +647,13 @@ int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count) {
             return fail(net->h, ADAF_E_BADARG, "set_tiles: no kernel variant with id %d", tile[i]);
         net->tiles[i] = tile[i];
     }
+    return ADAF_OK;
+}
+
+int adaf_resnet50_set_fusion(adaf_resnet50* net, int on) {
+    if (!net) return ADAF_E_BADARG;
+    net->fuse = on != 0;
+    net->fuse_stem_always = on == 2;
     return ADAF_OK;
 }
 

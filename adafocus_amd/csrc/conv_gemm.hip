@@ -764,6 +764,354 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
 
+// =============================================================================================
+// Fused bottleneck tail for the 64-plane stage (ACT/models/resnet.py:94-114, layer1):
+//     conv2 3x3 (64 -> 64) + BN + ReLU  ->  conv3 1x1 (64 -> 256) + BN + identity + ReLU  [->  next block's conv1 1x1 + BN + ReLU]
+// in ONE launch per 128-pixel tile.  Unfused, these layers are HBM-bound: conv3 reads a 151 MB map to write a 604 MB one
+// (14 FLOP/B against a machine balance of ~25), and the next conv1 reads the 604 MB straight back.  Here
+//   phase 1  the 3x3 implicit GEMM (K = 576) exactly as conv_gemm_glds_kernel<128,64> runs it (same DMA, swizzle, k order);
+//   mid      BN + ReLU on the accumulators, written to LDS in the A-operand image a DMA would have produced (the stage
+//            buffers are dead by then and are reused), every wave then keeps its 32-row band's fragments in registers;
+//   phase 2  conv3 in 8 passes of 32 output channels: W3 rows arrive by DMA, 32 MFMAs per wave, epilogue with the
+//            16-byte residual loads / output stores of conv_epilogue; the finished (post-ReLU) values also go to LDS as
+//            the A operand (one k slice) of
+//   phase 3  the next block's conv1: out1[128 x N1] += chunk[128 x 32] * W1n[:, 32 pass .. +32]^T, accumulated across
+//            the passes in registers -- conv3's output is consumed on chip while it is being written to HBM once.
+// Every product keeps the k order of the unfused kernels, so the results are BIT-IDENTICAL to the three separate
+// launches (tests: test_resnet50_fused_stage1_bit_identical).  Two blocks fit a CU (66 / 74 KB of LDS), so one block's
+// HBM-heavy phase 2 overlaps the other's MFMA-heavy phase 1.  The next conv1 cannot ride along when it carries a fused
+// temporal shift (its rows come from other clips' frames): N1 = 0 then.
+struct FusedTailArgs {
+    ConvArgs c2;          // the 3x3 conv (x, w, scale, bias, geometry; N = 64, K = 9 * 64)
+    const float* w3;      // [n3][64]
+    const float* s3;
+    const float* b3;
+    const float* res;     // identity / downsample branch [M][ldr]
+    float* out;           // [M][n3]
+    int n3, ldr;
+    const float* w1n;     // [N1][n3] or nullptr
+    const float* s1n;
+    const float* b1n;
+    float* out1;          // [M][N1]
+    int act1n;
+};
+
+template <int N1>
+__global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTailArgs fa) {
+    constexpr int BM = 128, BN = 64, NW = 4, WGN = 2;
+    constexpr int TM = 2, TN = 1;
+    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW), NI = AI + BI;
+    constexpr int STAGE = BM * 32 + BN * 32;             // floats
+    constexpr int XREG = 2 * STAGE;                      // phase-1 stage ring; phase 2: A2 / chunk image + weight chunks
+    constexpr int PW = 32;                               // conv3 output channels per pass
+    constexpr int TN1 = N1 / 64;                         // phase-3 wave tile: 64 rows x (N1 / 2) columns
+    // phase-2 image of the ring region: stage 0 -- idle during the LAST phase-1 slice, so the first chunks are requested a
+    // whole slice early -- holds the W3 chunk buffer(s) and the W1n chunk; then the [2][128][32] A2 image (its first slice
+    // doubles as the conv3-output chunk image)
+    constexpr int W3OFF = 0;
+    constexpr bool W3DB = N1 != 128;                     // two W3 chunk buffers unless the 128-wide W1n chunk needs the room
+    constexpr int W1OFF = (W3DB ? 2 : 1) * 2 * PW * 32;
+    constexpr int A2OFF = W1OFF + N1 * 32;
+    constexpr int XUSED = A2OFF + 2 * BM * 32;
+    static_assert(A2OFF <= BM * 32 + BN * 32, "the weight chunk buffers must fit stage 0");
+    constexpr int XSZ = XUSED > XREG ? XUSED : XREG;
+    constexpr int SLAB = NW * 32 * 36;
+    __shared__ __attribute__((aligned(16))) float smem[XSZ + SLAB];
+    const ConvArgs& a = fa.c2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    int bid = blockIdx.x;
+    {
+        const int q = a.nblocks >> 3, r = a.nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = bid * BM;
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- phase 1: 3x3 implicit GEMM, tile 128 x 64, K = KH*KW*64 ------------------------------------------
+    const int lr = lane >> 3, ls = lane & 7;
+    long long boff[AI];
+    unsigned amask[AI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int row = (j * NW + wave) * 8 + lr;
+        const int m = m0 + row;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int qa = (ls ^ ((row >> 1) & 7)) * 4;
+        const int ohw = a.OH * a.OW;
+        const int img = mm / ohw;
+        const int rem = mm - img * ohw;
+        const int oy = rem / a.OW;
+        const int ox = rem - oy * a.OW;
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        boff[j] = ((long long)img * a.H * a.W + (long long)iy0 * a.W + ix0) * a.ldx + qa;
+        unsigned mk = 0;
+        for (int kh = 0; kh < a.KH; ++kh)
+            for (int kw = 0; kw < a.KW; ++kw)
+                if (ok && (unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W) mk |= 1u << (kh * a.KW + kw);
+        amask[j] = mk;
+    }
+    const float* pb[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = (j * NW + wave) * 8 + lr;           // BN = 64 = a.N: always a valid filter
+        pb[j] = a.w + (size_t)row * a.K + (ls ^ ((row >> 1) & 7)) * 4;
+    }
+    int nx_tap = 0, nx_c0 = 0, nx_kh = 0, nx_kw = 0;
+    long long nx_toff = 0;
+    auto prep = [&](int kt) {
+        if (kt == 0) { nx_c0 = 0; nx_tap = 0; nx_kh = 0; nx_kw = 0; }
+        else {
+            nx_c0 += 32;
+            if (nx_c0 == a.cin) {
+                nx_c0 = 0;
+                ++nx_tap;
+                if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
+            }
+        }
+        nx_toff = ((long long)nx_kh * a.W + nx_kw) * a.ldx + nx_c0;
+    };
+    auto issue_one = [&](int q, int buf) {
+        if (q < BI) {
+            float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[q], (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
+            pb[q] += 32;
+            return;
+        }
+        const int j = q - BI;
+        float* As = smem + buf * STAGE + wave * 8 * 32;
+        const float* src = ((amask[j] >> nx_tap) & 1u) ? a.x + boff[j] + nx_toff : a.zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    const int sw = (lane >> 1) & 7;
+    const int hb = ((lane >> 5) ^ sw) & 1;
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 32 + ((((2 * kk) ^ (sw & 6)) | hb) << 2);
+    const int a_base = wm * TM * 32 * 32;
+    const int b_base = BM * 32 + wn * TN * 32 * 32;
+
+    // ---- phase-2 helpers (declared here: the first weight chunks and residual rows are requested during phase 1)
+    float* A2 = smem + A2OFF;               // [2 slices][128 rows][32], chunk index XOR-ed with (row>>1)&7
+    float* W3s = smem + W3OFF;              // [2 buffers][2 slices][32 rows][32]
+    float* W1s = smem + W1OFF;              // [N1 rows][32]
+    float* slab = smem + XSZ + wave * 32 * 36;
+    const bool full = m0 + BM <= a.M;       // every lane stores in every pass: the counted waits below are exact
+    const int c4 = lane & 7, rsub = lane >> 3;               // epilogue: 8 chunks of 4 channels per row, 8 rows per instruction
+    // instruction u = j*4 + wave of a W3 chunk: slice u / 4, rows (u % 4) * 8 + lr
+    auto issue_w3 = [&](int np) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = j * NW + wave;
+            const int sl = u >> 2, row = (u & 3) * 8 + lr;
+            const float* src = fa.w3 + (size_t)(np * PW + row) * 64 + sl * 32 + ((ls ^ ((row >> 1) & 7)) << 2);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(W3s + (W3DB ? (np & 1) * 2048 : 0) + u * 256), 16, 0, 0);
+        }
+    };
+    auto issue_w1 = [&](int np) {
+        if (N1 == 0) return;
+#pragma unroll
+        for (int j = 0; j < (N1 ? N1 / 32 : 1); ++j) {
+            const int u = j * NW + wave;
+            const int row = u * 8 + lr;
+            const float* src = fa.w1n + (size_t)row * fa.n3 + np * PW + ((ls ^ ((row >> 1) & 7)) << 2);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(W1s + u * 256), 16, 0, 0);
+        }
+    };
+    f32x4 rv[4];                             // identity rows of the coming conv3 pass (requested one pass ahead)
+    auto load_res = [&](int np) {
+        const int n = np * PW + 4 * c4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + wave * 32 + u * 8 + rsub;
+            rv[u] = *reinterpret_cast<const f32x4*>(m < a.M ? fa.res + (size_t)m * fa.ldr + n : a.zeros);
+        }
+    };
+
+    const int nk = a.K / 32;
+    prep(0);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) issue_one(q, 0);
+    auto slice = [&](int kt, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nbuf = (kt + 1) & 1;
+        if (more) prep(kt + 1);
+        else {   // last slice (odd index: it reads stage 1): stage 0 is idle -> first conv3 weight chunk + identity rows
+            issue_w3(0);
+            issue_w1(0);
+            load_res(0);
+        }
+        const float* St = smem + (kt & 1) * STAGE;
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[0]);
+        bf[0][0] = *reinterpret_cast<const f32x4*>(St + b_base + foff[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cb = kk & 1, nb = cb ^ 1;
+            if (kk < 3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[kk + 1]);
+                bf[nb][0] = *reinterpret_cast<const f32x4*>(St + b_base + foff[kk + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][s4], bf[cb][0][s4], acc[i][0], 0, 0, 0);
+                if (s4 < 2) {
+                    if (more) {
+#pragma unroll
+                        for (int q = 0; q < NI; ++q)
+                            if ((q * 8) / NI == 2 * kk + s4) issue_one(q, nbuf);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
+    slice(nk - 1, std::false_type{});
+    __syncthreads();      // every wave is done with the stage ring: it becomes the phase-2 workspace
+
+    // ---- phase 2 set-up: BN + ReLU of conv2 into the A image (the first weight chunks are already on their way)
+    {
+        const int k = wn * 32 + (lane & 31);                 // conv2 output channel = conv3's k index
+        const float sc = a.scale ? a.scale[k] : 1.f, bi = a.bias ? a.bias[k] : 0.f;
+        const int kc = (lane & 31) >> 2, ke = lane & 3;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                A2[wn * (BM * 32) + row * 32 + ((kc ^ ((row >> 1) & 7)) << 2) + ke] = fmaxf(fmaf(acc[i][0][r], sc, bi) + 0.f, 0.f);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // this wave's 32-row band of the conv3 A operand, K = 64: 8 fragments stay in registers for all passes
+    f32x4 af2[2][4];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) af2[sl][kk] = *reinterpret_cast<const f32x4*>(A2 + sl * (BM * 32) + wave * 1024 + foff[kk]);
+    // (a wave rewrites only its own band of the image in the epilogue below, after these reads: no barrier needed)
+
+    f32x16 acc1[TM][TN1 ? TN1 : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < (TN1 ? TN1 : 1); ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+
+    const int npass = fa.n3 / PW;
+    const int crow = 4 * (lane >> 5);
+    for (int np = 0; np < npass; ++np) {
+        // the other W3 buffer was last read in pass np-1, two barriers ago: its refill rides under this pass
+        if (W3DB && np + 1 < npass) issue_w3(np + 1);
+        // ---- conv3, 32 output channels: [32 x 64] band x [64 x 32]
+        f32x16 acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+        const float* W3c = W3s + (W3DB ? (np & 1) * 2048 : 0);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(W3c + sl * 1024 + foff[kk]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(af2[sl][kk][s4], bf[s4], acc3, 0, 0, 0);
+            }
+        // ---- epilogue: BN + identity + ReLU, 16-byte accesses; the result is also the next conv1's A chunk
+        {
+            const int n = np * PW + 4 * c4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(fa.s3 + n);
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(fa.b3 + n);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(crow + (r & 3) + 8 * (r >> 2)) * 36 + (lane & 31)] = acc3[r];
+            __builtin_amdgcn_wave_barrier();
+            f32x4 ov[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = u * 8 + rsub;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 36 + 4 * c4);
+                f32x4 o;
+                o.x = fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, 0.f);
+                o.y = fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, 0.f);
+                o.z = fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, 0.f);
+                o.w = fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, 0.f);
+                ov[u] = o;
+                if (N1) {
+                    const int arow = wave * 32 + row;
+                    *reinterpret_cast<f32x4*>(A2 + arow * 32 + ((c4 ^ ((arow >> 1) & 7)) << 2)) = o;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + wave * 32 + u * 8 + rsub;
+                if (m < a.M) *reinterpret_cast<f32x4*>(fa.out + (size_t)m * fa.n3 + n) = ov[u];
+            }
+            if (np + 1 < npass) load_res(np + 1);        // the next pass's identity rows travel under this pass's tail
+        }
+        // Everything this wave needs next was requested BEFORE this pass's four output stores (vmcnt retires in order), so
+        // it waits for "all but the newest four" and never for its own stores; ragged last block: plain vmcnt(0).
+        // (newest in flight: 4 stores + the 4 identity loads of the next pass)
+        if (!full) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (np + 1 < npass) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // chunk image complete; this pass's W3 rows consumed; W1n[np] (and W3[np+1]) landed
+        if (!W3DB && np + 1 < npass) issue_w3(np + 1);
+        if (N1) {
+            // ---- next conv1: acc1 += chunk[128 x 32] x W1n[:, 32 np ..]^T, wave tile 64 x N1/2
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 af[TM], bf[TN1 ? TN1 : 1];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(A2 + (wm * 64 + i * 32) * 32 + foff[kk]);
+#pragma unroll
+                for (int j = 0; j < TN1; ++j) bf[j] = *reinterpret_cast<const f32x4*>(W1s + (wn * TN1 * 32 + j * 32) * 32 + foff[kk]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN1; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s4], bf[j][s4], acc1[i][j], 0, 0, 0);
+            }
+            if (W3DB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // single W3 buffer: its refill must have landed
+            __builtin_amdgcn_s_barrier();     // chunk image and W1n[np] consumed
+            if (np + 1 < npass) issue_w1(np + 1);
+        }
+    }
+    if (N1) {
+        ConvArgs o1 = a;
+        o1.scale = fa.s1n; o1.bias = fa.b1n; o1.res = nullptr; o1.out = fa.out1; o1.N = N1; o1.ldo = N1; o1.ldr = N1;
+        o1.act = fa.act1n; o1.vec_epi = 1;
+        __syncthreads();
+        conv_epilogue<TM, (TN1 ? TN1 : 1)>(o1, smem, acc1, m0, 0, wm, wn, lane, wave);
+    }
+}
+
 // One thread per output element: the plain statement of the same contract.
 __global__ void conv_naive_kernel(const ConvArgs a) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -952,4 +1300,22 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s) {
     const long long total = (long long)a.M * a.N;
     hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// Launcher of conv_fused_tail_kernel: c2 = the 3x3 conv's flattened description (64 -> 64, cin % 32 == 0, 16-byte epilogue legal).
+int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3, const float* b3, const float* res, int ldr,
+                           float* out, int n3, const float* w1n, const float* s1n, const float* b1n, float* out1, int n1,
+                           hipStream_t s) {
+    if (c2.N != 64 || c2.cin != 64 || (c2.K & 31) || c2.KH * c2.KW > 32 || n3 % 32 || (n1 != 0 && n1 != 64 && n1 != 128)) return -1;
+    FusedTailArgs fa;
+    fa.c2 = c2;
+    fa.c2.tiles_n = 1;
+    fa.c2.nblocks = (c2.M + 127) / 128;
+    fa.w3 = w3; fa.s3 = s3; fa.b3 = b3; fa.res = res; fa.out = out; fa.n3 = n3; fa.ldr = ldr;
+    fa.w1n = w1n; fa.s1n = s1n; fa.b1n = b1n; fa.out1 = out1; fa.act1n = ADAF_ACT_RELU;
+    const dim3 grid(fa.c2.nblocks), block(256);
+    if (n1 == 0) hipLaunchKernelGGL((conv_fused_tail_kernel<0>), grid, block, 0, s, fa);
+    else if (n1 == 64) hipLaunchKernelGGL((conv_fused_tail_kernel<64>), grid, block, 0, s, fa);
+    else hipLaunchKernelGGL((conv_fused_tail_kernel<128>), grid, block, 0, s, fa);
+    return 0;
 }

@@ -279,11 +279,15 @@ class ResNet50Trunk:
         ms = (C.c_float * k)()
         fl = (C.c_double * k)()
         by = (C.c_double * k)()
-        tl = (C.c_int * k)()
+        tl = (C.c_int * k)(*([-1] * k))
         L.check(self._lib.adaf_resnet50_forward_profiled(self._net, L.ptr(x), n, p, int(tsm_segments), int(tsm_div),
                                                          L.ptr(out), 2048, L.ptr(ws), need, L.stream_ptr(), ms, fl, by,
                                                          tl), self._h)
-        return [dict(ms=ms[i], flops=fl[i], bytes=by[i], tile=tl[i]) for i in range(k)]
+        return [dict(ms=ms[i], flops=fl[i], bytes=by[i], tile=tl[i]) for i in range(k) if tl[i] != -1]
+
+    def set_fusion(self, on):
+        """Stage-1 conv2 -> conv3 (-> next conv1) and stem + max-pool as single launches (default on; bit-identical)."""
+        L.check(self._lib.adaf_resnet50_set_fusion(self._net, int(on)), self._h)   # 2 = also the fused stem where it does not pay (tests)
 
     def set_tiles(self, tiles):
         arr = (C.c_int * len(tiles))(*tiles)

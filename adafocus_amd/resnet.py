@@ -80,9 +80,16 @@ class ResNet(nn.Module):
             if self._trunk is None or self._trunk.device != dev:
                 self._trunk = hip_ops.ResNet50Trunk(dev)
                 self._trunk.set_math(getattr(self, "_math", None) or DEFAULT_MATH)
+                self._trunk.set_fusion(getattr(self, "_fusion", True))
             self._trunk.load(params)
             self._sig = sig
         return self._trunk
+
+    def set_fusion(self, on):
+        """Trunk layer fusion (stage-1 bottleneck tails, stem + max-pool) on / off; bit-identical either way."""
+        self._fusion = int(on)
+        if self._trunk is not None:
+            self._trunk.set_fusion(on)
 
     def set_math(self, mode):
         """Opt-in arithmetic of the convolutions: "f32" (default, fp32 matrix pipe) or "split_bf16" (fp32 operands

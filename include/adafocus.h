@@ -203,6 +203,13 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
                                    int* launch_tile);
 /* Kernel-variant override table for tuning: tile[i] as in adaf_conv_params.tile for conv launch i (0 = auto). */
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
+/* Layer fusion inside the trunk (default on; off = one launch per layer, for A/B and the bit-identity tests):
+ *   - stage 1 (64 planes): conv2 3x3 -> conv3 1x1 + identity + ReLU -> the NEXT block's conv1 1x1 in one launch per
+ *     128-pixel tile (csrc/conv_gemm.hip conv_fused_tail_kernel); the next conv1 is left out when it carries a temporal shift;
+ *   - stem conv 7x7/2 + BN + ReLU + max-pool 3x3/2 in one launch (csrc/stem.hip) at the patch sizes where that is the
+ *     faster plan (on = 2: at every size, for tests).
+ * Results are bit-identical to the unfused launches (same k order in every product).  ADAF_MATH_F32 only. */
+int adaf_resnet50_set_fusion(adaf_resnet50* net, int on);
 /* Arithmetic of the trunk's convolutions (no reference counterpart; the reference is plain fp32).
  *   ADAF_MATH_F32            (default) v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain per output.
  *   ADAF_MATH_F32_SPLIT_BF16 (opt-in)  every fp32 operand x is decomposed EXACTLY into bf16 parts h + m + l (round-to-

@@ -302,6 +302,35 @@ def test_sth_video_div_and_baseline_golden(dev, vd):
             prev = patch
 
 
+# ------------------------------------------------------------------------------------ fused trunk launches
+@pytest.mark.parametrize("p,n,tsm", [(96, 8, 0), (128, 4, 0), (100, 3, 0), (72, 4, 4), (96, 16, 8), (64, 1, 0), (33, 5, 0)])
+def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
+    """Stage-1 conv2 -> conv3 -> next conv1 in one launch and stem + max-pool in one launch (adaf_resnet50_set_fusion):
+    same k order in every product, hence torch.equal with the one-launch-per-layer plan -- full tiles, ragged last tiles
+    (n * (p/4)^2 not a multiple of 128), with the temporal shift (next conv1 left out) and without."""
+    from adafocus_amd.resnet import resnet50
+    net = resnet50(num_classes=10).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 11).items()})
+    net = net.to(dev)
+    net.set_math("f32")
+    net.tsm_segments = tsm
+    x = rnd((n, p, p, 4), 900 + p + n).to(dev)
+    x[..., 3] = 0
+    net.set_fusion(False)
+    ref = net.features_nhwc4(x).clone()
+    prof_ref = net._sync().profile(x, tsm_segments=tsm)
+    net.set_fusion(2)          # 2: the fused stem launch at every patch size, not only where it is the faster plan
+    got = net.features_nhwc4(x).clone()
+    prof = net._sync().profile(x, tsm_segments=tsm)
+    net.set_fusion(True)
+    assert torch.equal(net.features_nhwc4(x), ref)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref)
+    assert len(prof) < len(prof_ref)                       # the fused plan really ran (fewer launches)
+    assert abs(sum(e["flops"] for e in prof) - sum(e["flops"] for e in prof_ref)) < 1e-6 * sum(e["flops"] for e in prof_ref)
+
+
 # ------------------------------------------------------------------------------------ GRU scan
 def _gru_weights(dev):
     sd = synth_sd("ACT", 606, "classifier.", keep_prefix=False)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch table of the ResNet-50 trunk (HIP-event bracketed): ms, TFLOP/s, algorithmic TB/s, tile.
-usage: layer_table.py [patch=96] [patches=1024] [tsm_segments=0]"""
+usage: layer_table.py [patch=96] [patches=1024] [tsm_segments=0] [fusion=1]"""
 import os
 import sys
 
@@ -24,13 +24,39 @@ trunk = net._sync()
 for _ in range(3):
     trunk.forward(x, tsm_segments=tsm) if tsm else trunk.forward(x)
 runs = [trunk.profile(x, tsm_segments=tsm) for _ in range(5)]
-names = ["stem", "maxpool"]
+fuse = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+trunk.set_fusion(fuse)
+for _ in range(2):
+    trunk.forward(x, tsm_segments=tsm) if tsm else trunk.forward(x)
+runs = [trunk.profile(x, tsm_segments=tsm) for _ in range(5)]
+# launch names follow the plan: tile 90 = stem + max-pool in one launch, 91 = conv2 -> conv3, 92 = conv2 -> conv3 -> next conv1
+order = []
 for li, nb in enumerate((3, 4, 6, 3), 1):
     for b in range(nb):
-        names += ["L%d.%d.c1" % (li, b), "L%d.%d.c2" % (li, b)]
-        if b == 0:
-            names.append("L%d.%d.ds" % (li, b))
-        names.append("L%d.%d.c3" % (li, b))
+        order += [("L%d.%d" % (li, b), b == 0)]
+names, skip_c1 = [], False
+it = iter(runs[0])
+e = next(it)
+names.append("stem+pool" if e["tile"] == 90 else "stem")
+if e["tile"] != 90:
+    next(it)
+    names.append("maxpool")
+for blk, has_ds in order:
+    if not skip_c1:
+        next(it)
+        names.append(blk + ".c1")
+    skip_c1 = False
+    if has_ds:
+        next(it)
+        names.append(blk + ".ds")
+    e = next(it)
+    if e["tile"] in (91, 92):
+        names.append(blk + (".c2+c3+c1'" if e["tile"] == 92 else ".c2+c3"))
+        skip_c1 = e["tile"] == 92
+    else:
+        names.append(blk + ".c2")
+        next(it)
+        names.append(blk + ".c3")
 names.append("avgpool")
 tot = 0.0
 ideal = 0.0
