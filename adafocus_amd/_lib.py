@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libadafocus_hip.so")
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 MATH_F32, MATH_F32_SPLIT_BF16 = 0, 1
+DTYPE_F32, DTYPE_F16 = 0, 1
 CONV_TILES = 4
 
 # every symbol include/adafocus.h declares (tests check the library exports all of them)
@@ -30,6 +31,7 @@ SYMBOLS = (
     "adaf_mobilenetv2_set_param", "adaf_mobilenetv2_finalize", "adaf_mobilenetv2_workspace_bytes",
     "adaf_mobilenetv2_forward", "adaf_mobilenetv2_set_fusion", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
     "adaf_crop_gather_nhwc4_f32", "adaf_ingest_u8_f32", "adaf_crop_resize_f32", "adaf_resize_nearest_f32",
+    "adaf_conv2d_bn_act_f16", "adaf_pack_conv_weight_f16", "adaf_cast_f32_f16", "adaf_dwconv3x3_bn_act_f16", "adaf_mobilenetv2_set_dtype",
 )
 
 
@@ -103,6 +105,11 @@ def load_library():
     lib.adaf_ingest_u8_f32.argtypes = [vp, vp, ip, ip, ip, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]
     lib.adaf_crop_resize_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, ip, ip, vp, ip, ip, vp, ip, vp, vp]
     lib.adaf_resize_nearest_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp, ip, vp]
+    lib.adaf_conv2d_bn_act_f16.argtypes = [vp, C.POINTER(ConvParams), vp, ip, vp, vp, vp, vp, vp, ip, vp]
+    lib.adaf_pack_conv_weight_f16.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp]
+    lib.adaf_cast_f32_f16.argtypes = [vp, vp, C.c_size_t, vp, ip, vp]
+    lib.adaf_dwconv3x3_bn_act_f16.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp]
+    lib.adaf_mobilenetv2_set_dtype.argtypes = [vp, ip]
     _lib = lib
     return lib
 

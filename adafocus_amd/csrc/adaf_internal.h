@@ -39,6 +39,7 @@ struct ConvArgs {
     int tsm_T, tsm_fold, tsm_hw;
     const float* zeros;  // >= 64 bytes of zeros (handle-owned): target of predicated-off loads
     int vec_epi;         // 1: 16-byte epilogue is legal (aligned out/res/scale/bias, strides % 4 == 0)
+    int in16, out16, res16;   // half-precision STORAGE (N2): x and w / out / res hold fp16 (strides stay in elements)
     int tiles_n;         // ceil(N / BN) for the chosen tile
     int nblocks;
 };
@@ -127,6 +128,11 @@ void adaf_launch_ingest_u8(const uint8_t* u8, int clips, int T, int H, int W, co
                            float* out, hipStream_t s);
 void adaf_launch_crop_nhwc4(const float* frames, int nf, int H, int W, const float* act, int fpa, int P, float* out,
                             int32_t* coords, hipStream_t s);
+// half-precision storage (N2)
+void adaf_launch_pack_weight_f16(const float* w, int cout, int cin, int kh, int kw, int cin_pad, void* o, hipStream_t s);
+void adaf_launch_cast(const void* x, long long count, void* o, int to_f16, hipStream_t s);
+void adaf_launch_dwconv3x3_f16(const void* x, int n, int h, int w, int c, int stride, const float* wt, const float* scale,
+                               const float* bias, int act, void* o, hipStream_t s);
 // stem.hip
 void adaf_launch_pack_stem_weight(const float* w_oihw, float* wr, hipStream_t s);
 size_t adaf_stem_weight_floats();

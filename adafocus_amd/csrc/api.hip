@@ -53,6 +53,7 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
         if (fold % 4) return fail(h, ADAF_E_LAYOUT, "conv: temporal-shift fold=%d must be a multiple of 4", fold);
     }
     a->wsp = nullptr;
+    a->in16 = a->out16 = a->res16 = 0;
     a->x = x; a->w = w; a->scale = scale; a->bias = bias; a->res = res; a->out = out;
     a->M = (int)M; a->N = p->cout; a->K = p->kh * p->kw * p->cin;
     a->cin = p->cin; a->H = p->h; a->W = p->w; a->OH = oh; a->OW = ow; a->KH = p->kh; a->KW = p->kw;
@@ -247,6 +248,62 @@ int adaf_conv2d_naive_f32(adaf_handle* h, const adaf_conv_params* p, const float
     adaf_launch_conv_naive(a, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "naive conv launch");
+}
+
+// ---- half-precision storage (N2) -----------------------------------------------------------------------------
+int adaf_conv2d_bn_act_f16(adaf_handle* h, const adaf_conv_params* p, const void* x, int x_dtype, const void* w_ohwi,
+                           const float* scale, const float* bias, const void* residual_f16, void* out, int out_dtype,
+                           void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if ((x_dtype != ADAF_DTYPE_F32 && x_dtype != ADAF_DTYPE_F16) || (out_dtype != ADAF_DTYPE_F32 && out_dtype != ADAF_DTYPE_F16))
+        return fail(h, ADAF_E_BADARG, "conv_f16: unknown dtype");
+    if (x_dtype == ADAF_DTYPE_F32 && out_dtype == ADAF_DTYPE_F32) return fail(h, ADAF_E_BADARG, "conv_f16: nothing is fp16; use adaf_conv2d_bn_act_f32");
+    ConvArgs a;
+    int rc = make_conv_args(h, p, static_cast<const float*>(x), static_cast<const float*>(w_ohwi), scale, bias,
+                            static_cast<const float*>(residual_f16), static_cast<float*>(out), &a);
+    if (rc) return rc;
+    a.in16 = x_dtype == ADAF_DTYPE_F16;
+    a.out16 = out_dtype == ADAF_DTYPE_F16;
+    a.res16 = residual_f16 != nullptr;
+    if (a.in16 && (p->cin % 8 || a.ldx % 8)) return fail(h, ADAF_E_LAYOUT, "conv_f16: fp16 operands need cin %% 8 == 0 (16-byte chunks)");
+    if (!a.in16 && residual_f16) return fail(h, ADAF_E_BADARG, "conv_f16: a residual needs fp16 operands");
+    if (p->tile && (p->tile < 81 || p->tile > 88)) return fail(h, ADAF_E_BADARG, "conv_f16: tile ids are 81..84, 88");
+    if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0)
+        return fail(h, ADAF_E_LAYOUT, "conv_f16: shape not eligible (1x1: cin %% 8 == 0; k x k: cin %% 64 == 0)");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "conv_f16 launch");
+}
+
+int adaf_pack_conv_weight_f16(adaf_handle* h, const float* w_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                              void* w_ohwi_f16, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!w_oihw || !w_ohwi_f16 || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cin_pad < cin || cin_pad % 8)
+        return fail(h, ADAF_E_BADARG, "pack_f16: bad arguments (cin_pad %% 8 == 0)");
+    adaf_launch_pack_weight_f16(w_oihw, cout, cin, kh, kw, cin_pad, w_ohwi_f16, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "pack_f16 launch");
+}
+
+int adaf_cast_f32_f16(adaf_handle* h, const void* src, size_t count, void* dst, int to_f16, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (count == 0) return ADAF_OK;
+    if (!src || !dst) return fail(h, ADAF_E_BADARG, "cast: null pointer");
+    adaf_launch_cast(src, (long long)count, dst, to_f16 ? 1 : 0, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "cast launch");
+}
+
+int adaf_dwconv3x3_bn_act_f16(adaf_handle* h, const void* x_f16, int n, int hh, int ww, int c, int stride, const float* w_33c,
+                              const float* scale, const float* bias, int act, void* out_f16, void* stream) {
+    if (!h) return ADAF_E_BADARG;
+    if (!x_f16 || !w_33c || !scale || !bias || !out_f16 || n <= 0 || hh <= 0 || ww <= 0 || c <= 0) return fail(h, ADAF_E_BADARG, "dwconv_f16: bad arguments");
+    if (stride != 1 && stride != 2) return fail(h, ADAF_E_BADARG, "dwconv_f16: stride must be 1 or 2");
+    if (act < ADAF_ACT_NONE || act > ADAF_ACT_RELU6) return fail(h, ADAF_E_BADARG, "dwconv_f16: activation");
+    if (c % 4 || (reinterpret_cast<uintptr_t>(x_f16) & 7) || (reinterpret_cast<uintptr_t>(out_f16) & 7) || !aligned16(w_33c) || !aligned16(scale) || !aligned16(bias))
+        return fail(h, ADAF_E_LAYOUT, "dwconv_f16: c %% 4 == 0 and 8 / 16-byte alignment required");
+    adaf_launch_dwconv3x3_f16(x_f16, n, hh, ww, c, stride, w_33c, scale, bias, act, out_f16, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "dwconv_f16 launch");
 }
 
 int adaf_pack_conv_weight_f32(adaf_handle* h, const float* w_oihw, int cout, int cin, int kh, int kw, int cin_pad,

@@ -24,6 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -62,9 +64,11 @@ __device__ __forceinline__ float finish_act(float v, bool sig) { return sig ? 1.
 
 // ---- epilogue shared by both kernel families: BN affine, residual, activation ---------------
 // C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
-template <int TM, int TN>
+// ET (half-precision storage variants, N2): bit 0 = `out` holds fp16, bit 1 = `res` holds fp16; strides stay in ELEMENTS.
+template <int TM, int TN, int ET = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0,
                                               int wm, int wn, int lane, int wave) {
+    constexpr bool O16 = (ET & 1) != 0, R16 = (ET & 2) != 0;
     const bool sig = a.act == ADAF_ACT_SIGMOID;
     const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
@@ -100,7 +104,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
                 for (int u = 0; u < 4; ++u) {
                     const int m = m0 + wm * WM + i * 32 + (it + u) * RPI + rsub;
                     const bool ok = n_ok && m < a.M && has_res;
-                    rv[u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+                    if (R16) {
+                        const f16x4 hv = *reinterpret_cast<const f16x4*>(ok ? reinterpret_cast<const _Float16*>(a.res) + (size_t)m * a.ldr + n
+                                                                            : reinterpret_cast<const _Float16*>(a.zeros));
+                        rv[u] = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+                    } else
+                        rv[u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -112,7 +121,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
                     o.y = finish_act(fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi), sig);
                     o.z = finish_act(fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi), sig);
                     o.w = finish_act(fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi), sig);
-                    if (n_ok && m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                    if (n_ok && m < a.M) {
+                        if (O16)
+                            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.ldo + n) =
+                                f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+                        else
+                            *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                    }
                 }
             }
         }
@@ -135,20 +150,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 const bool ok = has_res && n_ok && m < a.M;
-                rv[r] = *(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+                if (R16) rv[r] = ok ? (float)reinterpret_cast<const _Float16*>(a.res)[(size_t)m * a.ldr + n] : 0.f;
+                else rv[r] = *(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 const float v = finish_act(fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi), sig);
-                if (n_ok && m < a.M) a.out[(size_t)m * a.ldo + n] = v;
+                if (n_ok && m < a.M) {
+                    if (O16) reinterpret_cast<_Float16*>(a.out)[(size_t)m * a.ldo + n] = (_Float16)v;
+                    else a.out[(size_t)m * a.ldo + n] = v;
+                }
             }
         }
     }
 }
 
 // FLAGS bit 0: raise wave priority around the MFMA cluster (s_setprio)
-template <int BM, int BN, int WGM, int WGN, int BK, bool DENSE, int FLAGS>
+template <int BM, int BN, int WGM, int WGN, int BK, bool DENSE, int FLAGS, int ET = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int NT = 64 * WGM * WGN;      // threads per block
     constexpr int LDP = BK + 4;             // LDS row pitch in floats (conflict-free b128 access)
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
         __syncthreads();
     }
 
-    conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+    conv_epilogue<TM, TN, ET>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
 
 
@@ -345,7 +364,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // three bf16 parts after the LDS read and multiplied with 6 / 9 v_mfma_f32_32x32x16_bf16 per 16 k (see split3).
 // BSP (split tiles only): the weights come pre-split as three bf16 planes (ConvArgs::wsp); their LDS image is
 // [plane][BN rows][64 B] with the 16-byte chunk index XOR-ed with (row>>2)&3, and a fragment is one ds_read_b128.
-template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false>
+// DT (half-precision STORAGE, N2 / BASELINE config 5): bit 0 = fp16 output, bit 1 = fp16 residual, bit 2 = fp16 operands
+// (x and w): a k slice is then 64 halfs -- the same 128 bytes per row, so the DMA, the LDS image and its swizzle are
+// byte-identical and the loader simply counts in 32-bit words (the launcher halves K / cin / ldx); a lane's 16-byte
+// fragment is exactly the 8 halfs one v_mfma_f32_32x32x16_f16 wants (lanes 0-31: k 0..7, lanes 32-63: k 8..15 of a
+// 16-k step = chunk 2 kk + (lane >> 5), the f32 mapping).  Accumulation, BN and activation stay fp32.
+template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -739,6 +763,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                 for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(St + b_base + j * 1024 + foff[kk + 1]);
             }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((DT & 4) != 0) {
+                // fp16 operands: one 32x32x16 MFMA per tile pair and 16-k step; the slice's DMA follows in four groups
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[cb][i]),
+                                                                            __builtin_bit_cast(f16x8, bf[cb][j]), acc[i][j], 0, 0, 0);
+                if (PIPE) {
+                    if (more) {
+#pragma unroll
+                        for (int q = 0; q < NI; ++q)
+                            if ((q * 4) / NI == kk) issue_one(q, nbuf);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
@@ -756,12 +797,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            }
         }
     };
     for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
     slice(nk - 1, std::false_type{});
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
-    conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+    conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
 
 // =============================================================================================
@@ -1169,6 +1211,28 @@ void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WGM, WGN, BK, false, FLAGS>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
 }
 
+// fp16-operand launches (tile ids 81..84, 88): `a` arrives in ELEMENT units; the loader counts 32-bit words
+template <int BM, int BN, int WGM, int WGN, int DT>
+void launch_glds16(ConvArgs a, bool dense, hipStream_t s) {
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    a.K /= 2; a.cin /= 2; a.ldx /= 2; a.tsm_fold /= 2;
+    const bool special = a.tsm_T > 0 || (a.K & 31);
+    if (dense && special)
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, true, 0, false, DT>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+    else if (dense)
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, false, 0, false, DT>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 0, false, DT>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_glds16_dt(const ConvArgs& a, bool dense, hipStream_t s) {
+    // operands fp16; output fp16 or fp32; residual (if any) fp16
+    if (a.out16) launch_glds16<BM, BN, WGM, WGN, 4 | 2 | 1>(a, dense, s);
+    else launch_glds16<BM, BN, WGM, WGN, 4 | 2>(a, dense, s);
+}
+
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
@@ -1213,13 +1277,50 @@ bool adaf_conv_tile_exists(int tile) {
         case 51: case 52: case 53: case 54:
         case 61: case 62: case 63: case 64: case 65: case 66: case 67:
         case 71: case 72: case 73: case 74:
+        case 81: case 82: case 83: case 84: case 88:      // fp16 operands (adaf_conv2d_bn_act_f16 only)
             return true;
         default:
             return false;
     }
 }
 
+// fp16 operands (tile ids 81..84, 88): word-granular eligibility of the DMA kernel
+static bool conv_glds16_ok(const ConvArgs& a) {
+    if ((a.K & 1) || (a.cin & 1) || (a.ldx & 1)) return false;
+    const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (dense) return (a.K / 2) % 4 == 0;
+    return (a.K / 2) % 32 == 0 && (a.cin / 2) % 32 == 0 && a.KH * a.KW <= 32;
+}
+
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
+    if (a.in16) {
+        if (!conv_glds16_ok(a) || (a.res && !a.res16)) return -1;
+        const bool dense16 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+        if (tile < 81 || tile > 88) {
+            tile = adaf_pick_conv_tile(a.M, a.N, a.K, cus) + 80;
+            const int pad64 = ((a.N + 63) / 64) * 64;
+            if ((pad64 - a.N) * 5 >= a.N && (long long)((a.M + 127) / 128) >= cus) tile = 88;
+        }
+        switch (tile) {
+            case 81: launch_glds16_dt<128, 128, 2, 2>(a, dense16, s); break;
+            case 82: launch_glds16_dt<128, 64, 2, 2>(a, dense16, s); break;
+            case 83: launch_glds16_dt<64, 64, 2, 2>(a, dense16, s); break;
+            case 84: launch_glds16_dt<64, 128, 2, 2>(a, dense16, s); break;
+            case 88: launch_glds16_dt<128, 32, 4, 1>(a, dense16, s); break;
+            default: return -1;
+        }
+        return tile;
+    }
+    if (a.out16) {   // fp32 operands, fp16 store (the 3x3 stem of the half-precision MobileNetV2): register-staged 128x64 tile
+        if (a.res) return -1;
+        ConvArgs b = a;
+        b.tiles_n = (b.N + 63) / 64;
+        b.nblocks = ((b.M + 127) / 128) * b.tiles_n;
+        const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+        if (dense) hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 2, 2, 32, true, 0, 1>), dim3(b.nblocks), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 2, 2, 32, false, 0, 1>), dim3(b.nblocks), dim3(256), 0, s, b);
+        return 2;
+    }
     const bool bsp_ok = a.wsp != nullptr && (a.K & 31) == 0 && adaf_conv_glds_ok(a);
     if (tile == 40) {   // split tiles, automatic: the bigger the wave tile the fewer split instructions per product
         tile = 0;

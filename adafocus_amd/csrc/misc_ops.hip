@@ -24,6 +24,31 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     o[idx] = i < cin ? w[(((long long)oc * cin + i) * kh + y) * kw + x] : 0.f;
 }
 
+// the same with fp16 output (half-precision storage path, N2): round-to-nearest-even of the fp32 weight
+__global__ void pack_weight_f16_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw, int cin_pad,
+                                       _Float16* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)cout * kh * kw * cin_pad;
+    if (idx >= total) return;
+    const int i = (int)(idx % cin_pad);
+    long long t = idx / cin_pad;
+    const int x = (int)(t % kw);
+    t /= kw;
+    const int y = (int)(t % kh);
+    const int oc = (int)(t / kh);
+    o[idx] = (_Float16)(i < cin ? w[(((long long)oc * cin + i) * kh + y) * kw + x] : 0.f);
+}
+
+__global__ void cast_f32_f16_kernel(const float* __restrict__ x, long long count, _Float16* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) o[idx] = (_Float16)x[idx];
+}
+
+__global__ void cast_f16_f32_kernel(const _Float16* __restrict__ x, long long count, float* __restrict__ o) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) o[idx] = (float)x[idx];
+}
+
 // scale = gamma / sqrt(var + eps); bias = beta - mean * scale  (eval-mode BatchNorm)
 __global__ void fold_bn_kernel(const float* g, const float* b, const float* m, const float* v, float eps, int c,
                                float* scale, float* bias) {
@@ -155,10 +180,28 @@ __global__ void pack_dw_weight_kernel(const float* __restrict__ w, int c, float*
 // HBM/L2-bound VALU work (no contraction across channels, so the matrix cores have nothing to do): taps are
 // aligned 16-byte loads that neighbouring lanes (adjacent channel groups) coalesce; a thread that owns PX
 // horizontally adjacent outputs loads each input column once (stride 1: PX+2 columns instead of 3*PX).
-template <int PX, int S, int RY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c4, int oh, int ow,
+// T = float | _Float16: element type of the activations in HBM (N2: half-precision storage; the taps, the BN affine and
+// the accumulation stay fp32 either way).
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<_Float16> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 ld(const _Float16* p) {
+        const h4 v = *reinterpret_cast<const h4*>(p);
+        return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+    }
+    static __device__ __forceinline__ void st(_Float16* p, f32x4 v) {
+        *reinterpret_cast<h4*>(p) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+};
+
+template <int PX, int S, int RY, typename T = float>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void dwconv3x3_kernel(const T* __restrict__ x, int n, int h, int w, int c4, int oh, int ow,
                                  const float* __restrict__ wt, const float* __restrict__ scale,
-                                 const float* __restrict__ bias, float lo, float hi, float* __restrict__ o) {
+                                 const float* __restrict__ bias, float lo, float hi, T* __restrict__ o) {
     // a thread owns PX horizontally adjacent outputs of RY consecutive output rows: the S*(RY-1)+3 input rows and
     // S*(PX-1)+3 input columns they touch are loaded once
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,12 +225,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     for (int ky = 0; ky < NR; ++ky) {
         const int iy = oy0 * S - 1 + ky;
         const bool rv = (unsigned)iy < (unsigned)h;
-        const float* row = x + (((size_t)img * h + min(max(iy, 0), h - 1)) * w) * (size_t)c + 4 * cq;
+        const T* row = x + (((size_t)img * h + min(max(iy, 0), h - 1)) * w) * (size_t)c + 4 * cq;
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int ix = ox0 * S - 1 + ci;
             const bool ok = rv && (unsigned)ix < (unsigned)w;
-            const f32x4 ld = *reinterpret_cast<const f32x4*>(row + (size_t)min(max(ix, 0), w - 1) * c);
+            const f32x4 ld = Vec4<T>::ld(row + (size_t)min(max(ix, 0), w - 1) * c);
             v[ky][ci] = ok ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -226,7 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                 r.y = fminf(fmaxf(fmaf(acc[rr][p].y, sc.y, bi.y), lo), hi);
                 r.z = fminf(fmaxf(fmaf(acc[rr][p].z, sc.z, bi.z), lo), hi);
                 r.w = fminf(fmaxf(fmaf(acc[rr][p].w, sc.w, bi.w), lo), hi);
-                *reinterpret_cast<f32x4*>(o + ((((size_t)img * oh + oy) * ow + ox) * (size_t)c + 4 * cq)) = r;
+                Vec4<T>::st(o + ((((size_t)img * oh + oy) * ow + ox) * (size_t)c + 4 * cq), r);
             }
         }
     }
@@ -346,4 +389,38 @@ void adaf_launch_grid_actions(const float* logits, int rows, int a, const float*
 void adaf_launch_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
     hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for((long long)rows * cols)), dim3(256), 0, s, src, lds, dst, ldd, rows,
                        cols);
+}
+
+// ---- half-precision storage (N2) ------------------------------------------------------------------------------
+void adaf_launch_pack_weight_f16(const float* w, int cout, int cin, int kh, int kw, int cin_pad, void* o, hipStream_t s) {
+    const long long total = (long long)cout * kh * kw * cin_pad;
+    hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(blocks_for(total)), dim3(256), 0, s, w, cout, cin, kh, kw, cin_pad,
+                       static_cast<_Float16*>(o));
+}
+
+void adaf_launch_cast(const void* x, long long count, void* o, int to_f16, hipStream_t s) {
+    if (to_f16)
+        hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(blocks_for(count)), dim3(256), 0, s, static_cast<const float*>(x), count,
+                           static_cast<_Float16*>(o));
+    else
+        hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(blocks_for(count)), dim3(256), 0, s, static_cast<const _Float16*>(x), count,
+                           static_cast<float*>(o));
+}
+
+void adaf_launch_dwconv3x3_f16(const void* x, int n, int h, int w, int c, int stride, const float* wt, const float* scale,
+                               const float* bias, int act, void* o, hipStream_t s) {
+    const int oh = (h + 2 - 3) / stride + 1, ow = (w + 2 - 3) / stride + 1;
+    const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
+    const _Float16* xi = static_cast<const _Float16*>(x);
+    _Float16* oo = static_cast<_Float16*>(o);
+    if (stride == 1) {
+        const long long total = (long long)n * ((oh + 1) / 2) * ((ow + 3) / 4) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 2, _Float16>), dim3(blocks_for(total)), dim3(256), 0, s, xi, n, h, w, c / 4, oh, ow, wt,
+                           scale, bias, lo, hi, oo);
+    } else {
+        const long long total = (long long)n * oh * ((ow + 1) / 2) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<2, 2, 1, _Float16>), dim3(blocks_for(total)), dim3(256), 0, s, xi, n, h, w, c / 4, oh, ow, wt,
+                           scale, bias, lo, hi, oo);
+    }
 }

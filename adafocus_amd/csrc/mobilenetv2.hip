@@ -19,6 +19,7 @@ struct MbConv {
     int cin, cout, k, stride, groups;
     int cin_pad;
     float* w = nullptr;
+    void* w16 = nullptr;   // the same filter bank in fp16 (dense convs, ADAF_DTYPE_F16 mode)
     float* scale = nullptr;
     float* bias = nullptr;
 };
@@ -35,6 +36,7 @@ struct adaf_mobilenetv2 {
     std::vector<MbBlock> blocks;
     int stem = 0, head = 0;
     bool fuse = true;       // expand -> depthwise in one kernel where the shape allows (mbconv.hip)
+    int dtype = ADAF_DTYPE_F32;   // storage type of activations and 1x1 weights
     bool finalized = false;
 };
 
@@ -127,6 +129,23 @@ int run_conv(adaf_mobilenetv2* net, const MbConv& L, const float* in, int n, int
     return adaf_launch_conv_gemm(a, 0, net->h->cus, st) > 0 ? ADAF_OK : ADAF_E_LAUNCH;
 }
 
+// half-precision storage: in16 -> fp16 x / w (L.w16), else the fp32 operands with an fp16 store (stem); out16 selects the store
+int run_conv16(adaf_mobilenetv2* net, const MbConv& L, const void* in, bool in16, int n, int hh, int ww, int act, const void* res16,
+               void* out, bool out16, hipStream_t st) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    const int oh = cdiv_out(hh, L.k, L.stride, L.k / 2), ow = cdiv_out(ww, L.k, L.stride, L.k / 2);
+    a.x = static_cast<const float*>(in); a.w = in16 ? static_cast<const float*>(L.w16) : L.w;
+    a.scale = L.scale; a.bias = L.bias; a.res = static_cast<const float*>(res16); a.out = static_cast<float*>(out);
+    a.M = n * oh * ow; a.N = L.cout; a.K = L.k * L.k * L.cin_pad;
+    a.cin = L.cin_pad; a.H = hh; a.W = ww; a.OH = oh; a.OW = ow; a.KH = a.KW = L.k; a.stride = L.stride; a.pad = L.k / 2;
+    a.ldx = L.cin_pad; a.ldo = L.cout; a.ldr = L.cout; a.act = act;
+    a.zeros = net->h->zeros;
+    a.vec_epi = (L.cout % 4 == 0) ? 1 : 0;
+    a.in16 = in16; a.out16 = out16; a.res16 = res16 != nullptr;
+    return adaf_launch_conv_gemm(a, 0, net->h->cus, st) > 0 ? ADAF_OK : ADAF_E_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -144,6 +163,7 @@ int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
     if (!net) return ADAF_OK;
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
+        if (L.w16) (void)hipFree(L.w16);
         if (L.scale) (void)hipFree(L.scale);
         if (L.bias) (void)hipFree(L.bias);
     }
@@ -154,6 +174,14 @@ int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
 int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on) {
     if (!net) return ADAF_E_BADARG;
     net->fuse = on != 0;
+    return ADAF_OK;
+}
+
+int adaf_mobilenetv2_set_dtype(adaf_mobilenetv2* net, int dtype) {
+    if (!net) return ADAF_E_BADARG;
+    if (dtype != ADAF_DTYPE_F32 && dtype != ADAF_DTYPE_F16) return mfail(net->h, ADAF_E_BADARG, "mobilenetv2: unknown dtype %d", dtype);
+    if (dtype != net->dtype) net->finalized = false;
+    net->dtype = dtype;
     return ADAF_OK;
 }
 
@@ -192,6 +220,10 @@ int adaf_mobilenetv2_finalize(adaf_mobilenetv2* net, void* stream) {
         if (!L.bias && hipMalloc(reinterpret_cast<void**>(&L.bias), L.cout * sizeof(float)) != hipSuccess) return mfail(h, ADAF_E_NOMEM, "mobilenetv2: hipMalloc");
         if (dw) adaf_launch_pack_dw_weight(w, L.cout, L.w, st);
         else adaf_launch_pack_weight(w, L.cout, L.cin, L.k, L.k, L.cin_pad, L.w, st);
+        if (!dw && L.k == 1 && net->dtype == ADAF_DTYPE_F16) {
+            if (!L.w16 && hipMalloc(&L.w16, wn * sizeof(unsigned short)) != hipSuccess) return mfail(h, ADAF_E_NOMEM, "mobilenetv2: hipMalloc");
+            adaf_launch_pack_weight_f16(w, L.cout, L.cin, 1, 1, L.cin_pad, L.w16, st);
+        }
         adaf_launch_fold_bn(g, b, m, v, 1e-5f, L.cout, L.scale, L.bias, st);
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -226,6 +258,45 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
     float* bufB = bufA + (size_t)chunk * io;
     float* bufE = bufB + (size_t)chunk * io;
     float* bufD = bufE + (size_t)chunk * ex;
+
+    if (net->dtype == ADAF_DTYPE_F16) {
+        // ---- half-precision storage: same launch plan, unfused, buffers hold fp16 (the byte budget above is generous)
+        if (tsm_segments > 0) return mfail(h, ADAF_E_BADARG, "mobilenetv2: the fp16 mode has no temporal shift");
+        for (int f0 = 0; f0 < n; f0 += chunk) {
+            const int nc = (n - f0) < chunk ? (n - f0) : chunk;
+            int hw = cdiv_out(size, 3, 2, 1);
+            int rc;
+            void* cur = bufA;
+            void* nxt = bufB;
+            if ((rc = run_conv16(net, net->convs[net->stem], frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size,
+                                 ADAF_ACT_RELU6, nullptr, cur, true, st)))
+                return mfail(h, rc, "mobilenetv2: stem launch (fp16 store)");
+            for (const MbBlock& b : net->blocks) {
+                const int hid = b.inp * b.t;
+                const bool residual = b.stride == 1 && b.inp == b.oup;
+                const void* dw_in = cur;
+                if (b.expand >= 0) {
+                    if ((rc = run_conv16(net, net->convs[b.expand], cur, true, nc, hw, hw, ADAF_ACT_RELU6, nullptr, bufE, true, st)))
+                        return mfail(h, rc, "mobilenetv2: expand launch (fp16)");
+                    dw_in = bufE;
+                }
+                const MbConv& D = net->convs[b.dw];
+                adaf_launch_dwconv3x3_f16(dw_in, nc, hw, hw, hid, b.stride, D.w, D.scale, D.bias, ADAF_ACT_RELU6, bufD, st);
+                const int ohw = cdiv_out(hw, 3, b.stride, 1);
+                if ((rc = run_conv16(net, net->convs[b.project], bufD, true, nc, ohw, ohw, ADAF_ACT_NONE, residual ? cur : nullptr, nxt,
+                                     true, st)))
+                    return mfail(h, rc, "mobilenetv2: project launch (fp16)");
+                void* t = cur; cur = nxt; nxt = t;
+                hw = ohw;
+            }
+            float* fm = featmap + (size_t)f0 * hw * hw * 1280;
+            if ((rc = run_conv16(net, net->convs[net->head], cur, true, nc, hw, hw, ADAF_ACT_RELU6, nullptr, fm, false, st)))
+                return mfail(h, rc, "mobilenetv2: head launch (fp16 operands, fp32 store)");
+            if (featvec) adaf_launch_avgpool(fm, nc, hw * hw, 1280, featvec + (size_t)f0 * ldvec, ldvec, st);
+        }
+        hipError_t e16 = hipGetLastError();
+        return e16 == hipSuccess ? ADAF_OK : mfail(h, ADAF_E_LAUNCH, "mobilenetv2 forward (fp16): %s", hipGetErrorString(e16));
+    }
 
     int fh = 0;
     for (int f0 = 0; f0 < n; f0 += chunk) {

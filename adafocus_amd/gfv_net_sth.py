@@ -26,6 +26,35 @@ from .utils import get_patch, get_patch_nhwc4, nchw_to_nhwc4
 __all__ = ["GFV", "Glancer", "Focuser", "PatchSampler"]
 
 
+class _FcMeanPool(torch.autograd.Function):
+    """mean_t FC(f_t) (+ mean_t glancer logits) with a backward for the CLASSIFIER parameters -- all that stage 3 of this
+    build trains (STH/stage3.py:351-353 with the local CNN frozen).  Forward = adaf_fc_meanpool_forward_f32; backward =
+    two GEMMs on the conv engine:  dW = g^T . mean_t(f)  and  db = g^T . 1  (d mean_t FC(f_t) / dW = mean_t f_t)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, glog, batch):
+        ctx.save_for_backward(feat)
+        ctx.batch = batch
+        return hip_ops.fc_meanpool_forward(feat, batch, weight.detach(), bias.detach(), glog)
+
+    @staticmethod
+    def backward(ctx, g):
+        (feat,) = ctx.saved_tensors
+        b = ctx.batch
+        t = feat.shape[0] // b
+        mean_feat = hip_ops.global_avgpool(feat.view(b, t, 1, -1))              # (B, F) = mean_t f_t
+        bp = (b + 3) // 4 * 4                                                     # the engine wants K % 4 == 0
+        gt = torch.zeros((g.shape[1], bp), device=g.device, dtype=torch.float32)
+        gt[:, :b] = g.t()
+        mt = torch.zeros((mean_feat.shape[1], bp), device=g.device, dtype=torch.float32)
+        mt[:, :b] = mean_feat.t()
+        ones = torch.zeros((4, bp), device=g.device, dtype=torch.float32)
+        ones[0, :b] = 1.0
+        dw = hip_ops.linear(gt, mt)                                               # (C, F)
+        db = hip_ops.linear(gt, ones)[:, 0].contiguous()                          # (C,)
+        return None, dw, db, None, None
+
+
 class GFV(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -72,11 +101,26 @@ class GFV(nn.Module):
         fm, logit = self.glancer(input_prime.reshape(b * t, 3, hh, ww))
         return fm.unflatten(0, (b, t)), logit.view(b, t, -1)
 
-    @torch.no_grad()
     def _stage(self, focuser_image, global_feat_map, global_feat_logit, step, args, prev_local_patch, with_baseline,
-               forced_action=None, baseline_action=None):
-        if self.training:
-            raise RuntimeError("adafocus_amd: eval mode only")
+               forced_action=None, baseline_action=None, train_classifier=False):
+        if self.training and not train_classifier:
+            raise RuntimeError("adafocus_amd: eval mode only (stage 3 trains the classifier through action_stage3)")
+        with torch.no_grad():
+            feat, local_patch, action, b, frames_total, ngroups = self._stage_features(
+                focuser_image, global_feat_map, step, args, prev_local_patch, with_baseline, forced_action, baseline_action)
+        per = b * frames_total
+        glog = global_feat_logit if self.with_glancer else None
+        if train_classifier:
+            # stage 3 (STH/stage3.py:351-353): the patches and local features are constants, the classifier learns
+            f = self.dropout(feat[:per]) if self.training else feat[:per]
+            return [_FcMeanPool.apply(f, self.classifier.weight, self.classifier.bias, glog, b)], local_patch, action
+        with torch.no_grad():
+            logits = [hip_ops.fc_meanpool_forward(feat[g * per:(g + 1) * per], b, self.classifier.weight.detach(),
+                                                  self.classifier.bias.detach(), glog) for g in range(ngroups)]
+        return logits, local_patch, action
+
+    def _stage_features(self, focuser_image, global_feat_map, step, args, prev_local_patch, with_baseline, forced_action,
+                        baseline_action):
         nfg = args.num_segments_glancer // args.video_div
         nff = args.num_segments_focuser // args.video_div
         b, _, c, hh, ww = focuser_image.shape
@@ -107,14 +151,10 @@ class GFV(nn.Module):
             base_cur = get_patch(cur.view(b, nff * c, hh, ww), rand_action, p).view(b, nff, 3, p, p)
             base_patch = base_cur if prev_local_patch is None else torch.cat([prev_local_patch, base_cur], dim=1)
             groups.append(nchw_to_nhwc4(base_patch.reshape(b * frames_total, 3, p, p)))
-        # TSM segments = frames per clip in this pass (tsn.py:num_segments is fixed at construction in the
-        # reference; with video_div = 1 both agree)
+        # the temporal shift views its input as clips of num_segments_focuser frames -- fixed at construction, as in the
+        # reference (tsn.py / temporal_shift.py:103): with video_div > 1 the partial passes shift across clip pairs
         feat = self.focuser.net.features_nhwc4(torch.cat(groups, 0) if len(groups) > 1 else groups[0])
-        per = b * frames_total
-        glog = global_feat_logit if self.with_glancer else None
-        logits = [hip_ops.fc_meanpool_forward(feat[g * per:(g + 1) * per], b, self.classifier.weight.detach(),
-                                              self.classifier.bias.detach(), glog) for g in range(len(groups))]
-        return logits, local_patch, action
+        return feat, local_patch, action, b, frames_total, len(groups)
 
     def action_stage2(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
                       prev_local_patch=None, training=True, with_baseline=True, forced_action=None, baseline_action=None):
@@ -127,9 +167,14 @@ class GFV(nn.Module):
 
     def action_stage3(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
                       prev_local_patch=None, forced_action=None):
-        """STH/models/gfv_net.py:190-225 -> (total_logit, local_patch)."""
+        """STH/models/gfv_net.py:190-225 -> (total_logit, local_patch).  In eval mode this is the inference forward.  With
+        grad enabled and the classifier's parameters requiring grad (stage-3 training, STH/stage3.py:313-317,351-353:
+        model.train() with glancer / focuser / policy in eval mode) `total_logit` carries an autograd graph into
+        classifier.weight / classifier.bias; the local CNN runs without grad on the HIP trunk (its fine-tuning -- the
+        reference's optimizer also lists the focuser backbone -- is training code beyond this build's scope)."""
+        train = self.training and torch.is_grad_enabled() and self.classifier.weight.requires_grad
         logits, local_patch, _ = self._stage(focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
-                                             prev_local_patch, False, forced_action)
+                                             prev_local_patch, False, forced_action, train_classifier=train)
         return logits[0], local_patch
 
     @torch.no_grad()

@@ -10,6 +10,7 @@ import torch
 from . import _lib as L
 from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
 from ._lib import MATH_F32, MATH_F32_SPLIT_BF16  # noqa: F401
+from ._lib import DTYPE_F32, DTYPE_F16  # noqa: F401
 
 
 def _h(t):
@@ -411,6 +412,12 @@ class MobileNetV2Net:
         """Expand 1x1 -> depthwise 3x3 in one kernel for the high-resolution blocks (default on)."""
         L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, 1 if on else 0), self._h)
 
+    def set_dtype(self, dtype):
+        """"f32" (default) or "f16": activations and 1x1 weights stored as fp16, fp32 accumulate (include/adafocus.h N2).
+        Call before load()."""
+        code = {"f32": DTYPE_F32, "f16": DTYPE_F16}.get(dtype, dtype)
+        L.check(self._lib.adaf_mobilenetv2_set_dtype(self._net, int(code)), self._h)
+
     def forward(self, frames_nhwc4, tsm_segments=0, tsm_div=8, want_vec=True):
         """(N,S,S,4) -> featmap (N,S/32,S/32,1280) NHWC, featvec (N,1280) or None."""
         L.need_gpu_f32(frames_nhwc4)
@@ -512,4 +519,81 @@ def resize_nearest(frames, out_hw, layout=LAYOUT_NCHW):
     h = _h(frames)
     L.check(L.load_library().adaf_resize_nearest_f32(h, L.ptr(frames), LAYOUT_NHWC4 if in4 else LAYOUT_NCHW, n, c, hh, ww, oh, ow,
                                                      L.ptr(out), layout, L.stream_ptr()), h)
+    return out
+
+
+# ---- N2: half-precision storage ---------------------------------------------------------------------------------
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.AdafError("adafocus_amd runs on MI355X only: got a %s tensor" % t.device)
+    L.on_current_device(*tensors)
+
+
+def cast(x, dtype):
+    """fp32 <-> fp16 element-wise conversion on the HIP side (round-to-nearest-even)."""
+    _need_gpu(x)
+    x = x.contiguous()
+    to16 = dtype == torch.float16
+    if x.dtype not in (torch.float32, torch.float16) or (x.dtype == torch.float16) == to16:
+        raise ValueError("cast: fp32 -> fp16 or fp16 -> fp32")
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    h = _h(x)
+    L.check(L.load_library().adaf_cast_f32_f16(h, L.ptr(x), x.numel(), L.ptr(out), 1 if to16 else 0, L.stream_ptr()), h)
+    return out
+
+
+def pack_conv_weight_f16(w_oihw, cin_pad=None):
+    """OIHW fp32 -> OHWI fp16 (input channels zero-padded to a multiple of 8)."""
+    L.need_gpu_f32(w_oihw)
+    w = w_oihw.contiguous()
+    co, ci, kh, kw = w.shape
+    cp = cin_pad or ((ci + 7) // 8 * 8)
+    out = torch.empty((co, kh, kw, cp), device=w.device, dtype=torch.float16)
+    h = _h(w)
+    L.check(L.load_library().adaf_pack_conv_weight_f16(h, L.ptr(w), co, ci, kh, kw, cp, L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def conv2d_bn_act_f16(x, w_ohwi, scale=None, bias=None, residual=None, stride=1, pad=0, act=ACT_NONE, out_dtype=torch.float16,
+                      tile=0):
+    """adaf_conv2d_bn_act_f16: x (N,H,W,Cin) fp16 with fp16 weights (or fp32 x / w with an fp16 store), fp32 accumulate and
+    epilogue, `out_dtype` store."""
+    _need_gpu(x, w_ohwi, scale, bias, residual)
+    x = x.contiguous()
+    w_ohwi = w_ohwi.contiguous()
+    if x.dtype != w_ohwi.dtype:
+        raise ValueError("conv2d_bn_act_f16: x and w must share a dtype")
+    n, hh, ww, cin = x.shape
+    cout, kh, kw, cin_w = w_ohwi.shape
+    if cin_w != cin:
+        raise ValueError("conv2d_bn_act_f16: x has %d channels, weight expects %d" % (cin, cin_w))
+    oh = (hh + 2 * pad - kh) // stride + 1
+    ow = (ww + 2 * pad - kw) // stride + 1
+    out = torch.empty((n, oh, ow, cout), device=x.device, dtype=out_dtype)
+    if residual is not None:
+        if residual.dtype != torch.float16:
+            raise ValueError("conv2d_bn_act_f16: the residual is fp16")
+        residual = residual.contiguous()
+    p = L.ConvParams(n=n, h=hh, w=ww, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad=pad, act=act, tsm_segments=0,
+                     tsm_div=8, ldx=0, ldo=0, ldr=0, tile=tile)
+    h = _h(x)
+    L.check(L.load_library().adaf_conv2d_bn_act_f16(h, C.byref(p), L.ptr(x), DTYPE_F16 if x.dtype == torch.float16 else DTYPE_F32,
+                                                    L.ptr(w_ohwi), L.ptr(scale), L.ptr(bias), L.ptr(residual), L.ptr(out),
+                                                    DTYPE_F16 if out_dtype == torch.float16 else DTYPE_F32, L.stream_ptr()), h)
+    return out
+
+
+def dwconv3x3_bn_act_f16(x, w_33c, scale, bias, stride=1, act=ACT_RELU6):
+    """Depthwise 3x3 on fp16 activations (N,H,W,C); taps, BN affine and the sum in fp32."""
+    _need_gpu(x, w_33c, scale, bias)
+    if x.dtype != torch.float16:
+        raise ValueError("dwconv3x3_bn_act_f16: fp16 activations expected")
+    x = x.contiguous()
+    n, hh, ww, c = x.shape
+    out = torch.empty((n, (hh - 1) // stride + 1, (ww - 1) // stride + 1, c), device=x.device, dtype=torch.float16)
+    h = _h(x)
+    L.check(L.load_library().adaf_dwconv3x3_bn_act_f16(h, L.ptr(x), n, hh, ww, c, stride, L.ptr(w_33c.contiguous()),
+                                                       L.ptr(scale.contiguous()), L.ptr(bias.contiguous()), act, L.ptr(out),
+                                                       L.stream_ptr()), h)
     return out

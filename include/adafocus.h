@@ -163,6 +163,27 @@ int adaf_pack_conv_weight_f32(adaf_handle* h, const float* w_oihw, int cout, int
 int adaf_fold_bn_f32(adaf_handle* h, const float* gamma, const float* beta, const float* mean, const float* var,
                      float eps, int channels, float* scale, float* bias, void* stream);
 
+/* ---- N2: half-precision STORAGE variants (BASELINE config 5) -------------------------------------------------
+ * Activations and 1x1 weights as fp16 in HBM, products on v_mfma_f32_32x32x16_f16, accumulation / BN affine /
+ * activation in fp32, fp16 (or fp32) store.  The reference computes in fp32 everywhere (no autocast in its validate
+ * loops) and has NO half-precision or EfficientNet implementation on a live path: these entry
+ * points have no reference call site and their parity is pinned only against the fp32 goldens at fp16 tolerance.
+ *   x_dtype F16: x [n,h,w,cin] and w [cout][kh][kw][cin] hold fp16 (adaf_pack_conv_weight_f16), cin %% 8 == 0
+ *               (k x k filters: cin %% 64 == 0); residual, if any, fp16; out fp16 or fp32.
+ *   x_dtype F32: fp32 operands as adaf_conv2d_bn_act_f32 with an fp16 store (the 3-channel stem); no residual.
+ *   adaf_conv_params.tile: 0 = automatic, 81..84 = 128x128 / 128x64 / 64x64 / 64x128, 88 = 128x32. */
+enum { ADAF_DTYPE_F32 = 0, ADAF_DTYPE_F16 = 1 };
+int adaf_conv2d_bn_act_f16(adaf_handle* h, const adaf_conv_params* p, const void* x, int x_dtype, const void* w_ohwi,
+                           const float* scale, const float* bias, const void* residual_f16, void* out, int out_dtype,
+                           void* stream);
+int adaf_pack_conv_weight_f16(adaf_handle* h, const float* w_oihw, int cout, int cin, int kh, int kw, int cin_pad,
+                              void* w_ohwi_f16, void* stream);
+/* Element-wise conversion, round-to-nearest-even: to_f16 != 0: fp32 -> fp16, else fp16 -> fp32. */
+int adaf_cast_f32_f16(adaf_handle* h, const void* src, size_t count, void* dst, int to_f16, void* stream);
+/* Depthwise 3x3 with fp16 activations (taps, BN affine and the sum in fp32). */
+int adaf_dwconv3x3_bn_act_f16(adaf_handle* h, const void* x_f16, int n, int hh, int ww, int c, int stride, const float* w_33c,
+                              const float* scale, const float* bias, int act, void* out_f16, void* stream);
+
 /* ---- pooling ---------------------------------------------------------------------------
  * nn.MaxPool2d(3, 2, 1) -- ACT/models/resnet.py:141,215; nn.AdaptiveAvgPool2d((1,1)) -- :150,222. */
 int adaf_maxpool3x3s2_f32(adaf_handle* h, const float* x, int n, int hh, int ww, int c, float* out, void* stream);
@@ -247,6 +268,10 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
 /* Expand 1x1 -> depthwise 3x3 in one kernel (the 6x-expanded map stays on chip) for the blocks whose shape allows it
  * (cin % 8 == 0, cin <= 32, map >= 28^2: b2..b7 at 224^2).  On by default; off = the three-launch form (tests, A/B). */
 int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
+/* ADAF_DTYPE_F16: the whole network with fp16 activations and 1x1 weights in HBM (see N2 above; the 3x3 stem reads the
+ * fp32 frames and stores fp16, the 1280-channel head stores fp32 for the consumers downstream; no temporal shift, no
+ * fused expand -> depthwise kernels in this mode).  Takes effect at the next finalize(). */
+int adaf_mobilenetv2_set_dtype(adaf_mobilenetv2* net, int dtype);
 
 /* ---- a11: policy head -------------------------------------------------------------------
  * idx = argmax_a logits[row, a] (first maximum), action = table_yx[idx] -- the eval branch of

@@ -302,6 +302,57 @@ def test_sth_video_div_and_baseline_golden(dev, vd):
             prev = patch
 
 
+def test_sth_stage3_classifier_training_forward(dev, O):
+    """f4: action_stage3 in stage-3 training mode (STH/stage3.py:313-317, 351-353: model.train() with glancer / focuser /
+    policy in eval mode): the local CNN runs frozen on the HIP trunk, the loss back-propagates into classifier.weight /
+    classifier.bias through two engine GEMMs; gradients against torch-CPU autograd on the oracle's features."""
+    g = golden("g7_sth_e2e")
+    m, a = _sth_model(dev, 1)
+    m.dropout.p = 0.0                       # dropout draws from the device RNG: compared with it disabled
+    m.train()
+    m.glancer.eval()
+    m.focuser.eval()
+    m.focuser.policy.policy.eval()
+    m.focuser.policy.policy_old.eval()
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    for p_ in m.classifier.parameters():
+        p_.requires_grad_(True)
+    gl = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=3)).to(dev)
+    fo = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=4)).view(2, 8, 3, 224, 224).to(dev)
+    forced = torch.from_numpy(g["forced_action"]).to(dev)
+    target = torch.tensor([5, 170], device=dev)
+    with torch.no_grad():
+        fm, glog = m.glance(gl)
+    pred, patch = m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced)
+    assert pred.requires_grad and not patch.requires_grad
+    assert np.abs(pred.detach().cpu().numpy() - g["logits_stage3_forced"]).max() < TOL
+    loss = torch.nn.functional.cross_entropy(pred, target)
+    loss.backward()
+    gw, gb = m.classifier.weight.grad.cpu(), m.classifier.bias.grad.cpu()
+    # oracle: same features on the CPU, autograd through Linear + mean
+    sd = synth_sd("STH", 1007)
+    sd.update(synth_sd("STH_POLICY", 1007))
+    sd = O.canonical_resnet_keys(sd, "focuser.net.base_model.")
+    with torch.no_grad():
+        feat = O.resnet50_trunk(sd, "focuser.net.base_model.", patch.detach().cpu().reshape(16, 3, 128, 128), 8, 8).flatten(1)
+    w = sd["classifier.weight"].clone().requires_grad_(True)
+    bb = sd["classifier.bias"].clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(feat, w, bb).view(2, 8, -1).mean(1) + glog.detach().cpu().mean(1)
+    torch.nn.functional.cross_entropy(ref, target.cpu()).backward()
+    assert (gw - w.grad).abs().max().item() < 1e-4 and (gb - bb.grad).abs().max().item() < 1e-4
+    assert gw.abs().max().item() > 1e-3            # a real gradient
+    # one SGD step moves the logits the way the CPU model's step does
+    with torch.no_grad():
+        m.classifier.weight -= 0.1 * m.classifier.weight.grad
+        m.classifier.bias -= 0.1 * m.classifier.bias.grad
+        w2, b2 = w - 0.1 * w.grad, bb - 0.1 * bb.grad
+    pred2, _ = m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced)
+    ref2 = torch.nn.functional.linear(feat, w2, b2).view(2, 8, -1).mean(1) + glog.detach().cpu().mean(1)
+    assert (pred2.detach().cpu() - ref2.detach()).abs().max().item() < TOL
+    m.eval()
+
+
 # ------------------------------------------------------------------------------------ fused trunk launches
 @pytest.mark.parametrize("p,n,tsm", [(96, 8, 0), (128, 4, 0), (100, 3, 0), (72, 4, 4), (96, 16, 8), (64, 1, 0), (33, 5, 0)])
 def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
@@ -329,6 +380,118 @@ def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
     assert torch.equal(got, ref)
     assert len(prof) < len(prof_ref)                       # the fused plan really ran (fewer launches)
     assert abs(sum(e["flops"] for e in prof) - sum(e["flops"] for e in prof_ref)) < 1e-6 * sum(e["flops"] for e in prof_ref)
+
+
+# ------------------------------------------------------------------------------------ N2: half-precision storage
+@pytest.mark.parametrize("tile", [0, 81, 82, 83, 84, 88])
+def test_conv_f16_operands_vs_fp32_reference(dev, ops, tile):
+    """adaf_conv2d_bn_act_f16: fp16 x / w, fp32 accumulate.  With operands that ARE fp16 values the products are exact, so
+    against an fp32 conv of the same values only the summation order (fp32 output) or one fp16 rounding (fp16 output) differs."""
+    gen = np.random.Generator(np.random.PCG64([41, tile]))
+    shapes = [(6, 14, 14, 64, 384, 1, 1, 0, False), (3, 7, 7, 960, 160, 1, 1, 0, True), (2, 28, 28, 24, 144, 1, 1, 0, False),
+              (5, 9, 9, 128, 64, 3, 2, 1, False), (2, 12, 12, 64, 64, 3, 1, 1, True), (1, 1, 1, 1280, 200, 1, 1, 0, False)]
+    for n, hh, ww, cin, cout, k, stride, pad, with_res in shapes:
+        x = torch.from_numpy(gen.standard_normal((n, hh, ww, cin), dtype=np.float32)).half()
+        w = torch.from_numpy(gen.standard_normal((cout, cin, k, k), dtype=np.float32) * np.float32(1.0 / np.sqrt(cin * k * k))).half()
+        sc = torch.from_numpy(gen.random(cout, dtype=np.float32) + np.float32(0.5))
+        bi = torch.from_numpy(gen.standard_normal(cout, dtype=np.float32))
+        oh = (hh + 2 * pad - k) // stride + 1
+        res = torch.from_numpy(gen.standard_normal((n, oh, oh, cout), dtype=np.float32)).half() if with_res else None
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), stride=stride, padding=pad)
+        ref = ref * sc[None, :, None, None] + bi[None, :, None, None]
+        if res is not None:
+            ref = ref + res.float().permute(0, 3, 1, 2)
+        ref = torch.relu(ref).permute(0, 2, 3, 1)
+        w16 = ops.pack_conv_weight_f16(w.float().to(dev))
+        assert torch.equal(w16.cpu(), w.permute(0, 2, 3, 1).contiguous())          # fp16 values survive the packer exactly
+        for odt in (torch.float32, torch.float16):
+            got = ops.conv2d_bn_act_f16(x.to(dev), w16, sc.to(dev), bi.to(dev), None if res is None else res.to(dev), stride=stride,
+                                        pad=pad, act=ops.ACT_RELU, out_dtype=odt, tile=tile)
+            assert got.dtype == odt
+            err = (got.float().cpu() - ref).abs().max().item()
+            assert err < (2e-4 if odt == torch.float32 else 2e-3 * max(1.0, ref.abs().max().item())), (cin, cout, k, odt, err)
+
+
+def test_dwconv_f16_and_casts(dev, ops):
+    gen = np.random.Generator(np.random.PCG64([42, 1]))
+    for n, hh, c, stride in ((3, 14, 384, 1), (2, 15, 96, 2), (1, 7, 960, 1), (4, 1, 32, 1)):
+        x = torch.from_numpy(gen.standard_normal((n, hh, hh, c), dtype=np.float32)).half()
+        w = torch.from_numpy(gen.standard_normal((c, 1, 3, 3), dtype=np.float32) * np.float32(0.3))
+        sc = torch.from_numpy(gen.random(c, dtype=np.float32) + np.float32(0.5))
+        bi = torch.from_numpy(gen.standard_normal(c, dtype=np.float32))
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, stride=stride, padding=1, groups=c)
+        ref = torch.clamp(ref * sc[None, :, None, None] + bi[None, :, None, None], 0, 6).permute(0, 2, 3, 1)
+        got = ops.dwconv3x3_bn_act_f16(x.to(dev), ops.pack_dw_weight(w.to(dev)), sc.to(dev), bi.to(dev), stride=stride)
+        assert got.dtype == torch.float16 and (got.float().cpu() - ref).abs().max().item() < 4e-3
+    v = torch.from_numpy(gen.standard_normal(1001, dtype=np.float32) * 100).to(dev)
+    assert torch.equal(ops.cast(v, torch.float16).cpu(), v.cpu().half())
+    assert torch.equal(ops.cast(ops.cast(v, torch.float16), torch.float32).cpu(), v.cpu().half().float())
+
+
+def test_mobilenetv2_f16_storage_vs_g5_golden(dev, ops):
+    """The MobileNetV2 blocks and the whole network of G5 (generated by the real reference in fp32) with activations and 1x1
+    weights stored as fp16: error of a storage format with 11 significant bits carried through up to 52 layers."""
+    from adafocus_amd.mobilenet import mobilenet_v2
+    g = golden("g5_mbv2_act")
+    mb = mobilenet_v2().eval()
+    shapes = {k: tuple(v.shape) for k, v in mb.state_dict().items()}
+    mb.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 505).items()})
+    mb = mb.to(dev)
+    xc = rnd((2, 3, 64, 64), 53).to(dev)
+    fm32, fv32 = mb.features_nhwc(xc)
+    fm32, fv32 = fm32.clone(), fv32.clone()
+    mb._engine.dtype = "f16"
+    fm16, fv16 = mb.features_nhwc(xc)
+    assert fm16.dtype == torch.float32 and not torch.equal(fm16, fm32)           # the fp16 plan really ran
+    ref_fm = torch.from_numpy(g["fm"]).permute(0, 2, 3, 1)
+    scale = float(ref_fm.abs().max())
+    assert (fm32.cpu() - ref_fm).abs().max().item() < 1e-3
+    assert (fm16.cpu() - ref_fm).abs().max().item() < 3e-2 * scale               # measured ~1e-2 of the range
+    assert (fv16.cpu() - torch.from_numpy(g["fv"])).abs().max().item() < 3e-2 * scale
+    rel = ((fm16.cpu() - ref_fm).pow(2).mean().sqrt() / ref_fm.pow(2).mean().sqrt()).item()
+    assert rel < 1e-2, rel
+    # single inverted-residual blocks (t = 6, stride 1 with identity; t = 6, stride 2) assembled from the fp16 entry points
+    sd = {k: v.to(dev) for k, v in mb.state_dict().items()}
+    xb = rnd((2, 24, 16, 16), 52)
+
+    def block(i, stride, residual):
+        pfx = "features.%d.conv." % i
+        x16 = xb.permute(0, 2, 3, 1).contiguous().half().to(dev)
+        we = ops.pack_conv_weight_f16(sd[pfx + "0.0.weight"])
+        se, be = ops.fold_bn(sd[pfx + "0.1.weight"], sd[pfx + "0.1.bias"], sd[pfx + "0.1.running_mean"], sd[pfx + "0.1.running_var"])
+        e = ops.conv2d_bn_act_f16(x16, we, se, be, act=ops.ACT_RELU6)
+        sdw, bdw = ops.fold_bn(sd[pfx + "1.1.weight"], sd[pfx + "1.1.bias"], sd[pfx + "1.1.running_mean"], sd[pfx + "1.1.running_var"])
+        d = ops.dwconv3x3_bn_act_f16(e, ops.pack_dw_weight(sd[pfx + "1.0.weight"]), sdw, bdw, stride=stride)
+        wp = ops.pack_conv_weight_f16(sd[pfx + "2.weight"])
+        sp, bp = ops.fold_bn(sd[pfx + "3.weight"], sd[pfx + "3.bias"], sd[pfx + "3.running_mean"], sd[pfx + "3.running_var"])
+        return ops.conv2d_bn_act_f16(d, wp, sp, bp, x16 if residual else None, act=ops.ACT_NONE, out_dtype=torch.float32)
+    for name, i, stride, residual in (("r2", 3, 1, True), ("r3", 4, 2, False)):
+        ref = torch.from_numpy(g[name]).permute(0, 2, 3, 1)
+        got = block(i, stride, residual).cpu()
+        assert (got - ref).abs().max().item() < 2e-2 * max(1.0, float(ref.abs().max())), name
+
+
+def test_config5_mbconv_f16_local_cnn_end_to_end(dev, O):
+    """BASELINE config 5's shape (T = 16, P = 144, MBConv local CNN, fp16 storage) through GFV.hot_path.  No reference
+    implementation exists (parity unpinned): checked against the oracle's MobileNetV2 + GRU in fp32 at fp16 tolerance."""
+    m, sd = _act_model(dev, num_segments=16, patch_size=144, local_arch="mbconv_f16")
+    assert m.focuser.feature_dim == 1280 and m.classifier.gru.weight_ih_l0.shape[1] == 2560
+    b, t = 4, 16
+    fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=51))
+    _, act = synth.synth_actions(b * t, 7, seed=52)
+    gvec = rnd((b, t, 1280), 53, 0.5)
+    with torch.no_grad():
+        lg, last, feat = m.hot_path(fr.view(b * t, 3, 224, 224).to(dev), gvec.to(dev), torch.from_numpy(act).to(dev), b, t)
+        patches = O.get_patch(fr.view(b * t, 3, 224, 224), torch.from_numpy(act), 144)
+        local = O.mobilenetv2_features(sd, "focuser.net.net.", patches, "act").mean([2, 3]).view(b, t, -1)
+        rl, rlast = O.recurrent_classifier(sd, "classifier.", torch.cat([gvec, local], dim=2))
+    lf = feat[:, :, 1280:].cpu()
+    assert ((lf - local).pow(2).mean().sqrt() / local.pow(2).mean().sqrt()).item() < 1e-2
+    assert (lg.cpu() - rl).abs().max().item() < 5e-2 and (last.cpu() - rlast).abs().max().item() < 5e-2
+    m32, _ = _act_model(dev, num_segments=16, patch_size=144, local_arch="mbconv_f32")
+    with torch.no_grad():
+        lg32, _, _ = m32.hot_path(fr.view(b * t, 3, 224, 224).to(dev), gvec.to(dev), torch.from_numpy(act).to(dev), b, t)
+    assert (lg32.cpu() - rl).abs().max().item() < TOL            # the same network in fp32 storage meets the fp32 bar
 
 
 # ------------------------------------------------------------------------------------ GRU scan
