@@ -47,11 +47,51 @@ class Args:
         self.__dict__.update(kw)
 
 
-def act_args(t, p, b):
-    return Args(num_segments=t, num_classes=200, reward="random", dataset="actnet", input_size=224, batch_size=b,
-                patch_size=p, with_glancer=True, feature_map_channels=1280, glance_size=224, action_dim=49,
-                hidden_state_dim=1024, policy_conv=True, gpu=0, continuous=False, gamma=0.7, policy_lr=0.0003,
-                random_patch=False, dropout=0.5, consensus="gru", hidden_dim=1024)
+def act_args(t, p, b, **over):
+    a = Args(num_segments=t, num_classes=200, reward="random", dataset="actnet", input_size=224, batch_size=b,
+             patch_size=p, with_glancer=True, feature_map_channels=1280, glance_size=224, action_dim=49,
+             hidden_state_dim=1024, policy_conv=True, gpu=0, continuous=False, gamma=0.7, policy_lr=0.0003,
+             random_patch=False, dropout=0.5, consensus="gru", hidden_dim=1024)
+    a.__dict__.update(over)
+    return a
+
+
+def config5_row(dev, b, streams, frames):
+    """BASELINE config 5's shape (T = 16, P = 144, MBConv local CNN, half-precision storage): the hot path with
+    adafocus_amd.mbconv_local as the local CNN, fp16 and fp32 storage side by side.  No reference implementation exists
+    (EfficientNet is a dead import there): parity unpinned, never the headline."""
+    from adafocus_amd import synth
+    from adafocus_amd.gfv_net import GFV
+    t, p = 16, 144
+    out = {}
+    _, act_np = synth.synth_actions(b * t, 7, seed=5)
+    actions = torch.from_numpy(act_np).to(dev)
+    gvec = torch.randn((b, t, 1280), device=dev)
+    ref = None
+    for arch in ("mbconv_f32", "mbconv_f16"):
+        model = GFV(act_args(t, p, b, local_arch=arch)).eval()
+        model.load_state_dict(synth_model_state(model, 1007), strict=True)
+        model = model.to(dev)
+        with torch.no_grad():
+            lg = model.hot_path(frames, gvec, actions, b, t)[0].clone()
+            for i in range(3):
+                model.hot_path(frames, gvec, actions, b, t)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(10):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    model.hot_path(frames, gvec, actions, b, t)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+        out[arch] = {"clips_per_s": round(10 * b / dt, 1), "ms_per_step": round(dt * 100, 3)}
+        if ref is None:
+            ref = lg
+        else:
+            out[arch]["rel_rms_logit_diff_vs_f32_storage"] = float(((lg - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+        del model
+    out["note"] = ("gather (P=144) + MobileNetV2-style MBConv local CNN over B*T patches + GRU classifier, B=%d, T=16; fp16 = activations "
+                   "and 1x1 weights stored as fp16, fp32 accumulate; parity unpinned (no reference implementation of this config)" % b)
+    return out
 
 
 def synth_model_state(model, seed):
@@ -438,6 +478,11 @@ def main():
                 "clips_per_s": round(10 * b / dt, 1),
                 "max_abs_logit_diff_vs_f32": float((alt_logits - ref_logits).abs().max().item()),
                 "note": "ADAF_MATH_F32_SPLIT_BF16: fp32 operands as three exact bf16 parts, 6 products, fp32 accumulate"}
+        if world == 1 and not a.skip_extras and (t, p) == (16, 96):
+            try:
+                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = config5_row(dev, b, streams, frames)
+            except Exception as exc:  # never fail the bench on an `also` row
+                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.skip_extras:
             # ---- rows f1/f2 of the scope table, measured the same way (inputs resident, HIP events): uint8 ingest,
             # glancer, policy, and the whole forward from the loader's uint8 clips
