@@ -88,6 +88,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
         const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nn) : one4;
         const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nn) : zero4;
         const bool has_res = a.res != nullptr;
+        // Identity rows travel one group of four rows-per-lane ahead of their use: the loads of group g+1 are issued before
+        // group g is finished, and group 0's before the first transposition, so no epilogue step waits on HBM / L2 with
+        // nothing else to do.  Launches without a residual (most) issue no load at all.
+        constexpr int GPB = (32 / RPI) / 4;      // groups per 32-row band
+        constexpr int NGR = TM * GPB;
+        f32x4 rv[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rv[q][u] = zero4;
+        auto ldres = [&](int g, int buf) {
+            const int i = g / GPB, it = (g % GPB) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + wm * WM + i * 32 + (it + u) * RPI + rsub;
+                const bool ok = n_ok && m < a.M;
+                if (R16) {
+                    const f16x4 hv = *reinterpret_cast<const f16x4*>(ok ? reinterpret_cast<const _Float16*>(a.res) + (size_t)m * a.ldr + n
+                                                                        : reinterpret_cast<const _Float16*>(a.zeros));
+                    rv[buf][u] = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+                } else
+                    rv[buf][u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+            }
+        };
+        if (has_res) ldres(0, 0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {   // one 32-row band at a time
             __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order; just pin the order
@@ -98,29 +123,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
                     st[(crow + (r & 3) + 8 * (r >> 2)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 32 / RPI; it += 4) {
-                f32x4 rv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int m = m0 + wm * WM + i * 32 + (it + u) * RPI + rsub;
-                    const bool ok = n_ok && m < a.M && has_res;
-                    if (R16) {
-                        const f16x4 hv = *reinterpret_cast<const f16x4*>(ok ? reinterpret_cast<const _Float16*>(a.res) + (size_t)m * a.ldr + n
-                                                                            : reinterpret_cast<const _Float16*>(a.zeros));
-                        rv[u] = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
-                    } else
-                        rv[u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
-                }
+            for (int gi = 0; gi < GPB; ++gi) {
+                const int g = i * GPB + gi, it = gi * 4, cb = g & 1;
+                if (has_res && g + 1 < NGR) ldres(g + 1, cb ^ 1);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int row = (it + u) * RPI + rsub;
                     const int m = m0 + wm * WM + i * 32 + row;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
                     f32x4 o;
-                    o.x = finish_act(fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, act_lo), act_hi), sig);
-                    o.y = finish_act(fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, act_lo), act_hi), sig);
-                    o.z = finish_act(fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, act_lo), act_hi), sig);
-                    o.w = finish_act(fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, act_lo), act_hi), sig);
+                    o.x = finish_act(fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[cb][u].x, act_lo), act_hi), sig);
+                    o.y = finish_act(fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[cb][u].y, act_lo), act_hi), sig);
+                    o.z = finish_act(fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[cb][u].z, act_lo), act_hi), sig);
+                    o.w = finish_act(fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[cb][u].w, act_lo), act_hi), sig);
                     if (n_ok && m < a.M) {
                         if (O16)
                             *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.ldo + n) =
