@@ -7,6 +7,7 @@
 // processed in chunks so the 6x-expanded intermediates stay within a bounded workspace.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -38,6 +39,12 @@ struct adaf_mobilenetv2 {
     bool fuse = true;       // expand -> depthwise in one kernel where the shape allows (mbconv.hip)
     int dtype = ADAF_DTYPE_F32;   // storage type of activations and 1x1 weights
     bool finalized = false;
+    // Two frame chunks travel through the network side by side (the second on this library-owned stream, forked from and
+    // joined to the caller's stream by events -- still fully asynchronous): the tail's launches are 30-100 us each and
+    // leave the device half empty on their own; a neighbour fills the ramps and tails.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool pair = true;
 };
 
 namespace {
@@ -103,9 +110,13 @@ void slab_sizes(const adaf_mobilenetv2* net, int size, size_t* io, size_t* ex, s
     if ((size_t)hw * hw * 32 > *ex) *ex = (size_t)hw * hw * 32;
 }
 
-const int kChunk = 512;   // frames per pass through the network
+int chunk_size() {   // frames per pass through the network (ADAF_MBV2_CHUNK overrides, for tuning)
+    static int c = [] { const char* e = getenv("ADAF_MBV2_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    return c;
+}
 
 int chunk_frames(int n, int tsm_segments) {
+    const int kChunk = chunk_size();
     int c = n < kChunk ? n : kChunk;
     if (tsm_segments > 0) {
         c -= c % tsm_segments;
@@ -161,6 +172,9 @@ int adaf_mobilenetv2_create(adaf_handle* h, adaf_mobilenetv2** out) {
 
 int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
     if (!net) return ADAF_OK;
+    if (net->aux) (void)hipStreamDestroy(net->aux);
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
         if (L.w16) (void)hipFree(L.w16);
@@ -173,7 +187,8 @@ int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
 
 int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on) {
     if (!net) return ADAF_E_BADARG;
-    net->fuse = on != 0;
+    net->fuse = (on & 1) != 0;
+    net->pair = (on & 4) == 0;     // bit 2 set: one frame chunk at a time (A/B)
     return ADAF_OK;
 }
 
@@ -236,7 +251,8 @@ size_t adaf_mobilenetv2_workspace_bytes(const adaf_mobilenetv2* net, int n, int 
     if (!net || n <= 0 || size <= 0) return 0;
     size_t io, ex, dw;
     slab_sizes(net, size, &io, &ex, &dw);
-    return (size_t)chunk_frames(n, tsm_segments) * (2 * io + ex + dw) * sizeof(float);
+    const int chunk = chunk_frames(n, tsm_segments);
+    return (size_t)chunk * (2 * io + ex + dw) * sizeof(float) * (n > chunk ? 2 : 1);     // two chunks in flight
 }
 
 int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, int n, int size, int tsm_segments,
@@ -298,9 +314,8 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
         return e16 == hipSuccess ? ADAF_OK : mfail(h, ADAF_E_LAUNCH, "mobilenetv2 forward (fp16): %s", hipGetErrorString(e16));
     }
 
-    int fh = 0;
-    for (int f0 = 0; f0 < n; f0 += chunk) {
-        const int nc = (n - f0) < chunk ? (n - f0) : chunk;
+    // one chunk of frames through the whole network on stream `st` with its own quarter of the workspace
+    auto run_chunk = [&](int f0, int nc, float* bufA, float* bufB, float* bufE, float* bufD, hipStream_t st) -> int {
         int hw = cdiv_out(size, 3, 2, 1);
         int rc;
         float* cur = bufA;
@@ -363,13 +378,38 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
             float* t = cur; cur = nxt; nxt = t;
             hw = ohw;
         }
-        fh = hw;
         float* fm = featmap + (size_t)f0 * hw * hw * 1280;
         if ((rc = run_conv(net, net->convs[net->head], cur, nc, hw, hw, ADAF_ACT_RELU6, nullptr, fm, 0, 0, st)))
             return mfail(h, rc, "mobilenetv2: head launch");
         if (featvec) adaf_launch_avgpool(fm, nc, hw * hw, 1280, featvec + (size_t)f0 * ldvec, ldvec, st);
+        return ADAF_OK;
+    };
+    const size_t per_chunk = (size_t)chunk * (2 * io + ex + dws);
+    const bool pair = net->pair && n > chunk;
+    if (pair && !net->aux) {
+        if (hipStreamCreateWithFlags(&net->aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess)
+            return mfail(h, ADAF_E_NOMEM, "mobilenetv2: could not create the second-chunk stream");
     }
-    (void)fh;
+    float* base2 = static_cast<float*>(ws) + per_chunk;
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int nc = (n - f0) < chunk ? (n - f0) : chunk;
+        int rc;
+        if (pair && f0 + chunk < n) {
+            const int f1 = f0 + chunk;
+            const int nc1 = (n - f1) < chunk ? (n - f1) : chunk;
+            (void)hipEventRecord(net->ev_fork, st);
+            (void)hipStreamWaitEvent(net->aux, net->ev_fork, 0);
+            if ((rc = run_chunk(f0, nc, bufA, bufB, bufE, bufD, st))) return rc;
+            if ((rc = run_chunk(f1, nc1, base2, base2 + (size_t)chunk * io, base2 + (size_t)chunk * 2 * io,
+                                base2 + (size_t)chunk * (2 * io + ex), net->aux)))
+                return rc;
+            (void)hipEventRecord(net->ev_join, net->aux);
+            (void)hipStreamWaitEvent(st, net->ev_join, 0);
+            f0 = f1;
+        } else if ((rc = run_chunk(f0, nc, bufA, bufB, bufE, bufD, st))) return rc;
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : mfail(h, ADAF_E_LAUNCH, "mobilenetv2 forward: %s", hipGetErrorString(e));
 }

@@ -249,7 +249,7 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the CPU baseline leg")
     ap.add_argument("--cpu-clips", type=int, default=None, help="(deprecated) 0 = skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--profile-steps", type=int, default=2, help="extra per-launch HIP-event passes for the roofline")
+    ap.add_argument("--profile-steps", type=int, default=3, help="per-launch HIP-event passes for the roofline (median per launch)")
     ap.add_argument("--sustained-steps", type=int, default=240, help="extra soak after the timed region (>= 3 s); 0 = skip")
     ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy + hot path)")
     ap.add_argument("--math", choices=["f32", "split_bf16"], default="f32",
@@ -394,20 +394,21 @@ def main():
         nconv = 0
         from adafocus_amd.utils import get_patch_nhwc4
         x4 = get_patch_nhwc4(frames, actions, p)
-        per_launch = None
-        for _ in range(max(a.profile_steps, 1)):
-            prof = trunk.profile(x4)
-            per_launch = prof
-            for e in prof:
-                tot_ms += e["ms"]
-                if e["flops"] > 0:
-                    conv_ms += e["ms"]
-                    conv_fl += e["flops"]
-                    nconv += 1
+        trunk.profile(x4)                                # untimed: the first bracketed pass pays for event creation
+        nps = max(a.profile_steps, 1)
+        runs = [trunk.profile(x4) for _ in range(nps)]
+        per_launch = []
+        for i, e in enumerate(runs[0]):                  # per launch: the median over the passes
+            ms = statistics.median(r[i]["ms"] for r in runs)
+            per_launch.append(dict(e, ms=ms))
+            tot_ms += ms * nps
+            if e["flops"] > 0:
+                conv_ms += ms * nps
+                conv_fl += e["flops"] * nps
+                nconv += nps
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # the same launches back to back (two events around three whole trunk passes): what the event brackets of the
         # per-launch pass add between kernels is not kernel time
-        nps = max(a.profile_steps, 1)
         with torch.no_grad():
             trunk.forward(x4)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -18,16 +18,19 @@ def main():
     title = sys.argv[3] if len(sys.argv) > 3 else d
     lines = ["# %s" % title, ""]
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
-        agg = collections.defaultdict(lambda: [0, 0.0])
+        agg = collections.defaultdict(lambda: [0, 0.0, []])
         for r in csv.DictReader(open(f)):
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             a = agg[short(r["Kernel_Name"])]
             a[0] += 1
             a[1] += dur
+            a[2].append(dur)
         tot = sum(v[1] for v in agg.values())
-        lines += ["## kernel trace: %s" % os.path.basename(f), "", "| kernel | calls | total us | avg us | % |", "|---|---|---|---|---|"]
-        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-            lines.append("| `%s` | %d | %.1f | %.2f | %.1f |" % (k, n, t, t / n, 100 * t / tot))
+        lines += ["## kernel trace: %s" % os.path.basename(f), "",
+                  "| kernel | calls | total us | avg us | median us | % |", "|---|---|---|---|---|---|"]
+        for k, (n, t, ds) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            ds.sort()
+            lines.append("| `%s` | %d | %.1f | %.2f | %.2f | %.1f |" % (k, n, t, t / n, ds[len(ds) // 2], 100 * t / tot))
         lines.append("")
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
