@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the steps are round-robined over (batch i+1's "
                     "trunk overlaps batch i's latency-bound GRU scan); 1 = strictly serial steps")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in for the step: tests the launcher and the protocol")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks run the real step on GPU 0 and gather over gloo (RCCL refuses "
+                    "two ranks on one device): exercises the N > 1 path on a single-GPU box; not a scaling measurement")
     a = ap.parse_args()
     if a.cpu_clips is not None and a.cpu_clips <= 0:
         a.cpu_baseline = 0
@@ -278,13 +280,15 @@ def main():
     if dry:
         dev = torch.device("cpu")
     else:
+        if a.share_gpu:
+            local = 0
         torch.cuda.set_device(local)              # rank i <-> GPU i of this node
         dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
+        if dry or a.share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -375,8 +379,8 @@ def main():
                                % (t, p, b, b * t),
                    "global_batch": b * world, "frames": t, "patch": p, "parallelism": "dp%d" % world,
                    "streams": len(streams)},
-        "ranks": world, "backend": ("gloo" if dry else "nccl (RCCL)") if world > 1 else None,
-        "rccl_ranks": (dist.get_world_size() if (world > 1 and not dry) else (1 if not dry else 0)),
+        "ranks": world, "backend": ("gloo" if dry else "gloo (all ranks share GPU 0)" if a.share_gpu else "nccl (RCCL)") if world > 1 else None,
+        "rccl_ranks": (dist.get_world_size() if (world > 1 and not dry and not a.share_gpu) else (1 if not dry and world == 1 else 0)),
         "per_rank_clips_per_s": [round(b * a.steps / s, 1) for s in per_rank_s],
         "gflop_per_clip": round(workload.hot_path_flops_per_clip(t, p) / 1e9, 2),
     }

@@ -34,3 +34,21 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_one_gpu():
+    """`python bench.py --gpus 2 --share-gpu` from a bare shell: the launcher spawns two ranks, both run the REAL hot path on
+    GPU 0 (their persistent GRU scans and trunks co-run on one device) and all-gather their logits (over gloo: RCCL refuses
+    two ranks on one device).  Proves the N > 1 code path on hardware; the throughput is not a scaling figure."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "6", "--warmup", "2",
+                          "--batch", "16", "--skip-extras", "--sustained-steps", "0", "--profile-steps", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["config"]["global_batch"] == 32
+    assert len(r["per_rank_clips_per_s"]) == 2 and min(r["per_rank_clips_per_s"]) > 0
+    assert r["value"] > 0 and "roofline" in r
