@@ -11,6 +11,7 @@ struct adaf_handle {
     int device = 0;
     int cus = 256;
     float* zeros = nullptr;  // device, 256 bytes of zeros
+    int conv_pos_major = 1;  // k x k convs may use position-major tiles with padding-tap skipping (conv_gemm.hip PM kernels)
     int gru_persistent = 1;  // GRU scans as one persistent kernel where the shape allows (gru_scan.hip): 0 off, 1 on, 2 on + cooperative launch
     // At most scan_slots persistent scans may execute at once (their grid barriers need every block resident; how many
     // fit is ASKED of the runtime at adaf_create: scan_resident = blocks per CU x CUs): launch i waits for the
@@ -40,6 +41,8 @@ struct ConvArgs {
     const float* zeros;  // >= 64 bytes of zeros (handle-owned): target of predicated-off loads
     int vec_epi;         // 1: 16-byte epilogue is legal (aligned out/res/scale/bias, strides % 4 == 0)
     int in16, out16, res16;   // half-precision STORAGE (N2): x and w / out / res hold fp16 (strides stay in elements)
+    int pm_allow;        // k x k convs: position-major tiles with padding-tap skipping may be used (bit-identical; default 1)
+    int pm_images, pm_groups;   // set by the launcher: images in the batch, image groups of BM per pixel position
     int tiles_n;         // ceil(N / BN) for the chosen tile
     int nblocks;
 };

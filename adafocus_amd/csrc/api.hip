@@ -54,6 +54,7 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
     }
     a->wsp = nullptr;
     a->in16 = a->out16 = a->res16 = 0;
+    a->pm_allow = h->conv_pos_major; a->pm_images = a->pm_groups = 0;
     a->x = x; a->w = w; a->scale = scale; a->bias = bias; a->res = res; a->out = out;
     a->M = (int)M; a->N = p->cout; a->K = p->kh * p->kw * p->cin;
     a->cin = p->cin; a->H = p->h; a->W = p->w; a->OH = oh; a->OW = ow; a->KH = p->kh; a->KW = p->kw;
@@ -116,6 +117,11 @@ int adaf_destroy(adaf_handle* h) {
 
 const char* adaf_last_error(const adaf_handle* h) { return h ? h->err.c_str() : "null handle"; }
 int adaf_device_cus(const adaf_handle* h) { return h ? h->cus : 0; }
+int adaf_set_conv_pos_major(adaf_handle* h, int on) {
+    if (!h) return ADAF_E_BADARG;
+    h->conv_pos_major = on ? 1 : 0;
+    return ADAF_OK;
+}
 int adaf_set_gru_persistent(adaf_handle* h, int on) {
     if (!h) return ADAF_E_BADARG;
     if (on < 0 || on > 2) return fail(h, ADAF_E_BADARG, "set_gru_persistent: mode %d (0 off, 1 on, 2 on + cooperative launch)", on);

@@ -65,10 +65,14 @@ __device__ __forceinline__ float finish_act(float v, bool sig) { return sig ? 1.
 // ---- epilogue shared by both kernel families: BN affine, residual, activation ---------------
 // C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
 // ET (half-precision storage variants, N2): bit 0 = `out` holds fp16, bit 1 = `res` holds fp16; strides stay in ELEMENTS.
+// Row map: tile row `ml` (m0 + offset inside the tile) lives at output row ml * rstride + roff and exists iff ml < rlimit.
+// Default (1, 0, a.M): the tile's rows are consecutive output pixels.  Position-major tiles (PM kernels): ml = image index,
+// rstride = OH*OW, roff = the tile's pixel position, rlimit = number of images.
 template <int TM, int TN, int ET = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0,
-                                              int wm, int wn, int lane, int wave) {
+                                              int wm, int wn, int lane, int wave, int rstride = 1, int roff = 0, int rlimit = -1) {
     constexpr bool O16 = (ET & 1) != 0, R16 = (ET & 2) != 0;
+    if (rlimit < 0) rlimit = a.M;
     const bool sig = a.act == ADAF_ACT_SIGMOID;
     const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
@@ -102,14 +106,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
             const int i = g / GPB, it = (g % GPB) * 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int m = m0 + wm * WM + i * 32 + (it + u) * RPI + rsub;
-                const bool ok = n_ok && m < a.M;
+                const int ml = m0 + wm * WM + i * 32 + (it + u) * RPI + rsub;
+                const bool ok = n_ok && ml < rlimit;
+                const size_t m = (size_t)ml * rstride + roff;
                 if (R16) {
-                    const f16x4 hv = *reinterpret_cast<const f16x4*>(ok ? reinterpret_cast<const _Float16*>(a.res) + (size_t)m * a.ldr + n
+                    const f16x4 hv = *reinterpret_cast<const f16x4*>(ok ? reinterpret_cast<const _Float16*>(a.res) + m * a.ldr + n
                                                                         : reinterpret_cast<const _Float16*>(a.zeros));
                     rv[buf][u] = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
                 } else
-                    rv[buf][u] = *reinterpret_cast<const f32x4*>(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+                    rv[buf][u] = *reinterpret_cast<const f32x4*>(ok ? a.res + m * a.ldr + n : a.zeros);
             }
         };
         if (has_res) ldres(0, 0);
@@ -129,19 +134,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int row = (it + u) * RPI + rsub;
-                    const int m = m0 + wm * WM + i * 32 + row;
+                    const int ml = m0 + wm * WM + i * 32 + row;
+                    const size_t m = (size_t)ml * rstride + roff;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
                     f32x4 o;
                     o.x = finish_act(fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv[cb][u].x, act_lo), act_hi), sig);
                     o.y = finish_act(fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv[cb][u].y, act_lo), act_hi), sig);
                     o.z = finish_act(fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv[cb][u].z, act_lo), act_hi), sig);
                     o.w = finish_act(fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv[cb][u].w, act_lo), act_hi), sig);
-                    if (n_ok && m < a.M) {
+                    if (n_ok && ml < rlimit) {
                         if (O16)
-                            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.out) + (size_t)m * a.ldo + n) =
+                            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.out) + m * a.ldo + n) =
                                 f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
                         else
-                            *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = o;
+                            *reinterpret_cast<f32x4*>(a.out + m * a.ldo + n) = o;
                     }
                 }
             }
@@ -163,18 +169,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
             float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const bool ok = has_res && n_ok && m < a.M;
-                if (R16) rv[r] = ok ? (float)reinterpret_cast<const _Float16*>(a.res)[(size_t)m * a.ldr + n] : 0.f;
-                else rv[r] = *(ok ? a.res + (size_t)m * a.ldr + n : a.zeros);
+                const int ml = mb + (r & 3) + 8 * (r >> 2);
+                const size_t m = (size_t)ml * rstride + roff;
+                const bool ok = has_res && n_ok && ml < rlimit;
+                if (R16) rv[r] = ok ? (float)reinterpret_cast<const _Float16*>(a.res)[m * a.ldr + n] : 0.f;
+                else rv[r] = *(ok ? a.res + m * a.ldr + n : a.zeros);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const int ml = mb + (r & 3) + 8 * (r >> 2);
+                const size_t m = (size_t)ml * rstride + roff;
                 const float v = finish_act(fminf(fmaxf(fmaf(acc[i][j][r], sc, bi) + rv[r], act_lo), act_hi), sig);
-                if (n_ok && m < a.M) {
-                    if (O16) reinterpret_cast<_Float16*>(a.out)[(size_t)m * a.ldo + n] = (_Float16)v;
-                    else a.out[(size_t)m * a.ldo + n] = v;
+                if (n_ok && ml < rlimit) {
+                    if (O16) reinterpret_cast<_Float16*>(a.out)[m * a.ldo + n] = (_Float16)v;
+                    else a.out[m * a.ldo + n] = v;
                 }
             }
         }
@@ -384,8 +392,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // byte-identical and the loader simply counts in 32-bit words (the launcher halves K / cin / ldx); a lane's 16-byte
 // fragment is exactly the 8 halfs one v_mfma_f32_32x32x16_f16 wants (lanes 0-31: k 0..7, lanes 32-63: k 8..15 of a
 // 16-k step = chunk 2 kk + (lane >> 5), the f32 mapping).  Accumulation, BN and activation stay fp32.
-template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0>
+// PM (k x k filters, fp32 pipe): POSITION-MAJOR tiles with padding-tap skipping.  A tile's BM rows are the SAME output
+// pixel of BM consecutive images (instead of BM consecutive pixels), so every row has the same set of filter taps inside
+// the image and the taps that only multiply padding are skipped for the whole tile -- no DMA, no MFMA: on the 3x3 maps of
+// stage 4 the corner / edge / centre pixels use 4 / 6 / 9 of the 9 taps (5.4 on average: 40 % of the products of the
+// row-major form are zeros), on 6x6 maps 7.1, on 12x12 8.0.  A skipped slice contributes exact zeros, so the result is
+// BIT-IDENTICAL to the row-major kernel.  Tile t = (image group g = t / (OH*OW), pixel p = t % (OH*OW)).
+template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0, bool PM = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
+    static_assert(!PM || (!DENSE && EMU == 0 && !BSP && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe");
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int AI = BM / (8 * NW);                                   // DMA instructions per wave per slice
@@ -410,7 +425,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     }
     const int tile_m = bid / a.tiles_n;
     const int tile_n = bid - tile_m * a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    // position-major: this tile's pixel, its first image, and the taps inside the image (uniform over the tile)
+    int pm_p = 0, pm_iy0 = 0, pm_ix0 = 0;
+    unsigned pm_mask = 0;
+    if (PM) {
+        // group-major order: consecutive tiles (= one XCD's share, see the remap above) are all pixel positions of the SAME
+        // images, so the rows an XCD gathers stay within a few image groups and in its L2 (position-major order made
+        // every XCD touch every image: measured 3x less gain)
+        const int ohw = a.OH * a.OW;
+        const int g = tile_m / ohw;
+        pm_p = tile_m - g * ohw;
+        m0 = g * BM;                                       // first IMAGE of the tile
+        const int oy = pm_p / a.OW, ox = pm_p - oy * a.OW;
+        pm_iy0 = oy * a.stride - a.pad;
+        pm_ix0 = ox * a.stride - a.pad;
+        for (int kh = 0; kh < a.KH; ++kh)
+            for (int kw = 0; kw < a.KW; ++kw)
+                if ((unsigned)(pm_iy0 + kh) < (unsigned)a.H && (unsigned)(pm_ix0 + kw) < (unsigned)a.W) pm_mask |= 1u << (kh * a.KW + kw);
+    }
 
     // ---- per-lane source bookkeeping ------------------------------------------------------
     const int lr = lane >> 3;   // row within the 8-row group
@@ -435,6 +469,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                 const int t = (mm / a.tsm_hw) % a.tsm_T;
                 tflag[j] = (ok ? 4 : 0) | (t > 0 ? 1 : 0) | (t < a.tsm_T - 1 ? 2 : 0);
             }
+        } else if (PM) {
+            const int img = m0 + row;                       // rows = images
+            const bool iok = img < a.pm_images;
+            boff[j] = ((long long)(iok ? img : 0) * a.H * a.W + (long long)pm_iy0 * a.W + pm_ix0) * a.ldx + qa[j];
+            amask[j] = iok ? pm_mask : 0u;
         } else {
             const int ohw = a.OH * a.OW;
             const int img = mm / ohw;
@@ -484,6 +523,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     // per-slice wave-uniform state of the NEXT slice's DMA (set by prep)
     bool nx_tsm = false, nx_tail = false;
     int nx_kt = 0, nx_tap = 0, nx_c0 = 0, nx_kh = 0, nx_kw = 0;
+    int nx_koff = 0;            // PM: offset of the slice inside a filter row (taps are skipped, so it is not 32 * kt)
     long long nx_toff = 0;
     auto prep = [&](int kt) {
         nx_kt = kt;
@@ -493,16 +533,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         } else {
             // one filter tap per slice (cin % 32 == 0); prep() is called for kt = 0, 1, 2, ... so the
             // (tap, channel offset) pair is advanced incrementally -- scalar adds, no division
-            if (kt == 0) { nx_c0 = 0; nx_tap = 0; nx_kh = 0; nx_kw = 0; }
+            bool moved = false;
+            if (kt == 0) { nx_c0 = 0; nx_tap = 0; nx_kh = 0; nx_kw = 0; moved = true; }
             else {
                 nx_c0 += 32;
                 if (nx_c0 == a.cin) {
                     nx_c0 = 0;
                     ++nx_tap;
                     if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
+                    moved = true;
+                }
+            }
+            if (PM && moved) {   // on to the next tap that touches the image (wave-uniform; the centre tap always does)
+                while (!((pm_mask >> nx_tap) & 1u)) {
+                    ++nx_tap;
+                    if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
                 }
             }
             nx_toff = ((long long)nx_kh * a.W + nx_kw) * a.ldx + nx_c0;
+            if (PM) nx_koff = nx_tap * a.cin + nx_c0;
         }
     };
     // one DMA instruction: q < BI -> weight rows, else activation rows
@@ -511,8 +560,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
             float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;   // 8 rows x 128 B = 16 rows x 64 B = 256 floats per instruction
             const float* srcb = pb[q];
             if (!BSP && SPECIAL && nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
+            if (PM) {
+                if (step_b[q]) srcb += nx_koff;         // (rows past N point at the zero block and stay there)
+            } else
+                pb[q] += step_b[q];
             __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
-            pb[q] += step_b[q];
             return;
         }
         const int j = q - BI;
@@ -561,7 +613,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
 #pragma unroll
     for (int j = 0; j < 2; ++j) foffb[j] = (lane & 31) * 16 + ((((2 * j + (lane >> 5)) ^ ((lane >> 2) & 3)) & 3) << 2);
 
-    const int nk = (a.K + 31) / 32;
+    const int nk = PM ? __builtin_popcount(pm_mask) * (a.cin >> 5) : (a.K + 31) / 32;
     prep(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_one(q, 0);
@@ -818,7 +870,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
     slice(nk - 1, std::false_type{});
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
-    conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+    if (PM) conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave, a.OH * a.OW, pm_p, a.pm_images);
+    else conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
 
 // =============================================================================================
@@ -1248,10 +1301,38 @@ void launch_glds16_dt(const ConvArgs& a, bool dense, hipStream_t s) {
     else launch_glds16<BM, BN, WGM, WGN, 4 | 2>(a, dense, s);
 }
 
+// Share of the filter taps that touch the image, averaged over the output pixels (1 = no padding work to skip).
+static double conv_tap_fill(const ConvArgs& a) {
+    long long in = 0;
+    for (int oy = 0; oy < a.OH; ++oy)
+        for (int ox = 0; ox < a.OW; ++ox)
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int iy = oy * a.stride - a.pad + kh, ix = ox * a.stride - a.pad + kw;
+                    in += (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                }
+    return (double)in / ((double)a.OH * a.OW * a.KH * a.KW);
+}
+
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
+        // position-major tiles with padding-tap skipping: when enough images share a pixel position to fill the tile
+        // rows and at least ~7 % of the products are padding
+        const int ohw = a.OH * a.OW;
+        const int images = ohw > 0 ? a.M / ohw : 0;
+        if (!dense && a.pm_allow && a.KH * a.KW > 1 && a.KH * a.KW <= 32 && images * ohw == a.M && images >= BM && ohw <= 4096 &&
+            conv_tap_fill(a) < 0.93) {
+            a.pm_images = images;
+            a.pm_groups = (images + BM - 1) / BM;
+            a.nblocks = ohw * a.pm_groups * a.tiles_n;
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 0, false, 0, true>), dim3(a.nblocks),
+                               dim3(64 * WGM * WGN), 0, s, a);
+            return;
+        }
+    }
     const bool special = a.tsm_T > 0 || (a.K & 31);
     if (dense && special)
         hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true, EMU, BSP>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);

@@ -62,6 +62,10 @@ int adaf_device_cus(const adaf_handle* h);
  *   mode 2 = persistent kernel launched with hipLaunchCooperativeKernel (the runtime itself guarantees co-residency).
  * All forms are deterministic; they differ in summation order. */
 int adaf_set_gru_persistent(adaf_handle* h, int mode);
+/* k x k convolutions on small maps: tiles of the SAME output pixel over consecutive images, so the filter taps that only
+ * multiply zero padding are skipped for the whole tile (40 % of the products of a 3x3 conv on a 3x3 map, 21 % on 6x6).
+ * Bit-identical to the row-major tiles (a skipped slice contributes exact zeros).  Default on; off for A/B and tests. */
+int adaf_set_conv_pos_major(adaf_handle* h, int on);
 
 /* ---- a1: patch gather -------------------------------------------------------------------
  * Replaces get_patch(images, action_sequence, patch_size) -- ACT/models/utils.py:37-51

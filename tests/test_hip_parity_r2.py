@@ -383,6 +383,34 @@ def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
     assert abs(sum(e["flops"] for e in prof) - sum(e["flops"] for e in prof_ref)) < 1e-6 * sum(e["flops"] for e in prof_ref)
 
 
+def test_conv_position_major_tap_skipping_bit_identical(dev, ops):
+    """k x k convs on small maps run position-major tiles that skip the filter taps lying wholly in the padding
+    (adaf_set_conv_pos_major): bit-identical to the row-major tiles, for every tile shape, strides 1 / 2, maps from 1x1 to
+    12x12, image counts that fill, overfill and underfill a tile group, with and without a residual."""
+    gen = np.random.Generator(np.random.PCG64([61, 7]))
+    cases = [(256, 3, 3, 64, 64, 3, 1, 1), (130, 6, 6, 32, 96, 3, 1, 1), (128, 6, 6, 64, 32, 3, 2, 1), (64, 3, 3, 128, 64, 3, 1, 1),
+             (200, 1, 1, 32, 64, 3, 1, 1), (129, 12, 12, 32, 64, 3, 1, 1), (70, 5, 7, 32, 64, 3, 2, 1), (256, 2, 2, 64, 128, 5, 1, 2)]
+    try:
+        for n, hh, ww, cin, cout, k, stride, pad in cases:
+            x = torch.from_numpy(gen.standard_normal((n, hh, ww, cin), dtype=np.float32)).to(dev)
+            w = ops.pack_conv_weight(torch.from_numpy(gen.standard_normal((cout, cin, k, k), dtype=np.float32) * np.float32(0.05)).to(dev))
+            sc = torch.from_numpy(gen.random(cout, dtype=np.float32) + np.float32(0.5)).to(dev)
+            bi = torch.from_numpy(gen.standard_normal(cout, dtype=np.float32)).to(dev)
+            oh, ow = (hh + 2 * pad - k) // stride + 1, (ww + 2 * pad - k) // stride + 1
+            res = torch.from_numpy(gen.standard_normal((n, oh, ow, cout), dtype=np.float32)).to(dev)
+            for tile in (0, 31, 32, 33, 34):
+                for r in (None, res):
+                    ops.set_conv_pos_major(False, dev)
+                    ref = ops.conv2d_bn_act(x, w, sc, bi, r, stride=stride, pad=pad, act=ops.ACT_RELU, tile=tile).clone()
+                    ops.set_conv_pos_major(True, dev)
+                    got = ops.conv2d_bn_act(x, w, sc, bi, r, stride=stride, pad=pad, act=ops.ACT_RELU, tile=tile)
+                    assert torch.equal(got, ref), (n, hh, ww, cin, cout, k, stride, tile, r is not None)
+            naive = ops.conv2d_bn_act(x, w, sc, bi, res, stride=stride, pad=pad, act=ops.ACT_RELU, naive=True)
+            assert (got - naive).abs().max().item() < 2e-4
+    finally:
+        ops.set_conv_pos_major(True, dev)
+
+
 # ------------------------------------------------------------------------------------ N2: half-precision storage
 @pytest.mark.parametrize("tile", [0, 81, 82, 83, 84, 88])
 def test_conv_f16_operands_vs_fp32_reference(dev, ops, tile):
