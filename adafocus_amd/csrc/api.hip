@@ -119,7 +119,7 @@ const char* adaf_last_error(const adaf_handle* h) { return h ? h->err.c_str() : 
 int adaf_device_cus(const adaf_handle* h) { return h ? h->cus : 0; }
 int adaf_set_conv_pos_major(adaf_handle* h, int on) {
     if (!h) return ADAF_E_BADARG;
-    h->conv_pos_major = on ? 1 : 0;
+    h->conv_pos_major = on < 0 || on > 2 ? 1 : on;    // 2: position-major rows WITHOUT tap skipping (experiments)
     return ADAF_OK;
 }
 int adaf_set_gru_persistent(adaf_handle* h, int on) {

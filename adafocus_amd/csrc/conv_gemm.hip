@@ -445,6 +445,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
             for (int kw = 0; kw < a.KW; ++kw)
                 if ((unsigned)(pm_iy0 + kh) < (unsigned)a.H && (unsigned)(pm_ix0 + kw) < (unsigned)a.W) pm_mask |= 1u << (kh * a.KW + kw);
     }
+    // taps the K walk visits: the ones inside the image (pm_allow == 2, experiments: all of them, to separate the cost of
+    // the position-major row order from the gain of the skipping)
+    const unsigned pm_walk = (PM && a.pm_allow == 2) ? ((1u << (a.KH * a.KW)) - 1u) : pm_mask;
 
     // ---- per-lane source bookkeeping ------------------------------------------------------
     const int lr = lane >> 3;   // row within the 8-row group
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
                 }
             }
             if (PM && moved) {   // on to the next tap that touches the image (wave-uniform; the centre tap always does)
-                while (!((pm_mask >> nx_tap) & 1u)) {
+                while (!((pm_walk >> nx_tap) & 1u)) {
                     ++nx_tap;
                     if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
                 }
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
 #pragma unroll
     for (int j = 0; j < 2; ++j) foffb[j] = (lane & 31) * 16 + ((((2 * j + (lane >> 5)) ^ ((lane >> 2) & 3)) & 3) << 2);
 
-    const int nk = PM ? __builtin_popcount(pm_mask) * (a.cin >> 5) : (a.K + 31) / 32;
+    const int nk = PM ? __builtin_popcount(pm_walk) * (a.cin >> 5) : (a.K + 31) / 32;
     prep(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_one(q, 0);

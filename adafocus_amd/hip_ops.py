@@ -313,7 +313,7 @@ def set_conv_pos_major(on, device=None):
     """k x k convs: position-major tiles with padding-tap skipping on / off (bit-identical; include/adafocus.h)."""
     dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
     h = L.handle(dev)
-    L.check(L.load_library().adaf_set_conv_pos_major(h, 1 if on else 0), h)
+    L.check(L.load_library().adaf_set_conv_pos_major(h, int(on)), h)
 
 
 def pack_dw_weight(w_c133):

@@ -25,6 +25,9 @@ for _ in range(3):
     trunk.forward(x, tsm_segments=tsm) if tsm else trunk.forward(x)
 runs = [trunk.profile(x, tsm_segments=tsm) for _ in range(5)]
 fuse = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+if len(sys.argv) > 5:      # 0 = row-major tiles, 1 = position-major with tap skipping (default), 2 = position-major without skipping
+    from adafocus_amd import hip_ops
+    hip_ops.set_conv_pos_major(int(sys.argv[5]), dev)
 trunk.set_fusion(fuse)
 for _ in range(2):
     trunk.forward(x, tsm_segments=tsm) if tsm else trunk.forward(x)
