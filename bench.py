@@ -102,10 +102,10 @@ def synth_model_state(model, seed):
 
 
 def load_traffic(t, p, b):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r1_traffic.json);
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r2_traffic.json, tools/profile_bench.sh);
     only reported when it was collected on this very workload."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
         w = d["workload"]
         if (w["frames"], w["patch"], w["batch"]) == (t, p, b):
             return d["hbm_bytes_per_launch"]
@@ -484,11 +484,6 @@ def main():
                 "clips_per_s": round(10 * b / dt, 1),
                 "max_abs_logit_diff_vs_f32": float((alt_logits - ref_logits).abs().max().item()),
                 "note": "ADAF_MATH_F32_SPLIT_BF16: fp32 operands as three exact bf16 parts, 6 products, fp32 accumulate"}
-        if world == 1 and not a.skip_extras and (t, p) == (16, 96):
-            try:
-                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = config5_row(dev, b, streams, frames)
-            except Exception as exc:  # never fail the bench on an `also` row
-                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.skip_extras:
             # ---- rows f1/f2 of the scope table, measured the same way (inputs resident, HIP events): uint8 ingest,
             # glancer, policy, and the whole forward from the loader's uint8 clips
@@ -496,7 +491,7 @@ def main():
                 from adafocus_amd.transforms import ingest_uint8
 
                 def timed(fn, iters=5):
-                    for _ in range(2):
+                    for _ in range(3):
                         fn()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -549,6 +544,11 @@ def main():
                 del u8, u8s, fr4, fmap, fvec
             except Exception as exc:  # upstream of the timed path; never fail the bench on it
                 res["next_rows"] = {"error": repr(exc)[:300]}
+        if world == 1 and not a.skip_extras and (t, p) == (16, 96):
+            try:
+                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = config5_row(dev, b, streams, frames)
+            except Exception as exc:  # never fail the bench on an `also` row
+                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = {"error": repr(exc)[:300]}
         if os.environ.get("ADAF_BENCH_LAUNCHES"):
             res["launches"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()} for e in per_launch]
         if a.full and not a.skip_extras:
