@@ -417,7 +417,8 @@ class MobileNetV2Net:
 
     def set_fusion(self, on):
         """Expand 1x1 -> depthwise 3x3 in one kernel for the high-resolution blocks (default on)."""
-        L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, 1 if on else 0), self._h)
+        # bit 0: fused kernels on; bit 2: one frame chunk at a time; bit 3: no fused depthwise -> project tail (A/B switches)
+        L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, int(on)), self._h)
 
     def set_dtype(self, dtype):
         """"f32" (default) or "f16": activations and 1x1 weights stored as fp16, fp32 accumulate (include/adafocus.h N2).
