@@ -417,7 +417,7 @@ class MobileNetV2Net:
 
     def set_fusion(self, on):
         """Expand 1x1 -> depthwise 3x3 in one kernel for the high-resolution blocks (default on)."""
-        # bit 0: fused kernels on; bit 2: one frame chunk at a time; bit 3: no fused depthwise -> project tail (A/B switches)
+        # bit 0: fused kernels on; bit 2 (value 4): one frame chunk at a time instead of two side by side (A/B switch)
         L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, int(on)), self._h)
 
     def set_dtype(self, dtype):

@@ -120,6 +120,27 @@ def test_crop_resize_randomised_vs_oracle(dev, ops, O):
         ops.crop_resize(fr, act, 32, size=0)
 
 
+def test_crop_resize_full_size_properties(dev, ops):
+    """BASELINE's full size (1024 frames of 224^2): (i) window size == patch size is the gather, bit for bit, through the
+    resampling kernel; (ii) a resample of a per-frame constant image is that constant (the four weights sum to 1);
+    (iii) resampling commutes with a per-frame affine map of the pixel values (linearity), to fp32 rounding."""
+    n, p = 1024, 96
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    fr = torch.randn((n, 3, 224, 224), generator=gen).to(dev)
+    act = torch.rand((n, 2), generator=gen).to(dev)
+    same = torch.full((n,), p, dtype=torch.int32, device=dev)
+    assert torch.equal(ops.crop_resize(fr, act, p, size=same, layout=ops.LAYOUT_NHWC4), ops.crop_gather(fr, act, p, 1, ops.LAYOUT_NHWC4))
+    sizes = torch.randint(32, 225, (n,), generator=gen, dtype=torch.int32).to(dev)
+    consts = torch.randn((n, 1, 1, 1), generator=gen).to(dev)
+    flat = consts.expand(n, 3, 224, 224).contiguous()
+    out = ops.crop_resize(flat, act, p, size=sizes)
+    assert (out - consts).abs().max().item() <= 1e-6 * max(1.0, float(consts.abs().max()))
+    base = ops.crop_resize(fr, act, p, size=sizes)
+    a_, b_ = 1.75, -0.5
+    lin = ops.crop_resize(fr * a_ + b_, act, p, size=sizes)
+    assert (lin - (base * a_ + b_)).abs().max().item() < 2e-5
+
+
 def test_resize_nearest_golden(dev, ops):
     g = golden("g10_resample")
     fr2 = rnd((2, 6, 224, 224), 102)

@@ -15,7 +15,7 @@ shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
 net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 3).items()})
 net = net.to(dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-if len(sys.argv) > 2:       # adaf_mobilenetv2_set_fusion bits: 1 fused kernels, 4 no chunk pairing, 8 no fused depthwise->project tail
+if len(sys.argv) > 2:       # adaf_mobilenetv2_set_fusion bits: 1 fused kernels, 4 no chunk pairing
     net._engine.fusion = int(sys.argv[2])
 x4 = torch.randn((n, 224, 224, 4), device=dev)
 x4[..., 3] = 0
