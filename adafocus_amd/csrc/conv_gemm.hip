@@ -1304,17 +1304,16 @@ void launch_glds16_dt(const ConvArgs& a, bool dense, hipStream_t s) {
     else launch_glds16<BM, BN, WGM, WGN, 4 | 2>(a, dense, s);
 }
 
-// Share of the filter taps that touch the image, averaged over the output pixels (1 = no padding work to skip).
+// Share of the filter taps that touch the image, averaged over the output pixels (1 = no padding work to skip).  The
+// tap mask of a pixel is the product of a row mask and a column mask, so the count factorises.
 static double conv_tap_fill(const ConvArgs& a) {
-    long long in = 0;
-    for (int oy = 0; oy < a.OH; ++oy)
-        for (int ox = 0; ox < a.OW; ++ox)
-            for (int kh = 0; kh < a.KH; ++kh)
-                for (int kw = 0; kw < a.KW; ++kw) {
-                    const int iy = oy * a.stride - a.pad + kh, ix = ox * a.stride - a.pad + kw;
-                    in += (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                }
-    return (double)in / ((double)a.OH * a.OW * a.KH * a.KW);
+    auto axis = [&](int out, int in, int k) {
+        long long c = 0;
+        for (int o = 0; o < out; ++o)
+            for (int t = 0; t < k; ++t) c += (unsigned)(o * a.stride - a.pad + t) < (unsigned)in;
+        return c;
+    };
+    return (double)(axis(a.OH, a.H, a.KH) * axis(a.OW, a.W, a.KW)) / ((double)a.OH * a.OW * a.KH * a.KW);
 }
 
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>

@@ -22,6 +22,7 @@ net = net.to(dev)
 x = torch.randn((n, p, p, 4), device=dev)
 x[..., 3] = 0
 trunk = net._sync()
+trunk.set_fusion(False)        # one launch per layer, so the launch lists of all runs line up
 nconv = 53
 
 
