@@ -15,6 +15,7 @@
 // one is multiplied.  A lane's ds_read_b128 brings four k-values for its row; MFMA sub-step s
 // consumes element s, so lanes 0-31 cover k = 8kk+s and lanes 32-63 cover k = 8kk+4+s -- the
 // same permutation on A and W, hence an exact (re-ordered) fp32 fma chain.
+#include <cstdlib>
 #include <type_traits>
 
 #include "adaf_internal.h"
@@ -77,6 +78,83 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f3
     const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
     const int crow = 4 * (lane >> 5);
+    if (ET == 0 && a.vec_epi == 2 && !sig) {
+        // ---- interior tiles (every row and column of the wave's sub-tile exists): the lean form.  fp32 MFMA and the VALU
+        // share lanes on gfx950, so for the short-K launches (K = 64..256: 1024..4096 MFMA passes per wave tile) the
+        // several hundred VALU passes of the general epilogue below -- 64-bit address arithmetic per row, the selects of the
+        // bounds handling, four ALU ops per element -- are time the matrix pipe does not get.  Here: scalar row bases the
+        // SALU advances + one constant 32-bit lane offset (global_load/store saddr form, no address VALU), no bounds
+        // selects, and v_pk_fma / v_pk_add / v_med3: 2 VALU per element instead of 4.  Same arithmetic, same results.
+        constexpr int WM = TM * 32, WN = TN * 32, SP = WN + 4;
+        constexpr int C4 = WN / 4, RPI = 64 / C4;
+        const int mrow0 = m0 + wm * WM, n0w = n0 + wn * WN;
+        const size_t span_o = (size_t)(RPI - 1) * rstride * a.ldo + a.N, span_r = (size_t)(RPI - 1) * rstride * a.ldr + a.N;
+        if (mrow0 + WM <= rlimit && n0w + WN <= a.N && span_o < (1u << 29) && span_r < (1u << 29)) {
+            float* st = smem + wave * 32 * SP;
+            const int c4 = lane % C4, rsub = lane / C4;
+            const int n = n0w + 4 * c4;
+            const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + n) : one4;
+            const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
+            const f32x2 sc0 = {sc.x, sc.y}, sc1 = {sc.z, sc.w}, bi0 = {bi.x, bi.y}, bi1 = {bi.z, bi.w};
+            const unsigned vo = (unsigned)(((size_t)rsub * rstride * a.ldo + n) * 4);
+            const unsigned vr = (unsigned)(((size_t)rsub * rstride * a.ldr + n) * 4);
+            auto uni = [](unsigned long long v) {       // wave-uniform by construction: pin to SGPRs
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+            };
+            const size_t row0 = (size_t)mrow0 * rstride + roff;
+            const unsigned long long obase = uni((unsigned long long)a.out + row0 * a.ldo * 4);
+            const unsigned long long rbase = uni((unsigned long long)a.res + row0 * a.ldr * 4);
+            const unsigned long long ostep = uni((unsigned long long)RPI * rstride * a.ldo * 4);
+            const unsigned long long rstep = uni((unsigned long long)RPI * rstride * a.ldr * 4);
+            constexpr int GPB = (32 / RPI) / 4, NGR = TM * GPB;     // groups of four row steps
+            typedef __attribute__((address_space(1))) char gchar;      // (global address space: plain pointers made from
+            typedef __attribute__((address_space(1))) f32x4 gf32x4;    //  integers would be FLAT accesses)
+            auto run = [&](auto res_tag) {
+                constexpr bool RES = decltype(res_tag)::value;
+                f32x4 rv[2][4];
+                auto ldres = [&](int g, int buf) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        rv[buf][u] = *reinterpret_cast<const gf32x4*>(reinterpret_cast<const gchar*>(rbase + (unsigned long long)(g * 4 + u) * rstep) + vr);
+                };
+                if (RES) ldres(0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            st[(crow + (r & 3) + 8 * (r >> 2)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int gi = 0; gi < GPB; ++gi) {
+                        const int g = i * GPB + gi, cb = g & 1;
+                        if (RES && g + 1 < NGR) ldres(g + 1, cb ^ 1);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int row = (gi * 4 + u) * RPI + rsub;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
+                            f32x2 p0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, sc0, bi0);
+                            f32x2 p1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, sc1, bi1);
+                            if (RES) {
+                                p0 += f32x2{rv[cb][u].x, rv[cb][u].y};
+                                p1 += f32x2{rv[cb][u].z, rv[cb][u].w};
+                            }
+                            const f32x4 o = {__builtin_amdgcn_fmed3f(p0.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(p0.y, act_lo, act_hi),
+                                             __builtin_amdgcn_fmed3f(p1.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(p1.y, act_lo, act_hi)};
+                            *reinterpret_cast<gf32x4*>(reinterpret_cast<gchar*>(obase + (unsigned long long)(g * 4 + u) * ostep) + vo) = o;
+                        }
+                    }
+                }
+            };
+            if (a.res != nullptr) run(std::true_type{});
+            else run(std::false_type{});
+            return;
+        }
+    }
     if (a.vec_epi) {
         // Transpose the wave's WM x WN tile through its private LDS slab (the K-loop buffers are
         // free after the final barrier) so every lane owns 4 consecutive channels of a row:
@@ -398,9 +476,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // stage 4 the corner / edge / centre pixels use 4 / 6 / 9 of the 9 taps (5.4 on average: 40 % of the products of the
 // row-major form are zeros), on 6x6 maps 7.1, on 12x12 8.0.  A skipped slice contributes exact zeros, so the result is
 // BIT-IDENTICAL to the row-major kernel.  Tile t = (image group g = t / (OH*OW), pixel p = t % (OH*OW)).
-template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0, bool PM = false>
+// LEAN (1x1/stride-1 launches without fix-ups, and position-major tiles): NO vector ALU work in the K loop.  On gfx950 the fp32
+// MFMA and the fp32/int VALU issue to the same lanes, so every v_add in the loop is a cycle the matrix pipe does not get
+// (DESIGN.md section 3.4).  The DMA is issued in its scalar-base form -- global_load_lds_dwordx4 voffset, s[base:base+1] --
+// with a per-lane 32-bit byte offset that never changes and a wave-uniform base the SALU advances per slice (the compiler
+// builtin only emits the 64-bit-VGPR-address form: one v_lshl_add_u64 per instruction per slice).  Rows past the end of the
+// problem read a valid row instead of the zero block (their outputs are discarded by the epilogue), so no select either.
+template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0, bool PM = false,
+          bool LEAN = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
     static_assert(!PM || (!DENSE && EMU == 0 && !BSP && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe");
+    static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && EMU == 0 && !BSP && PIPE == 1), "lean K loop: plain fp32-pipe launches");
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int AI = BM / (8 * NW);                                   // DMA instructions per wave per slice
@@ -452,6 +538,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
     // ---- per-lane source bookkeeping ------------------------------------------------------
     const int lr = lane >> 3;   // row within the 8-row group
     const int ls = lane & 7;    // LDS chunk slot
+    unsigned va[AI], vb[BI];    // LEAN: constant per-lane byte offsets of the activation / weight rows
+    const float* lean_a = a.x;  // LEAN: wave-uniform base of the activation rows (PM: moved to the tile's first tap)
+    if (LEAN && PM) lean_a = a.x + ((long long)pm_iy0 * a.W + pm_ix0) * a.ldx;
     const float* pa[AI];        // DENSE: running source pointer (or the zero block)
     int step_a[AI];             // DENSE: pointer advance per slice (0 for the zero block)
     long long boff[AI];         // generic: element offset of (image, oy*s-pad, ox*s-pad, chunk)
@@ -465,8 +554,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
         qa[j] = (ls ^ ((row >> 1) & 7)) * 4;
-        pa[j] = a.zeros; step_a[j] = 0; boff[j] = 0; amask[j] = 0; tflag[j] = 0;
-        if (DENSE) {
+        pa[j] = a.zeros; step_a[j] = 0; boff[j] = 0; amask[j] = 0; tflag[j] = 0; va[j] = 0;
+        if (LEAN) {
+            const int r = PM ? (m < a.pm_images ? m : 0) : mm;
+            va[j] = (unsigned)(((size_t)r * (PM ? (size_t)a.H * a.W : (size_t)1) * a.ldx + qa[j]) * 4);
+        } else if (DENSE) {
             if (ok) { pa[j] = a.x + (size_t)mm * a.ldx + qa[j]; step_a[j] = 32; }
             if (a.tsm_T > 0) {
                 const int t = (mm / a.tsm_hw) % a.tsm_T;
@@ -504,7 +596,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
             const int plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2);
             const int n = n0 + row;
             const int q = ((lane & 3) ^ ((row >> 2) & 3)) * 8;   // bf16 elements
-            qb[j] = q;
+            qb[j] = q; vb[j] = 0;
             if (n < a.N) {
                 pb[j] = reinterpret_cast<const float*>(a.wsp + ((size_t)plane * a.N + n) * a.K + q);
                 step_b[j] = 16;   // 32 bf16 = 16 floats per slice
@@ -514,6 +606,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
             const int n = n0 + row;
             const int q = (ls ^ ((row >> 1) & 7)) * 4;
             qb[j] = q;
+            vb[j] = (unsigned)(((size_t)(n < a.N ? n : 0) * a.K + q) * 4);
             if (n < a.N) { pb[j] = a.w + (size_t)n * a.K + q; step_b[j] = 32; }
             else { pb[j] = a.zeros; step_b[j] = 0; }
         }
@@ -558,7 +651,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         }
     };
     // one DMA instruction: q < BI -> weight rows, else activation rows
+    const unsigned smem_lds = (unsigned)(size_t)(lptr_t)smem;      // LDS byte address of the block's buffer
+    auto lean_dma = [&](const float* sbase, unsigned voff, const float* lds) {
+        const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((lds - smem) * 4));
+        const unsigned long long b = (unsigned long long)sbase;     // wave-uniform by construction: pin it to SGPRs
+        const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+        // (s_nop: the M0 write -> LDS-DMA read hazard the compiler pads for its own builtin is ours to pad inside an asm block)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory");
+    };
     auto issue_one = [&](int q, int buf) {
+        if (LEAN) {
+            if (q < BI)
+                lean_dma(a.w + (PM ? nx_koff : nx_kt * 32), vb[q], smem + buf * STAGE + BM * 32 + (wave + q * NW) * 8 * 32);
+            else
+                lean_dma(PM ? lean_a + nx_toff : lean_a + nx_kt * 32, va[q - BI], smem + buf * STAGE + (wave + (q - BI) * NW) * 8 * 32);
+            return;
+        }
         if (q < BI) {
             float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;   // 8 rows x 128 B = 16 rows x 64 B = 256 floats per instruction
             const float* srcb = pb[q];
@@ -763,13 +872,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
         return;
     }
 
-    auto slice = [&](int kt, auto more_tag) {
+    // the K loop runs in pairs of slices so that the stage a slice reads is a compile-time constant: the fragment reads are
+    // then ds_read_b128 at (loop-invariant VGPR) + immediate, with no address arithmetic per slice
+    auto slice = [&](int kt, auto more_tag, auto stage_tag) {
         constexpr bool more = decltype(more_tag)::value;   // compile time: the last slice issues nothing
+        constexpr int stage = decltype(stage_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for slice kt has landed
         __builtin_amdgcn_s_barrier();                        // ... everyone's has, and slice kt-1 is consumed
-        const int nbuf = (kt + 1) & 1;
+        constexpr int nbuf = stage ^ 1;
         if (more) prep(kt + 1);
-        const float* St = smem + (kt & 1) * STAGE;
+        const float* St = smem + stage * STAGE;
         if (!PIPE) {
             if (more) {
 #pragma unroll
@@ -870,8 +982,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const Co
             }
         }
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
-    slice(nk - 1, std::false_type{});
+    {
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            slice(kt, std::true_type{}, S0{});
+            slice(kt + 1, std::true_type{}, S1{});
+        }
+        if (nk - kt == 2) {
+            slice(kt, std::true_type{}, S0{});
+            slice(kt + 1, std::false_type{}, S1{});
+        } else {
+            slice(kt, std::false_type{}, S0{});
+        }
+    }
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
     if (PM) conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave, a.OH * a.OW, pm_p, a.pm_images);
     else conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave);
@@ -1219,7 +1344,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
     if (N1) {
         ConvArgs o1 = a;
         o1.scale = fa.s1n; o1.bias = fa.b1n; o1.res = nullptr; o1.out = fa.out1; o1.N = N1; o1.ldo = N1; o1.ldr = N1;
-        o1.act = fa.act1n; o1.vec_epi = 1;
+        o1.act = fa.act1n; o1.vec_epi = a.vec_epi == 2 ? 2 : 1;
         __syncthreads();
         conv_epilogue<TM, (TN1 ? TN1 : 1)>(o1, smem, acc1, m0, 0, wm, wn, lane, wave);
     }
@@ -1272,8 +1397,15 @@ struct TileShape { int bm, bn; float eff; };
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
     {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.02f}, {64, 64, 0.98f}, {64, 128, 0.99f}};
 
+// ADAF_CONV_LEAN=0 keeps the builtin-DMA K loop and the general epilogue (A/B measurements); 2 = lean forms for position-major tiles only
+static int conv_lean_enabled() {
+    static const int on = [] { const char* e = getenv("ADAF_CONV_LEAN"); return e ? atoi(e) : 1; }();
+    return on;
+}
+
 template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
+    if (a.vec_epi && conv_lean_enabled() == 1) a.vec_epi = 2;     // interior tiles take the lean epilogue
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (dense)
@@ -1318,8 +1450,12 @@ static double conv_tap_fill(const ConvArgs& a) {
 
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
+    if (a.vec_epi && conv_lean_enabled() == 1) a.vec_epi = 2;     // interior tiles take the lean epilogue
     a.tiles_n = (a.N + BN - 1) / BN;
     a.nblocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    // the lean K loop addresses rows with 32-bit byte offsets from a scalar base
+    const bool lean = conv_lean_enabled() && (size_t)a.M * a.ldx * 4 < 0xffffff00ull && (size_t)a.N * a.K * 4 < 0xffffff00ull &&
+                      (dense || (size_t)a.H * a.W * a.ldx * (size_t)(a.OH * a.OW > 0 ? a.M / (a.OH * a.OW) : 0) * 4 < 0xffffff00ull);
     if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
         // position-major tiles with padding-tap skipping: when enough images share a pixel position to fill the tile
         // rows and at least ~7 % of the products are padding
@@ -1330,12 +1466,24 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
             a.pm_images = images;
             a.pm_groups = (images + BM - 1) / BM;
             a.nblocks = ohw * a.pm_groups * a.tiles_n;
-            hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 0, false, 0, true>), dim3(a.nblocks),
-                               dim3(64 * WGM * WGN), 0, s, a);
+            if (lean && a.pm_allow != 2)
+                hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 0, false, 0, true, true>), dim3(a.nblocks),
+                                   dim3(64 * WGM * WGN), 0, s, a);
+            else
+                hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 0, false, 0, true>), dim3(a.nblocks),
+                                   dim3(64 * WGM * WGN), 0, s, a);
             return;
         }
     }
     const bool special = a.tsm_T > 0 || (a.K & 31);
+    if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
+        // (64x64 tiles keep the builtin form: measured equal at K = 1024 and 7 % slower at K = 2048, cout 512 -- stage 4's conv1)
+        if (dense && !special && lean && conv_lean_enabled() == 1 && BM * BN > 64 * 64) {
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, false, 0, false, 0, false, true>), dim3(a.nblocks),
+                               dim3(64 * WGM * WGN), 0, s, a);
+            return;
+        }
+    }
     if (dense && special)
         hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, PIPE, true, EMU, BSP>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
     else if (dense)
@@ -1510,6 +1658,7 @@ int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3,
     fa.c2 = c2;
     fa.c2.tiles_n = 1;
     fa.c2.nblocks = (c2.M + 127) / 128;
+    fa.c2.vec_epi = conv_lean_enabled() == 1 ? 2 : 1;       // the next block's conv1 tile goes out through the lean epilogue
     fa.w3 = w3; fa.s3 = s3; fa.b3 = b3; fa.res = res; fa.out = out; fa.n3 = n3; fa.ldr = ldr;
     fa.w1n = w1n; fa.s1n = s1n; fa.b1n = b1n; fa.out1 = out1; fa.act1n = ADAF_ACT_RELU;
     const dim3 grid(fa.c2.nblocks), block(256);
