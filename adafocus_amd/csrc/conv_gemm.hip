@@ -484,7 +484,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // problem read a valid row instead of the zero block (their outputs are discarded by the epilogue), so no select either.
 template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0, bool PM = false,
           bool LEAN = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_glds_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (BM == 128 && BN == 128 && WGM * WGN == 4) ? 2 : 1)   // 128x128: two blocks per CU
+void conv_gemm_glds_kernel(const ConvArgs a) {
     static_assert(!PM || (!DENSE && EMU == 0 && !BSP && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe");
     static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && EMU == 0 && !BSP && PIPE == 1), "lean K loop: plain fp32-pipe launches");
     constexpr int NW = WGM * WGN;

@@ -3,6 +3,7 @@ tools/gen_golden_r2.py): resampling crop (N1), nearest glancer input, the per-st
 shape end to end, Something-Something video_div = 2 + the reward-baseline branch (f4), the fused GRU scan (FC folded in,
 h0, batches above 64, cooperative launch), the two-stream pipelined forward and multi-stream safety of the glancer."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -704,3 +705,21 @@ def test_device_mismatch_is_refused(dev, ops):
     x = torch.zeros((1, 3, 64, 64), device="cuda:1")
     with pytest.raises(AdafError):
         ops.crop_gather(x, torch.zeros((1, 2), device="cuda:1"), 32)
+
+
+@pytest.mark.gpu
+def test_conv_lean_forms_bit_identical_to_builtin_forms():
+    """The VALU-free K loop (scalar-base LDS-DMA, clamped rows) and the lean epilogue (saddr accesses, packed fma/add, med3)
+    against the builtin-DMA K loop and the general epilogue they replace (ADAF_CONV_LEAN=0): same digests on interior,
+    ragged, position-major and sub-tile launches, default tile and forced 128x128 / 128x64 / 64x64."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("1", "0"):
+        env = dict(os.environ, ADAF_CONV_LEAN=mode)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "lean_ab.py")], capture_output=True, text=True, timeout=600,
+                           cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 3])
+    assert len(outs[0]) == 8 * 4 and outs[0] == outs[1]

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/profile_bench.sh left in gpurun_out/ into profiles/ and derive profiles/<tag>_traffic.json
+(the per-launch HBM bytes bench.py reports as roofline.traffic) from the FETCH_SIZE / WRITE_SIZE passes.
+usage: publish_profiles.py [tag=r2]"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+NAMES = {"trace1": "bench_kernel_trace", "trace3": "bench_kernel_trace_3streams", "mfma": "bench_pmc_mfma",
+         "fetch": "bench_pmc_fetch_size", "write": "bench_pmc_write_size"}
+CMDS = {
+    "trace1": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 4 --skip-extras --streams 1 --cpu-baseline 0",
+    "trace3": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 30 --warmup 6 --skip-extras --cpu-baseline 0",
+    "mfma": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0",
+    "fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0",
+    "write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0",
+}
+CONV = re.compile(r"conv_gemm_|conv_fused_tail_|stem7x7_")
+
+
+def counter_rows(path, counter):
+    """(dispatches, sum) over the conv-engine kernels of one summary; stem dispatches = trunk passes"""
+    disp, total, passes = 0, 0.0, 0
+    for line in open(path):
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        if len(cells) < 5 or cells[1] != counter or not CONV.search(cells[0]):
+            continue
+        disp += int(cells[2])
+        total += float(cells[3])
+        if "stem7x7_" in cells[0]:
+            passes += int(cells[2])
+    return disp, total, passes
+
+
+for short, name in NAMES.items():
+    src = os.path.join(OUT, "%s_%s.md" % (tag, short))
+    if not os.path.exists(src):
+        print("missing", src)
+        continue
+    body = open(src).read().split("\n", 1)[1]
+    open(os.path.join(PROF, "%s_%s.md" % (tag, name)), "w").write("# %s\n%s" % (CMDS[short], body))
+    print("published", name)
+
+fd, fs, passes = counter_rows(os.path.join(PROF, "%s_bench_pmc_fetch_size.md" % tag), "FETCH_SIZE")
+wd, ws, _ = counter_rows(os.path.join(PROF, "%s_bench_pmc_write_size.md" % tag), "WRITE_SIZE")
+per_launch = int((2 * fs + ws) * 1024 / fd)
+json.dump({
+    "source": "profiles/%s_bench_pmc_fetch_size.md + %s_bench_pmc_write_size.md (rocprofv3 --pmc, separate passes; conv_gemm_*, "
+              "conv_fused_tail_* and stem7x7_* kernels)" % (tag, tag),
+    "workload": {"frames": 16, "patch": 96, "batch": 64},
+    "conv_dispatches_counted": [fd, wd],
+    "trunk_conv_launches_per_step": fd // max(passes, 1),
+    "passes": passes,
+    "fetch_kb_sum": fs, "write_kb_sum": ws,
+    "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950, MI355X_MICROARCH.md)",
+    "hbm_bytes_per_launch": per_launch,
+    "algorithmic_bytes_note": "sum over the launches of in + out (+ residual) + weights, bench.py launch table: see roofline.flop_per_launch / DESIGN 3.2",
+}, open(os.path.join(PROF, "%s_traffic.json" % tag), "w"), indent=1)
+print("traffic: %d dispatches over %d passes, %.1f MB / launch" % (fd, passes, per_launch / 1e6))
