@@ -1035,7 +1035,11 @@ struct FusedTailArgs {
     int act1n;
 };
 
-template <int N1>
+// PM: position-major tiles (the 128 rows of a tile are one output pixel of 128 consecutive images): the 3x3 gather then has
+// no per-row tap masks -- scalar-base DMA, no VALU in the K loop -- and skips the taps that only multiply padding, exactly as
+// the stand-alone position-major conv kernel does (bit-identical).  Everything after phase 1 addresses its rows through the
+// row map (tile row r -> output row (m0 + r) * rstride + roff), so the two forms share phases 2 and 3.
+template <int N1, bool PM>
 __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTailArgs fa) {
     constexpr int BM = 128, BN = 64, NW = 4, WGN = 2;
     constexpr int TM = 2, TN = 1;
@@ -1069,66 +1073,113 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = bid * BM;
+    // row map of the tile
+    int m0 = bid * BM, rstride = 1, roff = 0, rlimit = a.M;
+    int pm_iy0 = 0, pm_ix0 = 0;
+    unsigned pm_mask = 0;
+    if (PM) {   // group-major order, as in conv_gemm_glds_kernel: an XCD's consecutive tiles are the pixels of the same images
+        const int ohw = a.OH * a.OW;
+        const int g = bid / ohw;
+        roff = bid - g * ohw;
+        m0 = g * BM;
+        rstride = ohw;
+        rlimit = a.pm_images;
+        const int oy = roff / a.OW, ox = roff - oy * a.OW;
+        pm_iy0 = oy * a.stride - a.pad;
+        pm_ix0 = ox * a.stride - a.pad;
+        for (int kh = 0; kh < a.KH; ++kh)
+            for (int kw = 0; kw < a.KW; ++kw)
+                if ((unsigned)(pm_iy0 + kh) < (unsigned)a.H && (unsigned)(pm_ix0 + kw) < (unsigned)a.W) pm_mask |= 1u << (kh * a.KW + kw);
+    }
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    const unsigned smem_lds = (unsigned)(size_t)(lptr_t)smem;
+    auto uni = [](unsigned long long v) {       // wave-uniform by construction: pin to SGPRs
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    // scalar-base LDS-DMA (see the LEAN note above conv_gemm_glds_kernel): constant lane offset, SALU-advanced base
+    auto lean_dma = [&](const float* sbase, unsigned voff, const float* lds) {
+        const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((lds - smem) * 4));
+        const unsigned long long sb = uni((unsigned long long)sbase);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory");
+    };
 
     // ---- phase 1: 3x3 implicit GEMM, tile 128 x 64, K = KH*KW*64 ------------------------------------------
     const int lr = lane >> 3, ls = lane & 7;
     long long boff[AI];
     unsigned amask[AI];
+    unsigned va[AI], vb[BI];
+    const float* lean_a = a.x + ((long long)pm_iy0 * a.W + pm_ix0) * a.ldx;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
         const int row = (j * NW + wave) * 8 + lr;
         const int m = m0 + row;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
         const int qa = (ls ^ ((row >> 1) & 7)) * 4;
-        const int ohw = a.OH * a.OW;
-        const int img = mm / ohw;
-        const int rem = mm - img * ohw;
-        const int oy = rem / a.OW;
-        const int ox = rem - oy * a.OW;
-        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        boff[j] = ((long long)img * a.H * a.W + (long long)iy0 * a.W + ix0) * a.ldx + qa;
-        unsigned mk = 0;
-        for (int kh = 0; kh < a.KH; ++kh)
-            for (int kw = 0; kw < a.KW; ++kw)
-                if (ok && (unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W) mk |= 1u << (kh * a.KW + kw);
-        amask[j] = mk;
+        boff[j] = 0; amask[j] = 0; va[j] = 0;
+        if (PM) {
+            va[j] = (unsigned)(((size_t)(m < rlimit ? m : 0) * a.H * a.W * a.ldx + qa) * 4);
+        } else {
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int ohw = a.OH * a.OW;
+            const int img = mm / ohw;
+            const int rem = mm - img * ohw;
+            const int oy = rem / a.OW;
+            const int ox = rem - oy * a.OW;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            boff[j] = ((long long)img * a.H * a.W + (long long)iy0 * a.W + ix0) * a.ldx + qa;
+            unsigned mk = 0;
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw)
+                    if (ok && (unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W) mk |= 1u << (kh * a.KW + kw);
+            amask[j] = mk;
+        }
     }
-    const float* pb[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int row = (j * NW + wave) * 8 + lr;           // BN = 64 = a.N: always a valid filter
-        pb[j] = a.w + (size_t)row * a.K + (ls ^ ((row >> 1) & 7)) * 4;
+        vb[j] = (unsigned)(((size_t)row * a.K + (ls ^ ((row >> 1) & 7)) * 4) * 4);
     }
-    int nx_tap = 0, nx_c0 = 0, nx_kh = 0, nx_kw = 0;
+    int nx_tap = 0, nx_c0 = 0, nx_kh = 0, nx_kw = 0, nx_koff = 0;
     long long nx_toff = 0;
     auto prep = [&](int kt) {
-        if (kt == 0) { nx_c0 = 0; nx_tap = 0; nx_kh = 0; nx_kw = 0; }
+        bool moved = false;
+        if (kt == 0) { nx_c0 = 0; nx_tap = 0; nx_kh = 0; nx_kw = 0; moved = true; }
         else {
             nx_c0 += 32;
             if (nx_c0 == a.cin) {
                 nx_c0 = 0;
                 ++nx_tap;
                 if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
+                moved = true;
+            }
+        }
+        if (PM && moved) {      // on to the next tap that touches the image (the centre tap always does)
+            while (!((pm_mask >> nx_tap) & 1u)) {
+                ++nx_tap;
+                if (++nx_kw == a.KW) { nx_kw = 0; ++nx_kh; }
             }
         }
         nx_toff = ((long long)nx_kh * a.W + nx_kw) * a.ldx + nx_c0;
+        nx_koff = nx_tap * a.cin + nx_c0;
     };
     auto issue_one = [&](int q, int buf) {
         if (q < BI) {
-            float* Bs = smem + buf * STAGE + BM * 32 + wave * 8 * 32;
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[q], (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
-            pb[q] += 32;
+            lean_dma(a.w + nx_koff, vb[q], smem + buf * STAGE + BM * 32 + (wave + q * NW) * 8 * 32);
             return;
         }
         const int j = q - BI;
-        float* As = smem + buf * STAGE + wave * 8 * 32;
-        const float* src = ((amask[j] >> nx_tap) & 1u) ? a.x + boff[j] + nx_toff : a.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + j * NW * 8 * 32), 16, 0, 0);
+        float* As = smem + buf * STAGE + (wave + j * NW) * 8 * 32;
+        if (PM) {
+            lean_dma(lean_a + nx_toff, va[j], As);
+        } else {
+            const float* src = ((amask[j] >> nx_tap) & 1u) ? a.x + boff[j] + nx_toff : a.zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)As, 16, 0, 0);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -1150,54 +1201,72 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
     float* W3s = smem + W3OFF;              // [2 buffers][2 slices][32 rows][32]
     float* W1s = smem + W1OFF;              // [N1 rows][32]
     float* slab = smem + XSZ + wave * 32 * 36;
-    const bool full = m0 + BM <= a.M;       // every lane stores in every pass: the counted waits below are exact
+    const bool full = m0 + BM <= rlimit;    // every lane stores in every pass: the counted waits below are exact
     const int c4 = lane & 7, rsub = lane >> 3;               // epilogue: 8 chunks of 4 channels per row, 8 rows per instruction
-    // instruction u = j*4 + wave of a W3 chunk: slice u / 4, rows (u % 4) * 8 + lr
+    // instruction u = j*4 + wave of a W3 chunk: slice u / 4, rows (u % 4) * 8 + lr.  Lane offsets are constants; the
+    // chunk (np) moves the scalar base.
+    unsigned v3[2], v1[N1 ? N1 / 32 : 1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = j * NW + wave;
+        const int sl = u >> 2, row = (u & 3) * 8 + lr;
+        v3[j] = (unsigned)((row * 64 + sl * 32 + ((ls ^ ((row >> 1) & 7)) << 2)) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < (N1 ? N1 / 32 : 1); ++j) {
+        const int row = (j * NW + wave) * 8 + lr;
+        v1[j] = (unsigned)(((size_t)row * fa.n3 + ((ls ^ ((row >> 1) & 7)) << 2)) * 4);
+    }
     auto issue_w3 = [&](int np) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int u = j * NW + wave;
-            const int sl = u >> 2, row = (u & 3) * 8 + lr;
-            const float* src = fa.w3 + (size_t)(np * PW + row) * 64 + sl * 32 + ((ls ^ ((row >> 1) & 7)) << 2);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(W3s + (W3DB ? (np & 1) * 2048 : 0) + u * 256), 16, 0, 0);
-        }
+        for (int j = 0; j < 2; ++j)
+            lean_dma(fa.w3 + (size_t)np * PW * 64, v3[j], W3s + (W3DB ? (np & 1) * 2048 : 0) + (j * NW + wave) * 256);
     };
     auto issue_w1 = [&](int np) {
         if (N1 == 0) return;
 #pragma unroll
-        for (int j = 0; j < (N1 ? N1 / 32 : 1); ++j) {
-            const int u = j * NW + wave;
-            const int row = u * 8 + lr;
-            const float* src = fa.w1n + (size_t)row * fa.n3 + np * PW + ((ls ^ ((row >> 1) & 7)) << 2);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(W1s + u * 256), 16, 0, 0);
-        }
+        for (int j = 0; j < (N1 ? N1 / 32 : 1); ++j) lean_dma(fa.w1n + np * PW, v1[j], W1s + (j * NW + wave) * 256);
     };
+    // identity rows in / output rows out: scalar row bases (one per 8-row step u of the wave's band) + constant lane offsets
+    const unsigned vres = (unsigned)(((size_t)rsub * rstride * fa.ldr + 4 * c4) * 4);
+    const unsigned vout = (unsigned)(((size_t)rsub * rstride * fa.n3 + 4 * c4) * 4);
+    unsigned long long rbase[4], obase[4];
+    bool row_ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t grow = (size_t)(m0 + wave * 32 + u * 8) * rstride + roff;
+        rbase[u] = uni((unsigned long long)fa.res + grow * fa.ldr * 4);
+        obase[u] = uni((unsigned long long)fa.out + grow * fa.n3 * 4);
+        row_ok[u] = m0 + wave * 32 + u * 8 + rsub < rlimit;
+    }
     f32x4 rv[4];                             // identity rows of the coming conv3 pass (requested one pass ahead)
     auto load_res = [&](int np) {
-        const int n = np * PW + 4 * c4;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int m = m0 + wave * 32 + u * 8 + rsub;
-            rv[u] = *reinterpret_cast<const f32x4*>(m < a.M ? fa.res + (size_t)m * fa.ldr + n : a.zeros);
+            const gf32x4* src = reinterpret_cast<const gf32x4*>(reinterpret_cast<const gchar*>(rbase[u] + (unsigned long long)np * PW * 4) + vres);
+            if (full) rv[u] = *src;
+            else rv[u] = row_ok[u] ? *src : zero4;
         }
     };
 
-    const int nk = a.K / 32;
+    const int nk = PM ? __builtin_popcount(pm_mask) * (a.cin >> 5) : a.K / 32;     // even: cin = 64 -> two slices per tap
     prep(0);
 #pragma unroll
     for (int q = 0; q < NI; ++q) issue_one(q, 0);
-    auto slice = [&](int kt, auto more_tag) {
+    auto slice = [&](int kt, auto more_tag, auto stage_tag) {
         constexpr bool more = decltype(more_tag)::value;
+        constexpr int stage = decltype(stage_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int nbuf = (kt + 1) & 1;
+        constexpr int nbuf = stage ^ 1;
         if (more) prep(kt + 1);
         else {   // last slice (odd index: it reads stage 1): stage 0 is idle -> first conv3 weight chunk + identity rows
             issue_w3(0);
             issue_w1(0);
             load_res(0);
         }
-        const float* St = smem + (kt & 1) * STAGE;
+        const float* St = smem + stage * STAGE;
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(St + a_base + i * 1024 + foff[0]);
@@ -1227,8 +1296,17 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
             }
         }
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
-    slice(nk - 1, std::false_type{});
+    {
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            slice(kt, std::true_type{}, S0{});
+            slice(kt + 1, std::true_type{}, S1{});
+        }
+        slice(kt, std::true_type{}, S0{});
+        slice(kt + 1, std::false_type{}, S1{});
+    }
     __syncthreads();      // every wave is done with the stage ring: it becomes the phase-2 workspace
 
     // ---- phase 2 set-up: BN + ReLU of conv2 into the A image (the first weight chunks are already on their way)
@@ -1280,11 +1358,13 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(af2[sl][kk][s4], bf[s4], acc3, 0, 0, 0);
             }
-        // ---- epilogue: BN + identity + ReLU, 16-byte accesses; the result is also the next conv1's A chunk
+        // ---- epilogue: BN + identity + ReLU, 16-byte accesses; the result is also the next conv1's A chunk.  Packed
+        // fma / add (2 + 2 + 4 max per 16 bytes) and scalar-base accesses: the VALU shares the matrix pipe's lanes.
         {
             const int n = np * PW + 4 * c4;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(fa.s3 + n);
             const f32x4 bi = *reinterpret_cast<const f32x4*>(fa.b3 + n);
+            const f32x2 sc0 = {sc.x, sc.y}, sc1 = {sc.z, sc.w}, bi0 = {bi.x, bi.y}, bi1 = {bi.z, bi.w};
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab[(crow + (r & 3) + 8 * (r >> 2)) * 36 + (lane & 31)] = acc3[r];
@@ -1294,11 +1374,9 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
             for (int u = 0; u < 4; ++u) {
                 const int row = u * 8 + rsub;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 36 + 4 * c4);
-                f32x4 o;
-                o.x = fmaxf(fmaf(v.x, sc.x, bi.x) + rv[u].x, 0.f);
-                o.y = fmaxf(fmaf(v.y, sc.y, bi.y) + rv[u].y, 0.f);
-                o.z = fmaxf(fmaf(v.z, sc.z, bi.z) + rv[u].z, 0.f);
-                o.w = fmaxf(fmaf(v.w, sc.w, bi.w) + rv[u].w, 0.f);
+                const f32x2 p0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, sc0, bi0) + f32x2{rv[u].x, rv[u].y};
+                const f32x2 p1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, sc1, bi1) + f32x2{rv[u].z, rv[u].w};
+                const f32x4 o = {fmaxf(p0.x, 0.f), fmaxf(p0.y, 0.f), fmaxf(p1.x, 0.f), fmaxf(p1.y, 0.f)};
                 ov[u] = o;
                 if (N1) {
                     const int arow = wave * 32 + row;
@@ -1307,8 +1385,9 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int m = m0 + wave * 32 + u * 8 + rsub;
-                if (m < a.M) *reinterpret_cast<f32x4*>(fa.out + (size_t)m * fa.n3 + n) = ov[u];
+                gf32x4* dst = reinterpret_cast<gf32x4*>(reinterpret_cast<gchar*>(obase[u] + (unsigned long long)np * PW * 4) + vout);
+                if (full) *dst = ov[u];
+                else if (row_ok[u]) *dst = ov[u];
             }
             if (np + 1 < npass) load_res(np + 1);        // the next pass's identity rows travel under this pass's tail
         }
@@ -1347,7 +1426,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
         o1.scale = fa.s1n; o1.bias = fa.b1n; o1.res = nullptr; o1.out = fa.out1; o1.N = N1; o1.ldo = N1; o1.ldr = N1;
         o1.act = fa.act1n; o1.vec_epi = a.vec_epi == 2 ? 2 : 1;
         __syncthreads();
-        conv_epilogue<TM, (TN1 ? TN1 : 1)>(o1, smem, acc1, m0, 0, wm, wn, lane, wave);
+        conv_epilogue<TM, (TN1 ? TN1 : 1)>(o1, smem, acc1, m0, 0, wm, wn, lane, wave, rstride, roff, rlimit);
     }
 }
 
@@ -1449,6 +1528,12 @@ static double conv_tap_fill(const ConvArgs& a) {
     return (double)(axis(a.OH, a.H, a.KH) * axis(a.OW, a.W, a.KW)) / ((double)a.OH * a.OW * a.KH * a.KW);
 }
 
+// position-major tiles are used when less than this share of the filter taps touches the image (ADAF_PM_FILL overrides, experiments)
+static double conv_pm_fill_threshold() {
+    static const double t = [] { const char* e = getenv("ADAF_PM_FILL"); return e ? atof(e) : 0.96; }();
+    return t;
+}
+
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     if (a.vec_epi && conv_lean_enabled() == 1) a.vec_epi = 2;     // interior tiles take the lean epilogue
@@ -1459,11 +1544,11 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
                       (dense || (size_t)a.H * a.W * a.ldx * (size_t)(a.OH * a.OW > 0 ? a.M / (a.OH * a.OW) : 0) * 4 < 0xffffff00ull);
     if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
         // position-major tiles with padding-tap skipping: when enough images share a pixel position to fill the tile
-        // rows and at least ~7 % of the products are padding
+        // rows and at least 4 % of the products are padding
         const int ohw = a.OH * a.OW;
         const int images = ohw > 0 ? a.M / ohw : 0;
         if (!dense && a.pm_allow && a.KH * a.KW > 1 && a.KH * a.KW <= 32 && images * ohw == a.M && images >= BM && ohw <= 4096 &&
-            conv_tap_fill(a) < 0.93) {
+            conv_tap_fill(a) < conv_pm_fill_threshold()) {
             a.pm_images = images;
             a.pm_groups = (images + BM - 1) / BM;
             a.nblocks = ohw * a.pm_groups * a.tiles_n;
@@ -1655,6 +1740,9 @@ int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3,
                            float* out, int n3, const float* w1n, const float* s1n, const float* b1n, float* out1, int n1,
                            hipStream_t s) {
     if (c2.N != 64 || c2.cin != 64 || (c2.K & 31) || c2.KH * c2.KW > 32 || n3 % 32 || (n1 != 0 && n1 != 64 && n1 != 128)) return -1;
+    // scalar-base accesses: 32-bit lane offsets
+    if ((size_t)c2.M * c2.ldx * 4 >= 0xffffff00ull || (size_t)c2.M * n3 * 4 >= 0x3fffffffull * 4 || (size_t)n3 * 128 * 4 >= 0xffffff00ull)
+        return -1;
     FusedTailArgs fa;
     fa.c2 = c2;
     fa.c2.tiles_n = 1;
@@ -1662,9 +1750,26 @@ int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3,
     fa.c2.vec_epi = conv_lean_enabled() == 1 ? 2 : 1;       // the next block's conv1 tile goes out through the lean epilogue
     fa.w3 = w3; fa.s3 = s3; fa.b3 = b3; fa.res = res; fa.out = out; fa.n3 = n3; fa.ldr = ldr;
     fa.w1n = w1n; fa.s1n = s1n; fa.b1n = b1n; fa.out1 = out1; fa.act1n = ADAF_ACT_RELU;
+    // position-major tiles when the images fill the 128-row groups (<= 6 % padding rows): no tap masks in the gather
+    const int ohw = c2.OH * c2.OW;
+    const int images = ohw > 0 ? c2.M / ohw : 0;
+    const int groups = (images + 127) / 128;
+    const bool pm = c2.pm_allow == 1 && conv_lean_enabled() != 0 && images * ohw == c2.M && images >= 128 && ohw <= 4096 &&
+                    (long long)groups * 128 * 100 <= (long long)images * 106 && (size_t)ohw * 8 * (size_t)(n3 > ldr ? n3 : ldr) * 4 < 0xffffff00ull;
+    if (pm) {
+        fa.c2.pm_images = images;
+        fa.c2.pm_groups = groups;
+        fa.c2.nblocks = ohw * groups;
+    }
     const dim3 grid(fa.c2.nblocks), block(256);
-    if (n1 == 0) hipLaunchKernelGGL((conv_fused_tail_kernel<0>), grid, block, 0, s, fa);
-    else if (n1 == 64) hipLaunchKernelGGL((conv_fused_tail_kernel<64>), grid, block, 0, s, fa);
-    else hipLaunchKernelGGL((conv_fused_tail_kernel<128>), grid, block, 0, s, fa);
+    if (pm) {
+        if (n1 == 0) hipLaunchKernelGGL((conv_fused_tail_kernel<0, true>), grid, block, 0, s, fa);
+        else if (n1 == 64) hipLaunchKernelGGL((conv_fused_tail_kernel<64, true>), grid, block, 0, s, fa);
+        else hipLaunchKernelGGL((conv_fused_tail_kernel<128, true>), grid, block, 0, s, fa);
+    } else {
+        if (n1 == 0) hipLaunchKernelGGL((conv_fused_tail_kernel<0, false>), grid, block, 0, s, fa);
+        else if (n1 == 64) hipLaunchKernelGGL((conv_fused_tail_kernel<64, false>), grid, block, 0, s, fa);
+        else hipLaunchKernelGGL((conv_fused_tail_kernel<128, false>), grid, block, 0, s, fa);
+    }
     return 0;
 }
