@@ -557,7 +557,13 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         qa[j] = (ls ^ ((row >> 1) & 7)) * 4;
         pa[j] = a.zeros; step_a[j] = 0; boff[j] = 0; amask[j] = 0; tflag[j] = 0; va[j] = 0;
         if (LEAN) {
-            const int r = PM ? (m < a.pm_images ? m : 0) : mm;
+            int r = PM ? (m < a.pm_images ? m : 0) : mm;
+            if (DENSE && a.stride != 1) {       // 1x1 / stride s (the downsample convs): output pixel -> input pixel, still one row per row
+                const int ohw = a.OH * a.OW;
+                const int img = mm / ohw, rem = mm - img * ohw;
+                const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                r = (img * a.H + oy * a.stride) * a.W + ox * a.stride;
+            }
             va[j] = (unsigned)(((size_t)r * (PM ? (size_t)a.H * a.W : (size_t)1) * a.ldx + qa[j]) * 4);
         } else if (DENSE) {
             if (ok) { pa[j] = a.x + (size_t)mm * a.ldx + qa[j]; step_a[j] = 32; }
@@ -1564,7 +1570,10 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     const bool special = a.tsm_T > 0 || (a.K & 31);
     if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
         // (64x64 tiles keep the builtin form: measured equal at K = 1024 and 7 % slower at K = 2048, cout 512 -- stage 4's conv1)
-        if (dense && !special && lean && conv_lean_enabled() == 1 && BM * BN > 64 * 64) {
+        // a strided 1x1 conv without padding (ResNet's downsample branch) is the same GEMM with a row gather: lean form only
+        const bool strided1x1 = !dense && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride > 1 && a.tsm_T == 0 && (a.K & 31) == 0 &&
+                                (size_t)a.H * a.W * a.ldx * (size_t)(a.OH * a.OW > 0 ? a.M / (a.OH * a.OW) : 0) * 4 < 0xffffff00ull;
+        if ((dense || strided1x1) && !special && lean && conv_lean_enabled() == 1 && BM * BN > 64 * 64) {
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, false, 0, false, 0, false, true>), dim3(a.nblocks),
                                dim3(64 * WGM * WGN), 0, s, a);
             return;

@@ -725,4 +725,4 @@ def test_conv_lean_forms_bit_identical_to_builtin_forms():
                            cwd=root, env=env)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 3])
-    assert len(outs[0]) == 8 * 4 and outs[0] == outs[1]
+    assert len(outs[0]) == 9 * 4 and outs[0] == outs[1]

@@ -23,6 +23,7 @@ CASES = [
     (70, 6, 6, 128, 128, 3, 2, 1, 1, False),      # position-major, stride 2
     (3, 24, 24, 64, 64, 3, 1, 1, 1, False),       # row-major k x k (too few images for position-major tiles)
     (1, 5, 5, 96, 36, 1, 1, 0, 0, False),         # smaller than one tile
+    (9, 12, 12, 256, 512, 1, 2, 0, 0, False),     # 1x1 / stride 2 (downsample branch): the lean dense kernel with a row gather
 ]
 for i, (n, h, w, cin, cout, k, s, pad, act, res) in enumerate(CASES):
     g = np.random.Generator(np.random.PCG64([i, 23]))
