@@ -665,7 +665,7 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
                                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
         // (s_nop: the M0 write -> LDS-DMA read hazard the compiler pads for its own builtin is ours to pad inside an asm block)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory", "m0");   // (m0 is named so that the compiler does not merge its own M0 initialisations across this block; the "reserved register" warning is expected)
     };
     auto issue_one = [&](int q, int buf) {
         if (LEAN) {
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
     auto lean_dma = [&](const float* sbase, unsigned voff, const float* lds) {
         const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((lds - smem) * 4));
         const unsigned long long sb = uni((unsigned long long)sbase);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory", "m0");   // (m0 is named so that the compiler does not merge its own M0 initialisations across this block; the "reserved register" warning is expected)
     };
 
     // ---- phase 1: 3x3 implicit GEMM, tile 128 x 64, K = KH*KW*64 ------------------------------------------
