@@ -13,10 +13,12 @@
 //      dwconv3x3_kernel), BN + ReLU6, 16-byte stores.
 // The halo is recomputed by neighbouring tiles (1.56x / 1.24x of the expand FLOPs, which are ~1/10 of the
 // block's traffic-equivalent cost at these channel counts).
+#include <cstdlib>
 #include "adaf_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -138,6 +140,176 @@ __global__ __launch_bounds__(256) void mb_expand_dw_kernel(const MbFuseArgs a) {
             }
         }
         // no barrier here: the next chunk's barrier (after its weight load) orders these reads of E before the next writes
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same fused block with WAVE-PRIVATE tiles: every wave owns a small output tile (6x6 at stride 1, 3x4 at stride 2: a halo of
+// 64 / 63 pixels = two MFMA row bands) and runs expand -> BN/ReLU6 -> E in its own 9 KB of LDS -> depthwise taps -> stores on
+// its own, with no block-level barrier anywhere.  The kernel above is bound by the latency of its barrier-separated phase
+// chain; here the chain is private to a wave and the other waves of the CU fill its gaps.  The halo pixels'
+// input channels are loaded straight into MFMA A fragments (no X image in LDS), the expand filter rows into B fragments.
+// Costs: 1.8x (stride 1) / 1.3x (stride 2) of the expand products are halo recomputation.  Same products in the same order
+// per output as the kernels above: bit-identical.
+template <int S, int CIN>
+__global__ __launch_bounds__(256, 3) void mb_expand_dw_w_kernel(const MbFuseArgs a) {
+    constexpr int OTH = S == 1 ? 6 : 3, OTW = S == 1 ? 6 : 4;
+    constexpr int IH = (OTH - 1) * S + 3, IW = (OTW - 1) * S + 3;
+    constexpr int HP = IH * IW;             // 64 / 63 halo pixels
+    constexpr int EP = 36, KK = CIN / 8;
+    constexpr int NIT = OTH * OTW * 8;      // (output pixel, 4-channel group) items per chunk
+    constexpr int NR = (NIT + 63) / 64;
+    static_assert(HP <= 64, "halo = two row bands");
+    constexpr int HMAX = 192;               // hidden channels the LDS-resident taps / affines are sized for (launcher checks)
+    __shared__ __attribute__((aligned(16))) float Eall[4][64 * EP];
+    __shared__ __attribute__((aligned(16))) float Wd[9 * HMAX];
+    __shared__ __attribute__((aligned(16))) float Bn[4 * HMAX];       // expand scale | expand bias | depthwise scale | depthwise bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the block's only cooperative step: depthwise taps and both BN affines to LDS (a chunk then reads them at LDS latency
+    // instead of waiting for L2 once per chunk); zero past `hid` so the last, partial chunk needs no selects
+    for (int idx = tid; idx < 9 * HMAX; idx += 256) {
+        const int t = idx / HMAX, c = idx - t * HMAX;
+        Wd[idx] = c < a.hid ? a.wd[(size_t)t * a.hid + c] : 0.f;
+    }
+    for (int idx = tid; idx < HMAX; idx += 256) {
+        const bool v = idx < a.hid;
+        Bn[idx] = v ? a.se[idx] : 0.f;
+        Bn[HMAX + idx] = v ? a.be[idx] : 0.f;
+        Bn[2 * HMAX + idx] = v ? a.sd[idx] : 0.f;
+        Bn[3 * HMAX + idx] = v ? a.bd[idx] : 0.f;
+    }
+    __syncthreads();
+    float* Ew = Eall[wave];
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int half = lane >> 5, nl = lane & 31;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int c4 = lane & 7, og = lane >> 3;
+    float* e0 = Ew + (4 * half) * EP + nl;
+    // one tile per wave (a loop over several tiles per wave, to amortise the staging above, was measured: the compiler keeps
+    // tile-invariant values live across it, 168 VGPRs with spills, and every block shape got slower)
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.n * per_img) return;
+    const int img = tile / per_img;
+    const int rem = tile - img * per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int oy0 = ty * OTH, ox0 = tx * OTW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const bool inner = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= a.H && ix0 + IW <= a.W;
+
+    // A fragments of the two row bands: halo pixel p = 32 b + nl, k chunk 8 kk + 4 half
+    f32x4 af[2][KK];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int p = 32 * b + nl;
+        const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+        const bool ok = p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const float* src = a.x + (((size_t)img * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * CIN + 4 * half;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) af[b][kk] = ok ? *reinterpret_cast<const f32x4*>(src + 8 * kk) : zero4;
+    }
+    // which accumulator rows are halo pixels inside the image (border tiles only)
+    unsigned emask = 0xffffffffu;
+    if (!inner) {
+        emask = 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+                if (p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) emask |= 1u << (16 * b + r);
+            }
+    }
+
+    // expand filter rows as B fragments, one chunk ahead of their use (from L2)
+    auto wfrag = [&](int ch0, f32x4 (&w)[KK]) {
+        const int nch = ch0 + nl;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            w[kk] = nch < a.hid ? *reinterpret_cast<const f32x4*>(a.we + (size_t)nch * CIN + 8 * kk + 4 * half) : zero4;
+    };
+    f32x4 bf[KK], bnext[KK];
+    wfrag(0, bf);
+    for (int ch0 = 0; ch0 < a.hid; ch0 += 32) {
+        wfrag(ch0 + 32, bnext);             // (past the last chunk: zeros, no loads)
+        const float esc = Bn[ch0 + nl], ebi = Bn[HMAX + ch0 + nl];
+        const int ch = ch0 + 4 * c4;
+        const bool cv = ch < a.hid;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][kk][s4], bf[kk][s4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][kk][s4], bf[kk][s4], acc1, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();        // (the previous chunk's depthwise reads of E are issued: same-wave LDS ops run in order)
+        {
+            const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
+            if (inner) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v0 = __builtin_elementwise_fma(f32x2{acc0[r], acc0[r + 1]}, sc2, bi2);
+                    const f32x2 v1 = __builtin_elementwise_fma(f32x2{acc1[r], acc1[r + 1]}, sc2, bi2);
+                    const int o0 = ((r & 3) + 8 * (r >> 2)) * EP, o1 = (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * EP;
+                    e0[o0] = __builtin_amdgcn_fmed3f(v0.x, 0.f, 6.f);
+                    e0[o1] = __builtin_amdgcn_fmed3f(v0.y, 0.f, 6.f);
+                    e0[32 * EP + o0] = __builtin_amdgcn_fmed3f(v1.x, 0.f, 6.f);
+                    e0[32 * EP + o1] = __builtin_amdgcn_fmed3f(v1.y, 0.f, 6.f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ((r & 3) + 8 * (r >> 2)) * EP;
+                    const float v0 = __builtin_amdgcn_fmed3f(fmaf(acc0[r], esc, ebi), 0.f, 6.f);
+                    const float v1 = __builtin_amdgcn_fmed3f(fmaf(acc1[r], esc, ebi), 0.f, 6.f);
+                    e0[o] = ((emask >> r) & 1u) ? v0 : 0.f;
+                    e0[32 * EP + o] = ((emask >> (16 + r)) & 1u) ? v1 : 0.f;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (cv) {
+            f32x2 k0[9], k1[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 kq = *reinterpret_cast<const f32x4*>(&Wd[t * HMAX + ch]);
+                k0[t] = f32x2{kq.x, kq.y};
+                k1[t] = f32x2{kq.z, kq.w};
+            }
+            const f32x4 dsc = *reinterpret_cast<const f32x4*>(&Bn[2 * HMAX + ch]);
+            const f32x4 dbi = *reinterpret_cast<const f32x4*>(&Bn[3 * HMAX + ch]);
+            const f32x2 sc0 = {dsc.x, dsc.y}, sc1 = {dsc.z, dsc.w}, bi0 = {dbi.x, dbi.y}, bi1 = {dbi.z, dbi.w};
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int o = og + 8 * q;
+                if (o < OTH * OTW) {
+                    const int oy = o / OTW, ox = o - oy * OTW;
+                    const int gy = oy0 + oy, gx = ox0 + ox;
+                    const float* e = Ew + ((oy * S) * IW + ox * S) * EP + 4 * c4;
+                    f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(e + (ky * IW + kx) * EP);
+                            s0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, k0[ky * 3 + kx], s0);
+                            s1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, k1[ky * 3 + kx], s1);
+                        }
+                    if (gy < a.OH && gx < a.OW) {
+                        const f32x2 r0 = __builtin_elementwise_fma(s0, sc0, bi0), r1 = __builtin_elementwise_fma(s1, sc1, bi1);
+                        const f32x4 r = {__builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f),
+                                         __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f)};
+                        *reinterpret_cast<f32x4*>(a.out + (((size_t)img * a.OH + gy) * a.OW + gx) * a.hid + ch) = r;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = bnext[kk];
     }
 }
 
@@ -290,7 +462,30 @@ __global__ __launch_bounds__(256) void mb_stem_b1_kernel(const MbStemArgs a) {
 
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw) { return cin % 8 == 0 && cin <= 32 && hid % 4 == 0 && hw >= 28; }
 
+template <int S, int CIN>
+static void launch_expand_dw_w(MbFuseArgs a, hipStream_t s) {
+    constexpr int OTH = S == 1 ? 6 : 3, OTW = S == 1 ? 6 : 4;
+    a.tiles_x = (a.OW + OTW - 1) / OTW;
+    a.tiles_y = (a.OH + OTH - 1) / OTH;
+    const long long tiles = (long long)a.n * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((mb_expand_dw_w_kernel<S, CIN>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
+}
+
+// ADAF_MB_WAVE=0 keeps the block-cooperative kernel (A/B measurements)
+static bool mb_wave_enabled() {
+    static const bool on = [] { const char* e = getenv("ADAF_MB_WAVE"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s) {
+    if (mb_wave_enabled() && a.hid <= 192) {
+        if (stride == 1 && a.cin == 16) return launch_expand_dw_w<1, 16>(a, s);
+        if (stride == 2 && a.cin == 16) return launch_expand_dw_w<2, 16>(a, s);
+        if (stride == 1 && a.cin == 24) return launch_expand_dw_w<1, 24>(a, s);
+        if (stride == 2 && a.cin == 24) return launch_expand_dw_w<2, 24>(a, s);
+        if (stride == 1 && a.cin == 32) return launch_expand_dw_w<1, 32>(a, s);
+        if (stride == 2 && a.cin == 32) return launch_expand_dw_w<2, 32>(a, s);
+    }
     const int th = stride == 1 ? 8 : 3, tw = 8;
     a.tiles_x = (a.OW + tw - 1) / tw;
     a.tiles_y = (a.OH + th - 1) / th;
