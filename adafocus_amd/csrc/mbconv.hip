@@ -458,6 +458,196 @@ __global__ __launch_bounds__(256) void mb_stem_b1_kernel(const MbStemArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stem -> block 1 with WAVE-PRIVATE tiles (the restructuring that paid for the expand -> depthwise blocks above): a wave owns
+// 4 x 8 block-1 outputs <- 6 x 10 stem outputs (60 halo pixels = two MFMA row bands) <- 13 x 21 input pixels, and runs
+// window -> stem GEMM -> BN/ReLU6 -> E -> depthwise taps -> D (the project conv's A operand, exactly one row band) -> project
+// GEMM -> BN -> 16-byte stores on its own: no block-level barrier.  All filters live in registers (stem and project B
+// fragments) or LDS (taps).  112 = 28 x 4 = 14 x 8: the tiles cover the map exactly.  Same products in the same order as
+// mb_stem_b1_kernel and the unfused launches: bit-identical.
+__global__ __launch_bounds__(256, 4) void mb_stem_b1_w_kernel(const MbStemArgs a) {
+    constexpr int OTH = 4, OTW = 8;
+    constexpr int HH = OTH + 2, HW = OTW + 2, HP = HH * HW;          // stem-output halo 6 x 10
+    constexpr int XH = 2 * HH + 1, XW = 2 * HW + 1, XPIX = XH * XW;   // input window 13 x 21
+    constexpr int EP = 16, DP = 36, SP = 20;          // E holds 16 channels at a time
+    constexpr int XREG = (XPIX + 1) * 4 > 32 * DP ? (XPIX + 1) * 4 : 32 * DP;   // window (+ one zero pixel), later the D image
+    __shared__ __attribute__((aligned(16))) float Xall[4][XREG];
+    __shared__ __attribute__((aligned(16))) float Eall[4][64 * EP];               // E, later the output transposition slab
+    __shared__ __attribute__((aligned(16))) float Wd[9 * 32 + 64];                // taps | depthwise scale | depthwise bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int idx = tid; idx < 9 * 32 + 64; idx += 256)
+        Wd[idx] = idx < 288 ? a.wd[idx] : idx < 320 ? a.sd[idx - 288] : a.bd[idx - 320];
+    __syncthreads();
+    float* Xw = Xall[wave];
+    float* Ew = Eall[wave];
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.n * per_img) return;
+    const int img = tile / per_img;
+    const int rem = tile - img * per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int oy0 = ty * OTH, ox0 = tx * OTW;
+    const int hy0 = oy0 - 1, hx0 = ox0 - 1;                 // stem-output coordinates of the halo's first pixel
+    const int iy0 = 2 * hy0 - 1, ix0 = 2 * hx0 - 1;         // input coordinates of the window's first pixel
+    const bool inner = hy0 >= 0 && hx0 >= 0 && hy0 + HH <= a.H1 && hx0 + HW <= a.H1;
+    const int half = lane >> 5, nl = lane & 31;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // input window -> LDS (pixels outside the frame are the stem conv's zero padding)
+#pragma unroll
+    for (int u = 0; u < (XPIX + 63) / 64; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx < XPIX) {
+            const int r = idx / XW, c = idx - r * XW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = (unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S;
+            *reinterpret_cast<f32x4*>(&Xw[idx * 4]) =
+                ok ? *reinterpret_cast<const f32x4*>(a.x + (((size_t)img * a.S + iy) * a.S + ix) * 4) : zero4;
+        }
+    }
+    if (lane < 4) Xw[XPIX * 4 + lane] = 0.f;
+    // filters: stem rows (k = tap * 4 + channel, 40 with the zero tenth tap) and project rows as B fragments, BN affines
+    f32x4 bs[5], bp[4];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        const int t = 2 * kk + half;
+        bs[kk] = t < 9 ? *reinterpret_cast<const f32x4*>(a.ws + nl * 36 + 4 * t) : zero4;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) bp[kk] = nl < 16 ? *reinterpret_cast<const f32x4*>(a.wp + nl * 32 + 8 * kk + 4 * half) : zero4;
+    const float ssc = a.ss[nl], sbi = a.bs[nl];
+    const float psc = nl < 16 ? a.sp[nl] : 0.f, pbi = nl < 16 ? a.bp[nl] : 0.f;
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- stem GEMM: halo pixel p = 32 b + nl, tap t = 2 kk + half -> one input pixel (4 channels) of the window
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    {
+        int base[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int p = 32 * b + nl;
+            const int pl = p < HP ? p : 0;
+            base[b] = ((2 * (pl / HW)) * XW + 2 * (pl % HW)) * 4;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            const int t = 2 * kk + half;
+            const int toff = ((t / 3) * XW + t % 3) * 4;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Xw[t < 9 ? base[0] + toff : XPIX * 4]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Xw[t < 9 ? base[1] + toff : XPIX * 4]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], bs[kk][s4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], bs[kk][s4], acc1, 0, 0, 0);
+            }
+        }
+    }
+    // ---- BN + ReLU6 -> E -> depthwise 3x3 + BN + ReLU6 -> D, 16 channels at a time (E is then 60 x 16 floats: four blocks
+    // fit a CU instead of three).  Stem outputs outside the map are the depthwise conv's zero padding.
+    unsigned emask = 0xffffffffu;
+    if (!inner) {
+        emask = 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int hy = hy0 + p / HW, hx = hx0 + p % HW;
+                if (p < HP && (unsigned)hy < (unsigned)a.H1 && (unsigned)hx < (unsigned)a.H1) emask |= 1u << (16 * b + r);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {       // the accumulators become the E values in place
+        const f32x2 sc2 = {ssc, ssc}, bi2 = {sbi, sbi};
+        const f32x2 v0 = __builtin_elementwise_fma(f32x2{acc0[r], acc0[r + 1]}, sc2, bi2);
+        const f32x2 v1 = __builtin_elementwise_fma(f32x2{acc1[r], acc1[r + 1]}, sc2, bi2);
+        acc0[r] = __builtin_amdgcn_fmed3f(v0.x, 0.f, 6.f);
+        acc0[r + 1] = __builtin_amdgcn_fmed3f(v0.y, 0.f, 6.f);
+        acc1[r] = __builtin_amdgcn_fmed3f(v1.x, 0.f, 6.f);
+        acc1[r + 1] = __builtin_amdgcn_fmed3f(v1.y, 0.f, 6.f);
+    }
+    if (!inner) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = ((emask >> r) & 1u) ? acc0[r] : 0.f;
+            acc1[r] = ((emask >> (16 + r)) & 1u) ? acc1[r] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __builtin_amdgcn_wave_barrier();        // the previous half's tap reads are issued
+        if ((nl >> 4) == h) {
+            float* e0 = Ew + (4 * half) * EP + (nl & 15);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ((r & 3) + 8 * (r >> 2)) * EP;
+                e0[o] = acc0[r];
+                e0[32 * EP + o] = acc1[r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // item = (output pixel o = 16 q + lane / 4, channel group lane % 4 of this half)
+        const int c4 = lane & 3, ol = lane >> 2;
+        const int cg = 16 * h + 4 * c4;
+        f32x2 k0[9], k1[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 kq = *reinterpret_cast<const f32x4*>(&Wd[t * 32 + cg]);
+            k0[t] = f32x2{kq.x, kq.y};
+            k1[t] = f32x2{kq.z, kq.w};
+        }
+        const f32x4 dsc = *reinterpret_cast<const f32x4*>(&Wd[288 + cg]);
+        const f32x4 dbi = *reinterpret_cast<const f32x4*>(&Wd[320 + cg]);
+        const f32x2 sc0 = {dsc.x, dsc.y}, sc1 = {dsc.z, dsc.w}, bi0 = {dbi.x, dbi.y}, bi1 = {dbi.z, dbi.w};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int o = 16 * q + ol;
+            const int oy = o >> 3, ox = o & 7;
+            const float* e = Ew + (oy * HW + ox) * EP + 4 * c4;
+            f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(e + (ky * HW + kx) * EP);
+                    s0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, k0[ky * 3 + kx], s0);
+                    s1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, k1[ky * 3 + kx], s1);
+                }
+            const f32x2 r0 = __builtin_elementwise_fma(s0, sc0, bi0), r1 = __builtin_elementwise_fma(s1, sc1, bi1);
+            const f32x4 r = {__builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f),
+                             __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f)};
+            *reinterpret_cast<f32x4*>(&Xw[o * DP + cg]) = r;      // (the window is dead: D takes its place)
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- project 1x1 (32 -> 16) + BN: one row band of 32 output pixels, K = 32
+    f32x16 pa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&Xw[nl * DP + 8 * kk + 4 * half]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) pa = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4], bp[kk][s4], pa, 0, 0, 0);
+    }
+    if (nl < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ew[((r & 3) + 8 * (r >> 2) + 4 * half) * SP + nl] = fmaf(pa[r], psc, pbi) + 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = lane + 64 * j;
+        const int px = i >> 2, c = i & 3;
+        const int gy = oy0 + (px >> 3), gx = ox0 + (px & 7);
+        if (gy < a.H1 && gx < a.H1)
+            *reinterpret_cast<f32x4*>(a.out + (((size_t)img * a.H1 + gy) * a.H1 + gx) * 16 + 4 * c) =
+                *reinterpret_cast<const f32x4*>(&Ew[px * SP + 4 * c]);
+    }
+}
+
 }  // namespace
 
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw) { return cin % 8 == 0 && cin <= 32 && hid % 4 == 0 && hw >= 28; }
@@ -496,6 +686,13 @@ void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s) {
 }
 
 void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s) {
+    if (mb_wave_enabled()) {
+        a.tiles_x = (a.H1 + 7) / 8;
+        a.tiles_y = (a.H1 + 3) / 4;
+        a.total_tiles = a.n * a.tiles_x * a.tiles_y;
+        hipLaunchKernelGGL(mb_stem_b1_w_kernel, dim3((unsigned)((a.total_tiles + 3) / 4)), dim3(256), 0, s, a);
+        return;
+    }
     a.tiles_x = (a.H1 + 7) / 8;
     a.tiles_y = a.tiles_x;
     a.total_tiles = a.n * a.tiles_x * a.tiles_y;
