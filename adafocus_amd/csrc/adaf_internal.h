@@ -61,6 +61,13 @@ struct MbFuseArgs {
     int hid, OH, OW;
     int tiles_x, tiles_y;
     const float* zeros;
+    // whole-block kernel (expand -> depthwise -> project [+ identity]): project filter [cout][hid] + BN, identity rows, output
+    const float* wp;
+    const float* sp;
+    const float* bp;
+    const float* res;    // [n][OH][OW][cout] or nullptr
+    float* out2;         // [n][OH][OW][cout]
+    int cout;
 };
 struct MbStemArgs {       // fused stem -> block 1 (t = 1: depthwise + project) of MobileNetV2
     const float* x;       // [n][S][S][4] pixel-major frames
@@ -81,6 +88,8 @@ struct MbStemArgs {       // fused stem -> block 1 (t = 1: depthwise + project) 
 void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s);
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
+bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw);
+void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s);
 
 // gru_scan.hip
 int adaf_gru_scan_blocks_per_cu();

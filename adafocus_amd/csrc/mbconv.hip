@@ -648,6 +648,195 @@ __global__ __launch_bounds__(256, 4) void mb_stem_b1_w_kernel(const MbStemArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// A whole stride-1 inverted-residual block per wave: expand 1x1 -> BN/ReLU6 -> depthwise 3x3 -> BN/ReLU6 -> project 1x1 -> BN
+// (+ identity), wave-private tiles of 4 x 8 outputs <- 6 x 10 halo pixels.  The 6x-expanded maps never exist in HBM: a block
+// reads cin and writes cout channels per pixel (b3: 24 + 24 (+24 identity) instead of 24 + 144 + 144 + 24 (+24)).  Per chunk
+// of 32 hidden channels: the expand products (two row bands), E through LDS 16 channels at a time, the taps on the VALU into
+// D = one k slice of the project conv's A operand, and 16 project MFMAs into accumulators that live across the chunks.
+// The project conv's k order is the conv engine's (slices of 32, a partial last slice zero-filled): bit-identical to the
+// three separate launches.
+template <int CIN>
+__global__ __launch_bounds__(256, 3) void mb_block_w_kernel(const MbFuseArgs a) {
+    constexpr int OTH = 4, OTW = 8, HH = OTH + 2, HW = OTW + 2, HP = HH * HW;
+    constexpr int EP = 16, DP = 36, KK = CIN / 8, HMAX = 192, SP = 36;
+    __shared__ __attribute__((aligned(16))) float Eall[4][64 * EP];
+    __shared__ __attribute__((aligned(16))) float Dall[4][32 * DP];     // D chunk; at the end the output transposition slab
+    __shared__ __attribute__((aligned(16))) float Wd[9 * HMAX];
+    __shared__ __attribute__((aligned(16))) float Bn[4 * HMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int idx = tid; idx < 9 * HMAX; idx += 256) {
+        const int t = idx / HMAX, c = idx - t * HMAX;
+        Wd[idx] = c < a.hid ? a.wd[(size_t)t * a.hid + c] : 0.f;
+    }
+    for (int idx = tid; idx < HMAX; idx += 256) {
+        const bool v = idx < a.hid;
+        Bn[idx] = v ? a.se[idx] : 0.f;
+        Bn[HMAX + idx] = v ? a.be[idx] : 0.f;
+        Bn[2 * HMAX + idx] = v ? a.sd[idx] : 0.f;
+        Bn[3 * HMAX + idx] = v ? a.bd[idx] : 0.f;
+    }
+    __syncthreads();
+    float* Ew = Eall[wave];
+    float* Dw = Dall[wave];
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.n * per_img) return;
+    const int img = tile / per_img;
+    const int rem = tile - img * per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int oy0 = ty * OTH, ox0 = tx * OTW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const bool inner = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= a.H && ix0 + HW <= a.W;
+    const int half = lane >> 5, nl = lane & 31;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 af[2][KK];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int p = 32 * b + nl;
+        const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+        const bool ok = p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const float* src = a.x + (((size_t)img * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * CIN + 4 * half;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) af[b][kk] = ok ? *reinterpret_cast<const f32x4*>(src + 8 * kk) : zero4;
+    }
+    unsigned emask = 0xffffffffu;
+    if (!inner) {
+        emask = 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+                if (p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) emask |= 1u << (16 * b + r);
+            }
+    }
+    f32x16 pa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+
+    for (int ch0 = 0; ch0 < a.hid; ch0 += 32) {
+        // filter rows of this chunk: expand (B fragments, row = hidden channel) and project (row = output channel, k = hidden)
+        const int nch = ch0 + nl;
+        f32x4 bf[KK], bp[4];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            bf[kk] = nch < a.hid ? *reinterpret_cast<const f32x4*>(a.we + (size_t)nch * CIN + 8 * kk + 4 * half) : zero4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = ch0 + 8 * kk + 4 * half;
+            bp[kk] = (nl < a.cout && k < a.hid) ? *reinterpret_cast<const f32x4*>(a.wp + (size_t)nl * a.hid + k) : zero4;
+        }
+        const float esc = Bn[ch0 + nl], ebi = Bn[HMAX + ch0 + nl];
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][kk][s4], bf[kk][s4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][kk][s4], bf[kk][s4], acc1, 0, 0, 0);
+            }
+        {
+            const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {       // the accumulators become the E values in place
+                const f32x2 v0 = __builtin_elementwise_fma(f32x2{acc0[r], acc0[r + 1]}, sc2, bi2);
+                const f32x2 v1 = __builtin_elementwise_fma(f32x2{acc1[r], acc1[r + 1]}, sc2, bi2);
+                acc0[r] = __builtin_amdgcn_fmed3f(v0.x, 0.f, 6.f);
+                acc0[r + 1] = __builtin_amdgcn_fmed3f(v0.y, 0.f, 6.f);
+                acc1[r] = __builtin_amdgcn_fmed3f(v1.x, 0.f, 6.f);
+                acc1[r + 1] = __builtin_amdgcn_fmed3f(v1.y, 0.f, 6.f);
+            }
+            if (!inner) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc0[r] = ((emask >> r) & 1u) ? acc0[r] : 0.f;
+                    acc1[r] = ((emask >> (16 + r)) & 1u) ? acc1[r] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_wave_barrier();        // earlier reads of E (and, for h = 0, of D) are issued
+            if ((nl >> 4) == h) {
+                float* e0 = Ew + (4 * half) * EP + (nl & 15);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ((r & 3) + 8 * (r >> 2)) * EP;
+                    e0[o] = acc0[r];
+                    e0[32 * EP + o] = acc1[r];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int c4 = lane & 3, ol = lane >> 2;
+            const int cg = 16 * h + 4 * c4;           // channel group inside the chunk
+            f32x2 k0[9], k1[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 kq = *reinterpret_cast<const f32x4*>(&Wd[t * HMAX + ch0 + cg]);
+                k0[t] = f32x2{kq.x, kq.y};
+                k1[t] = f32x2{kq.z, kq.w};
+            }
+            const f32x4 dsc = *reinterpret_cast<const f32x4*>(&Bn[2 * HMAX + ch0 + cg]);
+            const f32x4 dbi = *reinterpret_cast<const f32x4*>(&Bn[3 * HMAX + ch0 + cg]);
+            const f32x2 sc0 = {dsc.x, dsc.y}, sc1 = {dsc.z, dsc.w}, bi0 = {dbi.x, dbi.y}, bi1 = {dbi.z, dbi.w};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int o = 16 * q + ol;
+                const int oy = o >> 3, ox = o & 7;
+                const float* e = Ew + (oy * HW + ox) * EP + 4 * c4;
+                f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(e + (ky * HW + kx) * EP);
+                        s0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, k0[ky * 3 + kx], s0);
+                        s1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, k1[ky * 3 + kx], s1);
+                    }
+                const f32x2 r0 = __builtin_elementwise_fma(s0, sc0, bi0), r1 = __builtin_elementwise_fma(s1, sc1, bi1);
+                const f32x4 r = {__builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f),
+                                 __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f)};
+                *reinterpret_cast<f32x4*>(&Dw[o * DP + cg]) = r;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // project: pa += D[32 px x 32] * Wp[:, ch0 .. ch0 + 32]^T  (channels past `hid` are zeros on both sides)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 ad = *reinterpret_cast<const f32x4*>(&Dw[nl * DP + 8 * kk + 4 * half]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) pa = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s4], bp[kk][s4], pa, 0, 0, 0);
+        }
+    }
+    // ---- project BN (+ identity): through the slab so that stores (and identity loads) are 16 bytes per lane
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float psc = nl < a.cout ? a.sp[nl] : 0.f, pbi = nl < a.cout ? a.bp[nl] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dw[((r & 3) + 8 * (r >> 2) + 4 * half) * SP + nl] = fmaf(pa[r], psc, pbi);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cq = a.cout >> 2;             // 16-byte pieces per output pixel (cout % 4 == 0)
+    for (int i = lane; i < 32 * cq; i += 64) {
+        const int px = i / cq, c = i - px * cq;
+        const int gy = oy0 + (px >> 3), gx = ox0 + (px & 7);
+        if (gy < a.OH && gx < a.OW) {
+            const size_t g = (((size_t)img * a.OH + gy) * a.OW + gx) * a.cout + 4 * c;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Dw[px * SP + 4 * c]);
+            if (a.res) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + g);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            *reinterpret_cast<f32x4*>(a.out2 + g) = v;
+        }
+    }
+}
+
 }  // namespace
 
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw) { return cin % 8 == 0 && cin <= 32 && hid % 4 == 0 && hw >= 28; }
@@ -683,6 +872,22 @@ void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s) {
     const size_t smem = sizeof(float) * ((size_t)160 * (a.cin + 4) + 128 * 36);
     if (stride == 1) hipLaunchKernelGGL((mb_expand_dw_kernel<1>), dim3(blocks), dim3(256), smem, s, a);
     else hipLaunchKernelGGL((mb_expand_dw_kernel<2>), dim3(blocks), dim3(256), smem, s, a);
+}
+
+// whole-block kernel: stride-1 blocks with up to 32 output channels (b3, b5, b6 of MobileNetV2 1.0)
+bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw) {
+    return mb_wave_enabled() && stride == 1 && (cin == 16 || cin == 24 || cin == 32) && hid % 4 == 0 && hid <= 192 && cout % 4 == 0 &&
+           cout <= 32 && hw >= 28;
+}
+
+void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s) {
+    a.tiles_x = (a.OW + 7) / 8;
+    a.tiles_y = (a.OH + 3) / 4;
+    const long long tiles = (long long)a.n * a.tiles_x * a.tiles_y;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (a.cin == 16) hipLaunchKernelGGL((mb_block_w_kernel<16>), grid, block, 0, s, a);
+    else if (a.cin == 24) hipLaunchKernelGGL((mb_block_w_kernel<24>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((mb_block_w_kernel<32>), grid, block, 0, s, a);
 }
 
 void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s) {

@@ -37,6 +37,7 @@ struct adaf_mobilenetv2 {
     std::vector<MbBlock> blocks;
     int stem = 0, head = 0;
     bool fuse = true;       // expand -> depthwise in one kernel where the shape allows (mbconv.hip)
+    bool whole = true;      // ... and the whole stride-1 block (expand -> depthwise -> project + identity) where that shape allows
     int dtype = ADAF_DTYPE_F32;   // storage type of activations and 1x1 weights
     bool finalized = false;
     // Two frame chunks travel through the network side by side (the second on this library-owned stream, forked from and
@@ -189,6 +190,7 @@ int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on) {
     if (!net) return ADAF_E_BADARG;
     net->fuse = (on & 1) != 0;
     net->pair = (on & 4) == 0;     // bit 2 set: one frame chunk at a time (A/B)
+    net->whole = (on & 8) == 0;    // bit 3 set: expand -> depthwise kernel + project launch instead of the whole-block kernel (A/B)
     return ADAF_OK;
 }
 
@@ -363,6 +365,17 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
                     fa.we = E.w; fa.se = E.scale; fa.be = E.bias; fa.wd = D.w; fa.sd = D.scale; fa.bd = D.bias;
                     fa.out = bufD; fa.hid = hid; fa.OH = fa.OW = cdiv_out(hw, 3, b.stride, 1);
                     fa.zeros = net->h->zeros;
+                    const MbConv& P = net->convs[b.project];
+                    if (net->whole && adaf_mb_block_ok(b.inp, hid, b.oup, b.stride, hw) && P.cin_pad == hid) {
+                        // the whole block in one launch: neither expanded map reaches HBM
+                        fa.wp = P.w; fa.sp = P.scale; fa.bp = P.bias; fa.cout = b.oup;
+                        fa.res = residual ? cur : nullptr;
+                        fa.out2 = nxt;
+                        adaf_launch_mb_block(fa, st);
+                        float* t = cur; cur = nxt; nxt = t;
+                        hw = fa.OH;
+                        continue;
+                    }
                     adaf_launch_mb_expand_dw(fa, b.stride, st);
                 } else {
                     if ((rc = run_conv(net, E, ein, nc, hw, hw, ADAF_ACT_RELU6, nullptr, bufE, fused_T, tsm_div, st)))
