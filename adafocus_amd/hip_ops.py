@@ -417,7 +417,8 @@ class MobileNetV2Net:
 
     def set_fusion(self, on):
         """Expand 1x1 -> depthwise 3x3 in one kernel for the high-resolution blocks (default on)."""
-        # bit 0: fused kernels on; bit 2 (value 4): one frame chunk at a time instead of two side by side (A/B switch)
+        # bit 0: fused kernels on; bit 2 (value 4): one frame chunk at a time instead of two side by side; bit 3 (value 8):
+        # expand -> depthwise kernel + project launch instead of the whole-block kernel of b3 / b5 / b6 (A/B switches)
         L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, int(on)), self._h)
 
     def set_dtype(self, dtype):

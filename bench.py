@@ -522,7 +522,9 @@ def main():
                     torch.cuda.synchronize()
                     piped_ms = (time.perf_counter() - t1) / 9 * 1e3
                 ing_bytes = float(b * t * 224 * 224 * (3 + 16))
-                gl_bytes = float(b * t) * workload.mobilenetv2_bytes_per_frame(224, fused=True, fused_tail=model.glancer.net.fused_tail())
+                gl_fusion = int(model.glancer.net._engine.fusion)        # adaf_mobilenetv2_set_fusion bits (True = 1)
+                gl_bytes = float(b * t) * workload.mobilenetv2_bytes_per_frame(224, fused=bool(gl_fusion & 1), fused_tail=model.glancer.net.fused_tail(),
+                                                                                whole_blocks=not (gl_fusion & 8))
                 gl_flop = 2.0 * workload.mobilenetv2_macs_per_frame(224)
                 res["next_rows"] = {
                     "f1_ingest_u8": {"bound": "hbm", "ms": round(ing_ms, 4), "achieved": round(ing_bytes / ing_ms / 1e6, 1),

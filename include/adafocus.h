@@ -269,8 +269,11 @@ size_t adaf_mobilenetv2_workspace_bytes(const adaf_mobilenetv2* net, int n, int 
 int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, int n, int size, int tsm_segments,
                              int tsm_div, float* featmap, float* featvec, int ldvec, void* ws, size_t ws_bytes,
                              void* stream);
-/* Expand 1x1 -> depthwise 3x3 in one kernel (the 6x-expanded map stays on chip) for the blocks whose shape allows it
- * (cin % 8 == 0, cin <= 32, map >= 28^2: b2..b7 at 224^2).  On by default; off = the three-launch form (tests, A/B). */
+/* Bits of `on` (default 1): bit 0 -- fused kernels: stem + block 1 in one launch; expand 1x1 -> depthwise 3x3 in one kernel
+ * (the 6x-expanded map stays on chip) for the blocks whose shape allows it (cin % 8 == 0, cin <= 32, map >= 28^2: b2..b7 at
+ * 224^2); and, unless bit 3 (value 8) is set, the WHOLE stride-1 block (expand -> depthwise -> project + identity) in one
+ * kernel where cout <= 32 and hidden <= 192 (b3, b5, b6).  bit 2 (value 4): one frame chunk at a time instead of two side by
+ * side.  0 = the three-launch form.  Every combination is bit-identical (tests, A/B). */
 int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
 /* ADAF_DTYPE_F16: the whole network with fp16 activations and 1x1 weights in HBM (see N2 above; the 3x3 stem reads the
  * fp32 frames and stores fp16, the 1280-channel head stores fp32 for the consumers downstream; no temporal shift, no

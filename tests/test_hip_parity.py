@@ -721,8 +721,9 @@ def test_mobilenetv2_act_golden(dev):
 
 
 def test_mobilenetv2_fused_expand_dw_bit_identical(dev):
-    """mbconv.hip (expand 1x1 -> depthwise 3x3 in one kernel, b2..b7 at 224^2) against the three-launch form: same k
-    order in the expand GEMM, same tap order in the depthwise sum, so the feature maps agree bit for bit -- including
+    """mbconv.hip (stem + block 1, expand 1x1 -> depthwise 3x3 and whole stride-1 blocks in one kernel, b1..b7 at 224^2)
+    against the three-launch form: same k order in the GEMMs, same tap order in the depthwise sum, so the feature maps agree
+    bit for bit -- including
     partial edge tiles (200^2, 120^2) and the chunked pass (520 frames > one 512-frame chunk)."""
     from adafocus_amd.mobilenet import mobilenet_v2
     net = mobilenet_v2().eval()
@@ -733,12 +734,15 @@ def test_mobilenetv2_fused_expand_dw_bit_identical(dev):
         x4 = torch.zeros((n, size, size, 4), device=dev)
         x4[..., :3] = rnd((n, size, size, 3), 60 + size).to(dev)
         with torch.no_grad():
-            net._engine.fusion = True
+            net._engine.fusion = True       # wave-private kernels: stem + b1, whole blocks b3 / b5 / b6, expand -> depthwise b2 / b4 / b7
             fm1, fv1 = [t.clone() for t in net.features_from_nhwc4(x4)]
+            net._engine.fusion = 9          # bit 3: expand -> depthwise + a project launch instead of the whole-block kernel
+            fm9, fv9 = [t.clone() for t in net.features_from_nhwc4(x4)]
             net._engine.fusion = False
             fm0, fv0 = [t.clone() for t in net.features_from_nhwc4(x4)]
         net._engine.fusion = True
         assert torch.equal(fm1, fm0) and torch.equal(fv1, fv0), (n, size)
+        assert torch.equal(fm9, fm0) and torch.equal(fv9, fv0), (n, size)
         assert fm0.abs().max().item() > 0.1
 
 
