@@ -1023,9 +1023,10 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
 //   phase 3  the next block's conv1: out1[128 x N1] += chunk[128 x 32] * W1n[:, 32 pass .. +32]^T, accumulated across
 //            the passes in registers -- conv3's output is consumed on chip while it is being written to HBM once.
 // Every product keeps the k order of the unfused kernels, so the results are BIT-IDENTICAL to the three separate
-// launches (tests: test_resnet50_fused_stage1_bit_identical).  Two blocks fit a CU (66 / 74 KB of LDS), so one block's
-// HBM-heavy phase 2 overlaps the other's MFMA-heavy phase 1.  The next conv1 cannot ride along when it carries a fused
-// temporal shift (its rows come from other clips' frames): N1 = 0 then.
+// launches (tests: test_resnet50_fused_launches_bit_identical).  Three blocks fit a CU for N1 = 0 / 64 (48 KB of LDS: the
+// phase-2 image is exactly the phase-1 ring, the epilogue's transposition slab lives in the dead half of the A2 image), two
+// for N1 = 128 (56 KB), so one block's HBM-heavy phase 2 overlaps the others' MFMA-heavy phase 1.  The next conv1 cannot ride
+// along when it carries a fused temporal shift (its rows come from other clips' frames): N1 = 0 then.
 struct FusedTailArgs {
     ConvArgs c2;          // the 3x3 conv (x, w, scale, bias, geometry; N = 64, K = 9 * 64)
     const float* w3;      // [n3][64]
@@ -1046,7 +1047,7 @@ struct FusedTailArgs {
 // the stand-alone position-major conv kernel does (bit-identical).  Everything after phase 1 addresses its rows through the
 // row map (tile row r -> output row (m0 + r) * rstride + roff), so the two forms share phases 2 and 3.
 template <int N1, bool PM>
-__global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTailArgs fa) {
+__global__ __launch_bounds__(256, N1 == 128 ? 2 : 3) void conv_fused_tail_kernel(const FusedTailArgs fa) {
     constexpr int BM = 128, BN = 64, NW = 4, WGN = 2;
     constexpr int TM = 2, TN = 1;
     constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW), NI = AI + BI;
@@ -1058,13 +1059,17 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
     // whole slice early -- holds the W3 chunk buffer(s) and the W1n chunk; then the [2][128][32] A2 image (its first slice
     // doubles as the conv3-output chunk image)
     constexpr int W3OFF = 0;
-    constexpr bool W3DB = N1 != 128;                     // two W3 chunk buffers unless the 128-wide W1n chunk needs the room
+    // two W3 chunk buffers only when there is no W1n chunk to make room for: the N1 = 0 / 64 forms then need exactly the 48 KB
+    // of the phase-1 ring and THREE blocks fit a CU (the N1 = 128 form: 56 KB, two)
+    constexpr bool W3DB = N1 == 0;
     constexpr int W1OFF = (W3DB ? 2 : 1) * 2 * PW * 32;
     constexpr int A2OFF = W1OFF + N1 * 32;
     constexpr int XUSED = A2OFF + 2 * BM * 32;
     static_assert(A2OFF <= BM * 32 + BN * 32, "the weight chunk buffers must fit stage 0");
     constexpr int XSZ = XUSED > XREG ? XUSED : XREG;
-    constexpr int SLAB = NW * 32 * 36;
+    // the conv3 epilogue's transposition slab is the SECOND slice of the A2 image: every wave has its band's fragments in
+    // registers by then, and only the first slice lives on as the chunk image (pitch 32, 16-byte chunks XOR-ed with row & 7)
+    constexpr int SLAB = 0;
     __shared__ __attribute__((aligned(16))) float smem[XSZ + SLAB];
     const ConvArgs& a = fa.c2;
 
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
     float* A2 = smem + A2OFF;               // [2 slices][128 rows][32], chunk index XOR-ed with (row>>1)&7
     float* W3s = smem + W3OFF;              // [2 buffers][2 slices][32 rows][32]
     float* W1s = smem + W1OFF;              // [N1 rows][32]
-    float* slab = smem + XSZ + wave * 32 * 36;
+    float* slab = smem + A2OFF + BM * 32 + wave * 32 * 32;
     const bool full = m0 + BM <= rlimit;    // every lane stores in every pass: the counted waits below are exact
     const int c4 = lane & 7, rsub = lane >> 3;               // epilogue: 8 chunks of 4 channels per row, 8 rows per instruction
     // instruction u = j*4 + wave of a W3 chunk: slice u / 4, rows (u % 4) * 8 + lr.  Lane offsets are constants; the
@@ -1373,13 +1378,16 @@ __global__ __launch_bounds__(256, 2) void conv_fused_tail_kernel(const FusedTail
             const f32x2 sc0 = {sc.x, sc.y}, sc1 = {sc.z, sc.w}, bi0 = {bi.x, bi.y}, bi1 = {bi.z, bi.w};
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) slab[(crow + (r & 3) + 8 * (r >> 2)) * 36 + (lane & 31)] = acc3[r];
+            for (int r = 0; r < 16; ++r) {
+                const int srow = crow + (r & 3) + 8 * (r >> 2);
+                slab[srow * 32 + ((((lane & 31) >> 2) ^ (srow & 7)) << 2) + (lane & 3)] = acc3[r];
+            }
             __builtin_amdgcn_wave_barrier();
             f32x4 ov[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = u * 8 + rsub;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 36 + 4 * c4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 32 + ((c4 ^ (row & 7)) << 2));
                 const f32x2 p0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, sc0, bi0) + f32x2{rv[u].x, rv[u].y};
                 const f32x2 p1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, sc1, bi1) + f32x2{rv[u].z, rv[u].w};
                 const f32x4 o = {fmaxf(p0.x, 0.f), fmaxf(p0.y, 0.f), fmaxf(p1.x, 0.f), fmaxf(p1.y, 0.f)};
