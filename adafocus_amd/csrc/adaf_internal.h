@@ -42,6 +42,11 @@ struct ConvArgs {
     int vec_epi;         // 1: 16-byte epilogue is legal (aligned out/res/scale/bias, strides % 4 == 0)
     int in16, out16, res16;   // half-precision STORAGE (N2): x and w / out / res hold fp16 (strides stay in elements)
     int pm_allow;        // k x k convs: position-major tiles with padding-tap skipping may be used (bit-identical; default 1)
+    // two convs over the same input as ONE GEMM (filter banks concatenated along N): column tiles at n0 >= split_n write
+    // out_b[m * ldo_b + n] (out_b already displaced by -split_n) with activation act_b; 0 = off
+    int split_n;
+    float* out_b;
+    int ldo_b, act_b;
     int pm_images, pm_groups;   // set by the launcher: images in the batch, image groups of BM per pixel position
     int tiles_n;         // ceil(N / BN) for the chosen tile
     int nblocks;

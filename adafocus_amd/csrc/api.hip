@@ -55,6 +55,7 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
     a->wsp = nullptr;
     a->in16 = a->out16 = a->res16 = 0;
     a->pm_allow = h->conv_pos_major; a->pm_images = a->pm_groups = 0;
+    a->split_n = 0; a->out_b = nullptr; a->ldo_b = 0; a->act_b = 0;
     a->x = x; a->w = w; a->scale = scale; a->bias = bias; a->res = res; a->out = out;
     a->M = (int)M; a->N = p->cout; a->K = p->kh * p->kw * p->cin;
     a->cin = p->cin; a->H = p->h; a->W = p->w; a->OH = oh; a->OW = ow; a->KH = p->kh; a->KW = p->kw;
@@ -398,6 +399,11 @@ struct adaf_resnet50 {
     std::map<std::string, std::pair<const float*, size_t>> params;
     std::vector<ConvLayer> convs;  // [0] = stem, then per block conv1, conv2, conv3, (downsample)
     std::vector<int> tiles;        // per conv launch override
+    // layer1.0's conv1 (64 -> 64) and downsample (64 -> 256) read the same map with the same 1x1 / stride-1 geometry: their
+    // filter banks and BN affines concatenated along the output channels, for one launch instead of two (run_trunk)
+    float* l10_w = nullptr;
+    float* l10_scale = nullptr;
+    float* l10_bias = nullptr;
     int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
     bool fuse = true;              // stage 1: conv2 -> conv3 (-> next conv1) in one launch; stem + max-pool in one launch
     bool fuse_stem_always = false; // (tests) take the fused stem launch at every patch size, not only where it is faster
@@ -518,12 +524,36 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             const int i_c2 = li + 1, i_c3 = li + 2, i_ds = li + 3;
             const int i_next = li + 3 + (b == 0 ? 1 : 0);          // the next block's conv1 (or convs.size())
             // conv1 (1x1, optional fused temporal shift) -> conv2 (3x3, stride) -> conv3 (1x1) + identity
-            if (!c1_done) {
+            bool ds_done = false;
+            if (s == 0 && b == 0 && !c1_done && net->fuse && net->l10_w && tsm_T == 0 && net->math == ADAF_MATH_F32 &&
+                !net->tiles[li] && !net->tiles[i_ds]) {
+                // layer1.0: conv1 and the downsample conv in ONE launch (same input, same 1x1 geometry; N = 64 + 256): the
+                // pooled map is read once instead of twice and a 0.07 ms launch disappears.  128x64 tiles: column tile 0 is conv1.
+                const ConvLayer &C1 = net->convs[li], &DS = net->convs[i_ds];
+                adaf_conv_params p;
+                memset(&p, 0, sizeof(p));
+                p.n = n; p.h = hh; p.w = ww; p.cin = C1.cin_pad; p.cout = C1.cout + DS.cout; p.kh = p.kw = 1; p.stride = 1; p.pad = 0;
+                p.act = ADAF_ACT_RELU;
+                ConvArgs am;
+                if ((rc = make_conv_args(h, &p, cur, net->l10_w, net->l10_scale, net->l10_bias, nullptr, t1, &am))) return rc;
+                am.ldo = C1.cout;                       // conv1's output rows are 64 wide
+                am.split_n = C1.cout;
+                am.out_b = buf[4] - C1.cout;            // column n of the merged GEMM is channel n - 64 of the downsample output
+                am.ldo_b = DS.cout;
+                am.act_b = ADAF_ACT_NONE;
+                const double M = (double)am.M;
+                mark(2.0 * M * (C1.cout + DS.cout) * C1.cin, 4.0 * (M * C1.cin + M * (C1.cout + DS.cout) + (double)(C1.cout + DS.cout) * C1.cin), 93);
+                if (adaf_launch_conv_gemm(am, 32, h->cus, st) < 0) return fail(h, ADAF_E_LAUNCH, "resnet50: merged layer1.0 launch");
+                h1 = am.OH; w1 = am.OW;
+                ++li;
+                ds_done = true;
+            } else if (!c1_done) {
                 if ((rc = conv(cur, hh, ww, ADAF_ACT_RELU, nullptr, t1, tsm_T > 0, &h1, &w1, 0))) return rc;
             } else ++li;
             c1_done = false;
             const float* identity = cur;
-            if (b == 0) {
+            if (b == 0 && ds_done) identity = buf[4];
+            else if (b == 0) {
                 li = i_ds;
                 int hd, wd;
                 if ((rc = conv(cur, hh, ww, ADAF_ACT_NONE, nullptr, buf[4], 0, &hd, &wd, 0))) return rc;
@@ -586,6 +616,9 @@ int adaf_resnet50_create(adaf_handle* h, adaf_resnet50** out) {
 int adaf_resnet50_destroy(adaf_resnet50* net) {
     if (!net) return ADAF_OK;
     if (net->stem_w) (void)hipFree(net->stem_w);
+    if (net->l10_w) (void)hipFree(net->l10_w);
+    if (net->l10_scale) (void)hipFree(net->l10_scale);
+    if (net->l10_bias) (void)hipFree(net->l10_bias);
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
         if (L.wsp) (void)hipFree(L.wsp);
@@ -649,6 +682,23 @@ int adaf_resnet50_finalize(adaf_resnet50* net, void* stream) {
             if (!net->stem_w && hipMalloc(reinterpret_cast<void**>(&net->stem_w), adaf_stem_weight_floats() * sizeof(float)) != hipSuccess)
                 return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc stem weights");
             adaf_launch_pack_stem_weight(w, net->stem_w, st);
+        }
+    }
+    {   // conv1 ++ downsample of layer1.0 (convs[1] and convs[4]: 1x1, stride 1, 64 input channels)
+        const ConvLayer &C1 = net->convs[1], &DS = net->convs[4];
+        if (C1.k == 1 && DS.k == 1 && C1.stride == 1 && DS.stride == 1 && C1.cin_pad == DS.cin_pad && C1.cout % 64 == 0) {
+            const size_t n1 = (size_t)C1.cout * C1.cin_pad, n2 = (size_t)DS.cout * DS.cin_pad;
+            const int cm = C1.cout + DS.cout;
+            if ((!net->l10_w && hipMalloc(reinterpret_cast<void**>(&net->l10_w), (n1 + n2) * sizeof(float)) != hipSuccess) ||
+                (!net->l10_scale && hipMalloc(reinterpret_cast<void**>(&net->l10_scale), cm * sizeof(float)) != hipSuccess) ||
+                (!net->l10_bias && hipMalloc(reinterpret_cast<void**>(&net->l10_bias), cm * sizeof(float)) != hipSuccess))
+                return fail(h, ADAF_E_NOMEM, "resnet50: hipMalloc merged layer1.0 filters");
+            (void)hipMemcpyAsync(net->l10_w, C1.w, n1 * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(net->l10_w + n1, DS.w, n2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(net->l10_scale, C1.scale, C1.cout * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(net->l10_scale + C1.cout, DS.scale, DS.cout * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(net->l10_bias, C1.bias, C1.cout * sizeof(float), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(net->l10_bias + C1.cout, DS.bias, DS.cout * sizeof(float), hipMemcpyDeviceToDevice, st);
         }
     }
     hipError_t e = hipStreamSynchronize(st);

@@ -70,9 +70,12 @@ __device__ __forceinline__ float finish_act(float v, bool sig) { return sig ? 1.
 // Default (1, 0, a.M): the tile's rows are consecutive output pixels.  Position-major tiles (PM kernels): ml = image index,
 // rstride = OH*OW, roff = the tile's pixel position, rlimit = number of images.
 template <int TM, int TN, int ET = 0>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0,
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a0, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0,
                                               int wm, int wn, int lane, int wave, int rstride = 1, int roff = 0, int rlimit = -1) {
     constexpr bool O16 = (ET & 1) != 0, R16 = (ET & 2) != 0;
+    // a launch that carries two convs over the same input (ConvArgs::split_n): this column tile's destination and activation
+    ConvArgs a = a0;
+    if (a0.split_n && n0 >= a0.split_n) { a.out = a0.out_b; a.ldo = a0.ldo_b; a.act = a0.act_b; }
     if (rlimit < 0) rlimit = a.M;
     const bool sig = a.act == ADAF_ACT_SIGMOID;
     const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;

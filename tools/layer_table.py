@@ -32,7 +32,8 @@ trunk.set_fusion(fuse)
 for _ in range(2):
     trunk.forward(x, tsm_segments=tsm) if tsm else trunk.forward(x)
 runs = [trunk.profile(x, tsm_segments=tsm) for _ in range(5)]
-# launch names follow the plan: tile 90 = stem + max-pool in one launch, 91 = conv2 -> conv3, 92 = conv2 -> conv3 -> next conv1
+# launch names follow the plan: tile 90 = stem + max-pool in one launch, 91 = conv2 -> conv3, 92 = conv2 -> conv3 -> next conv1,
+# 93 = layer1.0's conv1 + downsample conv in one launch
 order = []
 for li, nb in enumerate((3, 4, 6, 3), 1):
     for b in range(nb):
@@ -45,11 +46,13 @@ if e["tile"] != 90:
     next(it)
     names.append("maxpool")
 for blk, has_ds in order:
+    merged = False
     if not skip_c1:
-        next(it)
-        names.append(blk + ".c1")
+        e = next(it)
+        merged = e["tile"] == 93          # layer1.0: conv1 and the downsample conv in one launch
+        names.append(blk + (".c1+ds" if merged else ".c1"))
     skip_c1 = False
-    if has_ds:
+    if has_ds and not merged:
         next(it)
         names.append(blk + ".ds")
     e = next(it)
