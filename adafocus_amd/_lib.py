@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadafocus_hip.so")
 
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3, 4
 MATH_F32, MATH_F32_SPLIT_BF16 = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
 CONV_TILES = 4
@@ -32,6 +32,9 @@ SYMBOLS = (
     "adaf_mobilenetv2_forward", "adaf_mobilenetv2_set_fusion", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
     "adaf_crop_gather_nhwc4_f32", "adaf_ingest_u8_f32", "adaf_crop_resize_f32", "adaf_resize_nearest_f32",
     "adaf_conv2d_bn_act_f16", "adaf_pack_conv_weight_f16", "adaf_cast_f32_f16", "adaf_dwconv3x3_bn_act_f16", "adaf_mobilenetv2_set_dtype",
+    "adaf_pack_dw_weight_kxk_f32", "adaf_dwconv_same_workspace_bytes", "adaf_dwconv_same_bn_act", "adaf_se_gate_f32", "adaf_conv1x1_gated_bn",
+    "adaf_effnet_create", "adaf_effnet_destroy", "adaf_effnet_feature_dim", "adaf_effnet_block_count", "adaf_effnet_block_info",
+    "adaf_effnet_set_dtype", "adaf_effnet_set_param", "adaf_effnet_finalize", "adaf_effnet_workspace_bytes", "adaf_effnet_forward",
 )
 
 
@@ -111,6 +114,23 @@ def load_library():
     lib.adaf_cast_f32_f16.argtypes = [vp, vp, C.c_size_t, vp, ip, vp]
     lib.adaf_dwconv3x3_bn_act_f16.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp]
     lib.adaf_mobilenetv2_set_dtype.argtypes = [vp, ip]
+    lib.adaf_pack_dw_weight_kxk_f32.argtypes = [vp, vp, ip, ip, vp, vp]
+    lib.adaf_dwconv_same_workspace_bytes.restype = C.c_size_t
+    lib.adaf_dwconv_same_workspace_bytes.argtypes = [ip, ip, ip, ip, ip, ip, ip]
+    lib.adaf_dwconv_same_bn_act.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp, vp, C.c_size_t, vp]
+    lib.adaf_se_gate_f32.argtypes = [vp, vp, ip, ip, vp, vp, ip, vp, vp, vp, vp]
+    lib.adaf_conv1x1_gated_bn.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp, vp, vp, vp]
+    lib.adaf_effnet_create.argtypes = [vp, fp, fp, C.POINTER(vp)]
+    lib.adaf_effnet_destroy.argtypes = [vp]
+    lib.adaf_effnet_feature_dim.argtypes = [vp]
+    lib.adaf_effnet_block_count.argtypes = [vp]
+    lib.adaf_effnet_block_info.argtypes = [vp, ip, C.POINTER(C.c_int)]
+    lib.adaf_effnet_set_dtype.argtypes = [vp, ip]
+    lib.adaf_effnet_set_param.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    lib.adaf_effnet_finalize.argtypes = [vp, vp]
+    lib.adaf_effnet_workspace_bytes.restype = C.c_size_t
+    lib.adaf_effnet_workspace_bytes.argtypes = [vp, ip, ip, ip]
+    lib.adaf_effnet_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, vp, ip, vp, C.c_size_t, vp]
     _lib = lib
     return lib
 

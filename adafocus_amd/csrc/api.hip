@@ -39,7 +39,7 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
     const int ldx = p->ldx ? p->ldx : p->cin, ldo = p->ldo ? p->ldo : p->cout, ldr = p->ldr ? p->ldr : p->cout;
     if (ldx < p->cin || ldo < p->cout || ldr < p->cout) return fail(h, ADAF_E_BADARG, "conv: pixel stride smaller than channels");
     if (ldx % 4 || !aligned16(x) || !aligned16(w)) return fail(h, ADAF_E_LAYOUT, "conv: x/w must be 16-byte aligned, ldx % 4 == 0");
-    if (p->act < ADAF_ACT_NONE || p->act > ADAF_ACT_SIGMOID) return fail(h, ADAF_E_BADARG, "conv: unknown activation %d", p->act);
+    if (p->act < ADAF_ACT_NONE || p->act > ADAF_ACT_SWISH) return fail(h, ADAF_E_BADARG, "conv: unknown activation %d", p->act);
     const int oh = conv_out(p->h, p->kh, p->stride, p->pad), ow = conv_out(p->w, p->kw, p->stride, p->pad);
     if (oh <= 0 || ow <= 0) return fail(h, ADAF_E_BADARG, "conv: empty output");
     const long long M = (long long)p->n * oh * ow;

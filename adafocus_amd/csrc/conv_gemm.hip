@@ -61,7 +61,12 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float finish_act(float v, bool sig) { return sig ? 1.f / (1.f + expf(-v)) : v; }
+// sig: 0 = nothing left to do, 1 = sigmoid, 2 = swish (v * sigmoid(v); efficientnet_pytorch utils.py MemoryEfficientSwish)
+__device__ __forceinline__ float finish_act(float v, int sig) {
+    if (sig == 0) return v;
+    const float g = 1.f / (1.f + expf(-v));
+    return sig == 1 ? g : v * g;
+}
 
 // ---- epilogue shared by both kernel families: BN affine, residual, activation ---------------
 // C layout of the MFMA: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5).
@@ -77,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a0, float* smem, f
     ConvArgs a = a0;
     if (a0.split_n && n0 >= a0.split_n) { a.out = a0.out_b; a.ldo = a0.ldo_b; a.act = a0.act_b; }
     if (rlimit < 0) rlimit = a.M;
-    const bool sig = a.act == ADAF_ACT_SIGMOID;
+    const int sig = a.act == ADAF_ACT_SIGMOID ? 1 : a.act == ADAF_ACT_SWISH ? 2 : 0;
     const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
     const int crow = 4 * (lane >> 5);
@@ -1477,6 +1482,7 @@ __global__ void conv_naive_kernel(const ConvArgs a) {
     if (a.act == ADAF_ACT_RELU) v = fmaxf(v, 0.f);
     else if (a.act == ADAF_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
     else if (a.act == ADAF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    else if (a.act == ADAF_ACT_SWISH) v = v / (1.f + expf(-v));
     a.out[(size_t)m * a.ldo + n] = v;
 }
 

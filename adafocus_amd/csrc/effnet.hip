@@ -1,0 +1,951 @@
+// EfficientNet (B0..B7 by compound scaling; B3 = BASELINE.json config 5's local CNN) as one object: MBConv blocks with
+// squeeze-and-excite, swish, 3x3 / 5x5 depthwise convolutions with TensorFlow-SAME (asymmetric) padding, BN eps 1e-3.
+//
+// PARITY UNPINNED.  The reference has no EfficientNet on a live path: STH/ops/models_ada.py:6,69-75 imports the third-party,
+// un-vendored, un-pinned `efficientnet_pytorch` in dead AR-Net code, and STH/ops/net_flops_table.py:17,29 lists
+// "efficientnet-b3": feature dim 1536, (1.80 GFLOPs, 12 M params).  What is built here is the published algorithm of that
+// package (model.py MBConvBlock.forward / EfficientNet.extract_features, utils.py round_filters / round_repeats /
+// Conv2dStaticSamePadding / MemoryEfficientSwish), restated on the CPU by oracle/ref_effnet.py.
+//
+// Launch plan per block (activations NHWC, fp32 or fp16 storage; accumulation, BN affine, swish, SE always fp32):
+//   expand 1x1 + BN + swish           conv engine (conv_gemm.hip; fp16-operand DMA tiles in the fp16 mode)
+//   depthwise k x k + BN + swish      dw_same_kernel: input tile staged once in LDS, OXT outputs per thread along x, and the
+//                                     squeeze (global average pool) as per-block partial sums -- reduced in a fixed order, no
+//                                     atomics, so the result is deterministic
+//   squeeze -> FC -> swish -> FC -> sigmoid   se_gate_kernel, one block per image (wave-shuffle dot products)
+//   project 1x1 + BN (+ identity)     gated_project_kernel: the SE gate multiplies the A operand on its way from HBM to LDS
+//                                     (sigmoid(s) * x, then the conv -- the reference's order), MFMA, BN + identity epilogue
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "adaf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// ---- 16-byte chunks of activations: 4 floats or 8 halfs ---------------------------------------------------------------
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void unpack(const u32x4 u, float (&f)[4]) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&f)[4]) {
+        return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    }
+};
+template <> struct Chunk<_Float16> {
+    static constexpr int V = 8;
+    static __device__ __forceinline__ void unpack(const u32x4 u, float (&f)[8]) {
+        const f16x8 h = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e];
+        return __builtin_bit_cast(u32x4, h);
+    }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ADAF_ACT_SWISH) return v / (1.f + expf(-v));
+    if (act == ADAF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    if (act == ADAF_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ADAF_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+// ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
+struct DwArgs {
+    const void* x;       // [n][H][W][C]
+    void* out;           // [n][OH][OW][C]
+    const float* wt;     // [K*K][C] taps
+    const float* scale;  // [C] folded BN
+    const float* bias;
+    float* pool_part;    // [n][tiles][C] sums of the activated outputs over the block's pixels, or nullptr
+    int n, H, W, C, OH, OW;
+    int pad_t, pad_l;    // padding BEFORE the first row / column (SAME padding is asymmetric: the rest falls off the far edge)
+    int act;
+    int TH, tiles;       // output rows per block, blocks per image along y
+    int LPP, CS, slices; // lanes (16-byte chunks) per pixel in a block's channel slice, channels per slice, slices per pixel
+    int pitch16;         // LDS pixel pitch in 16-byte units (>= LPP; chosen so neighbouring thread groups hit different banks)
+    int WP;              // staged columns: ((ceil(OW / OXT) * OXT - 1) * S + K)
+};
+
+template <int K, int S, int OXT, typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 : 4, 8))) void dw_same_kernel(const DwArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int NC = (OXT - 1) * S + K;    // input columns the OXT outputs of a thread touch
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int slice = bid % a.slices; bid /= a.slices;
+    const int tile = bid % a.tiles;
+    const int img = bid / a.tiles;
+    const int c0 = slice * a.CS;
+    const int oy0 = tile * a.TH;
+    const int th = min(a.TH, a.OH - oy0);
+    const int ihn = (th - 1) * S + K;        // staged input rows
+    const int iy0 = oy0 * S - a.pad_t, ix0 = -a.pad_l;
+    const int pitchB = a.pitch16 * 16;
+    char* xin = dsm;                                                         // [ihn][WP][pitch16 * 16 B]
+    float* wl = reinterpret_cast<float*>(dsm + (size_t)((a.TH - 1) * S + K) * a.WP * pitchB);   // [K*K][CS]
+    for (int i = tid; i < K * K * a.CS; i += 256) wl[i] = a.wt[(size_t)(i / a.CS) * a.C + c0 + i % a.CS];
+    float* sbl = wl + K * K * a.CS;                                          // [2][CS] BN scale, bias (read back in the epilogue:
+    for (int i = tid; i < 2 * a.CS; i += 256)                                //  16 fewer live registers through the tap loop)
+        sbl[i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
+    {
+        const T* xb = static_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.C + c0;
+        const int items = ihn * a.WP * a.LPP;
+        for (int i = tid; i < items; i += 256) {
+            const int cg = i % a.LPP, p = i / a.LPP;
+            const int col = p % a.WP, row = p / a.WP;
+            const int iy = iy0 + row, ix = ix0 + col;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.C + cg * V);
+            *reinterpret_cast<u32x4*>(xin + (size_t)p * pitchB + cg * 16) = v;
+        }
+    }
+    __syncthreads();
+    const int NT = (256 / a.LPP) * a.LPP;   // active threads: a thread keeps ONE channel group for all of its items
+    const int cg = tid % a.LPP;
+    float psum[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) psum[e] = 0.f;
+    if (tid < NT) {
+        const int nxg = (a.OW + OXT - 1) / OXT;
+        const int items = th * nxg * a.LPP;
+        T* ob = static_cast<T*>(a.out) + ((size_t)img * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
+        for (int i = tid; i < items; i += NT) {
+            const int g = i / a.LPP;
+            const int xg = g % nxg, r = g / nxg;
+            const int ox0 = xg * OXT;
+            float acc[OXT][V];
+#pragma unroll
+            for (int o = 0; o < OXT; ++o)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                // the K taps of this filter row, then every staged column once: column ci feeds output o through tap
+                // kx = ci - o * S (resolved at compile time), so each LDS value is read and converted exactly once
+                const char* rowp = xin + ((size_t)(r * S + ky) * a.WP + ox0 * S) * pitchB + cg * 16;
+                float w[K][V];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* wp = wl + (ky * K + kx) * a.CS + cg * V;
+#pragma unroll
+                    for (int e = 0; e < V; e += 4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
+                        w[kx][e] = w4.x; w[kx][e + 1] = w4.y; w[kx][e + 2] = w4.z; w[kx][e + 3] = w4.w;
+                    }
+                }
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) {
+                    float xf[V];
+                    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * pitchB), xf);
+#pragma unroll
+                    for (int o = 0; o < OXT; ++o) {
+                        const int kx = ci - o * S;
+                        if (kx >= 0 && kx < K) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], w[kx][e], acc[o][e]);
+                        }
+                    }
+                }
+            }
+            float sc[V], bi[V];
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + cg * V + e), b4 = *reinterpret_cast<const f32x4*>(sbl + a.CS + cg * V + e);
+                sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
+                bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
+            }
+#pragma unroll
+            for (int o = 0; o < OXT; ++o) {
+                if (ox0 + o < a.OW) {
+                    float v[V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
+                        psum[e] += v[e];
+                    }
+                    *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.C) = Chunk<T>::pack(v);
+                }
+            }
+        }
+    }
+    if (a.pool_part) {
+        // squeeze: sum over the block's pixels per channel, in a fixed order (thread partials in LDS, then one thread per channel)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(dsm);     // [256][V] (the input tile is dead)
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[tid * V + e] = psum[e];
+        __syncthreads();
+        if (tid < a.CS) {
+            const int g = tid / V, e = tid % V;
+            float s = 0.f;
+            for (int t = g; t < NT; t += a.LPP) s += red[t * V + e];
+            a.pool_part[((size_t)img * a.tiles + tile) * a.C + c0 + tid] = s;
+        }
+    }
+}
+
+// mean[n][c] = sum_t part[n][t][c] / hw  (the stand-alone op's squeeze output)
+__global__ void pool_finish_kernel(const float* __restrict__ part, int n, int tiles, int c, float inv_hw, float* __restrict__ mean) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c) return;
+    const int img = idx / c, ch = idx - img * c;
+    float s = 0.f;
+    for (int t = 0; t < tiles; ++t) s += part[((size_t)img * tiles + t) * c + ch];
+    mean[idx] = s * inv_hw;
+}
+
+// ---- squeeze-and-excite gate: gate[n][c] = sigmoid(W_e swish(W_r mean[n] + b_r) + b_e) ----------------------------------
+// model.py MBConvBlock.forward: x_squeezed = adaptive_avg_pool2d(x, 1); _se_reduce -> swish -> _se_expand; sigmoid(.) * x.
+// One block per image.  part [n][tiles][C] partial sums (tiles = 1, inv_hw = 1 for a ready-made mean).
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int tiles, float inv_hw, int C,
+                                                      const float* __restrict__ wr, const float* __restrict__ br, int SQ,
+                                                      const float* __restrict__ we, int we_ldc, int we_ldj,
+                                                      const float* __restrict__ be, float* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    float* mean = reinterpret_cast<float*>(dsm);   // [C]
+    float* sq = mean + C;                          // [SQ]
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < tiles; ++t) s += part[((size_t)img * tiles + t) * C + c];
+        mean[c] = s * inv_hw;
+    }
+    __syncthreads();
+    for (int j = wave; j < SQ; j += 4) {
+        const float* w = wr + (size_t)j * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(mean[c], w[c], s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            const float v = s + br[j];
+            sq[j] = v / (1.f + expf(-v));
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = be[c];
+        for (int j = 0; j < SQ; ++j) s = fmaf(sq[j], we[(size_t)c * we_ldc + (size_t)j * we_ldj], s);
+        gate[(size_t)img * C + c] = 1.f / (1.f + expf(-s));
+    }
+}
+
+// ---- project 1x1 with the SE gate on the A operand + BN (+ identity) ---------------------------------------------------
+// out[m, n] = (sum_k (x[m, k] * gate[m / HW, k]) * w[n, k]) * scale[n] + bias[n] (+ res[m, n])
+// Block = 128 rows x (32 TN) columns, four waves stacked along M, K walked in 128-byte slices (32 floats / 64 halfs) through
+// ONE LDS stage with the next slice prefetched in registers -- the gate multiply happens on that register copy.
+struct ProjArgs {
+    const void* x;        // [M][K]
+    const float* gate;    // [M / HW][K] or nullptr (plain 1x1 conv)
+    const void* w;        // [N][K], same element type as x
+    const float* scale;   // [N] or nullptr
+    const float* bias;    // [N] or nullptr
+    const void* res;      // [M][N] or nullptr, same element type as out
+    void* out;            // [M][N]
+    int M, N, K, HW;
+};
+
+template <typename T, int TN>
+__global__ __launch_bounds__(256) void gated_project_kernel(const ProjArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int BKE = 8 * V;               // k elements per slice
+    constexpr int LDP = 36;                  // LDS row pitch in 32-bit words (128 B + 16 B pad: conflict-free b128 access)
+    constexpr int BM = 128, BN = 32 * TN;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int q = tid & 7, r = tid >> 3;     // 16-byte chunk of the slice, row inside a 32-row staging pass
+    const T* xb = static_cast<const T*>(a.x);
+    const T* wb = static_cast<const T*>(a.w);
+    const T* arow[4];
+    const float* grow[4];
+    bool aok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + r + 32 * p;
+        aok[p] = m < a.M;
+        const int mm = aok[p] ? m : 0;
+        arow[p] = xb + (size_t)mm * a.K;
+        grow[p] = a.gate ? a.gate + (size_t)(mm / a.HW) * a.K : nullptr;
+    }
+    const T* brow[TN];
+    bool bok[TN];
+#pragma unroll
+    for (int p = 0; p < TN; ++p) {
+        const int n = n0 + r + 32 * p;
+        bok[p] = n < a.N;
+        brow[p] = wb + (size_t)(bok[p] ? n : 0) * a.K;
+    }
+    u32x4 ra[4], rb[TN];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BKE + q * V;
+        const bool kok = k0 < a.K;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (aok[p] && kok) {
+                v = *reinterpret_cast<const u32x4*>(arow[p] + k0);
+                if (a.gate) {
+                    float f[V];
+                    Chunk<T>::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < V; e += 4) {
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(grow[p] + k0 + e);
+                        f[e] *= g.x; f[e + 1] *= g.y; f[e + 2] *= g.z; f[e + 3] *= g.w;
+                    }
+                    v = Chunk<T>::pack(f);
+                }
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < TN; ++p) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (bok[p] && kok) v = *reinterpret_cast<const u32x4*>(brow[p] + k0);
+            rb[p] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(&smem[(r + 32 * p) * LDP + q * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < TN; ++p) *reinterpret_cast<u32x4*>(&smem[(BM + r + 32 * p) * LDP + q * 4]) = rb[p];
+    };
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    const int nk = (a.K + BKE - 1) / BKE;
+    const float* As = smem + (wave * 32 + (lane & 31)) * LDP + (lane >> 5) * 4;
+    const float* Bs = smem + (BM + (lane & 31)) * LDP + (lane >> 5) * 4;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();             // the previous slice has been consumed
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(As + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDP + kk * 8);
+                if constexpr (sizeof(T) == 2) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf), acc[j], 0, 0, 0);
+                } else {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue.  C layout: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    T* ob = static_cast<T*>(a.out);
+    const T* rs = static_cast<const T*>(a.res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        if (n >= a.N) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f, bi = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (m >= a.M) continue;
+            float v = fmaf(acc[j][i], sc, bi);
+            if (rs) v += (float)rs[(size_t)m * a.N + n];
+            ob[(size_t)m * a.N + n] = (T)v;
+        }
+    }
+}
+
+// [C,1,K,K] (PyTorch depthwise) -> [K*K][C]
+__global__ void pack_dw_kxk_kernel(const float* __restrict__ w, int c, int kk, float* __restrict__ o) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kk * c) return;
+    const int ch = idx % c, tap = idx / c;
+    o[idx] = w[(size_t)ch * kk + tap];
+}
+// [R][C] -> [C][R]
+__global__ void transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ o) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int r = idx / cols, c = idx - r * cols;
+    o[(size_t)c * rows + r] = w[idx];
+}
+// mean over hw pixels of an fp16 / fp32 NHWC map -> fp32 [n][ldo]
+template <typename T>
+__global__ void avgpool_any_kernel(const T* __restrict__ x, int n, int hw, int c, float* __restrict__ o, int ldo) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c) return;
+    const int ch = idx % c, img = idx / c;
+    float s = 0.f;
+    const T* p = x + (size_t)img * hw * c + ch;
+    for (int i = 0; i < hw; ++i) s += (float)p[(size_t)i * c];
+    o[(size_t)img * ldo + ch] = s / (float)hw;
+}
+
+// ---- launch planning ---------------------------------------------------------------------------------------------------
+struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, tiles; size_t lds; };
+
+const size_t kDwLdsBudget = 40 * 1024;
+
+bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
+    p->V = 16 / esize;
+    if (C % p->V) return false;
+    const int chunks = C / p->V;
+    p->LPP = 1;
+    for (int d = 8; d >= 1; --d)
+        if (chunks % d == 0) { p->LPP = d; break; }
+    p->CS = p->LPP * p->V;
+    p->slices = C / p->CS;
+    p->OXT = OW % 4 == 0 ? 4 : OW % 3 == 0 ? 3 : OW % 5 == 0 ? 5 : 4;
+    const int nxg = (OW + p->OXT - 1) / p->OXT;
+    p->WP = (nxg * p->OXT - 1) * S + K;
+    // neighbouring thread groups (x groups, OXT * S pixels apart) should land half an LDS bank cycle (128 B) apart
+    p->pitch16 = p->LPP;
+    for (int t = p->LPP; t <= p->LPP + 8; ++t)
+        if ((p->OXT * S * t) % 16 == 8) { p->pitch16 = t; break; }
+    const size_t fixed = (size_t)(K * K + 2) * p->CS * 4;
+    auto bytes = [&](int th) { return (size_t)((th - 1) * S + K) * p->WP * p->pitch16 * 16 + fixed; };
+    int th = OH;
+    while (th > 1 && bytes(th) > kDwLdsBudget) --th;
+    if (bytes(th) > 64 * 1024) return false;
+    // even tiles
+    p->tiles = (OH + th - 1) / th;
+    p->TH = (OH + p->tiles - 1) / p->tiles;
+    p->tiles = (OH + p->TH - 1) / p->TH;
+    p->lds = bytes(p->TH);
+    const size_t red = (size_t)256 * p->V * 4;
+    if (p->lds < red) p->lds = red;
+    return true;
+}
+
+template <int K, int S, typename T>
+void launch_dw_oxt(const DwArgs& a, int oxt, size_t lds, hipStream_t s) {
+    const dim3 grid((unsigned)((size_t)a.n * a.tiles * a.slices)), block(256);
+    if (oxt == 3) hipLaunchKernelGGL((dw_same_kernel<K, S, 3, T>), grid, block, lds, s, a);
+    else if (oxt == 5) hipLaunchKernelGGL((dw_same_kernel<K, S, 5, T>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((dw_same_kernel<K, S, 4, T>), grid, block, lds, s, a);
+}
+
+template <typename T>
+bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, size_t lds, hipStream_t s) {
+    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T>(a, oxt, lds, s);
+    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T>(a, oxt, lds, s);
+    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T>(a, oxt, lds, s);
+    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T>(a, oxt, lds, s);
+    else return false;
+    return true;
+}
+
+}  // namespace
+
+// Depthwise k x k (k = 3 | 5, stride 1 | 2), padding pad_t / pad_l before the first row / column and whatever the output
+// extent needs after the last; returns the number of partial-sum tiles per image (> 0) or < 0.
+// pool_part: [n][tiles][c] floats (adaf_effnet_dw_tiles() says how many) or nullptr.
+int adaf_effnet_dw_tiles(int c, int oh, int ow, int k, int stride, int dtype) {
+    DwPlan p;
+    if (!plan_dw(c, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
+    return p.tiles;
+}
+
+int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, int pad_t, int pad_l, int oh,
+                        int ow, const float* wt, const float* scale, const float* bias, int act, void* out, float* pool_part,
+                        hipStream_t s) {
+    DwPlan p;
+    if (!plan_dw(c, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.out = out; a.wt = wt; a.scale = scale; a.bias = bias; a.pool_part = pool_part;
+    a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
+    a.TH = p.TH; a.tiles = p.tiles; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices; a.pitch16 = p.pitch16; a.WP = p.WP;
+    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.lds, s)
+                                            : launch_dw_t<float>(a, k, stride, p.OXT, p.lds, s);
+    return ok ? p.tiles : -1;
+}
+
+void adaf_launch_pool_finish(const float* part, int n, int tiles, int c, int hw, float* mean, hipStream_t s) {
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)(((size_t)n * c + 255) / 256)), dim3(256), 0, s, part, n, tiles, c,
+                       1.f / (float)hw, mean);
+}
+
+void adaf_launch_se_gate(const float* part, int tiles, int hw, int n, int c, const float* wr, const float* br, int sq,
+                         const float* we, int we_ldc, int we_ldj, const float* be, float* gate, hipStream_t s) {
+    hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), (size_t)(c + sq) * 4, s, part, tiles, 1.f / (float)hw, c, wr, br, sq, we,
+                       we_ldc, we_ldj, be, gate);
+}
+
+int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, const float* gate, const void* w, int n,
+                              const float* scale, const float* bias, const void* res, void* out, hipStream_t s) {
+    const int v = dtype == ADAF_DTYPE_F16 ? 8 : 4;
+    if (k % v || m <= 0 || n <= 0 || hw <= 0) return -1;
+    ProjArgs a;
+    a.x = x; a.gate = gate; a.w = w; a.scale = scale; a.bias = bias; a.res = res; a.out = out; a.M = m; a.N = n; a.K = k; a.HW = hw;
+    // column tile: the fewest padded columns, then the fewest column tiles (the A panel is re-read per column tile)
+    int best = 1, best_pad = 1 << 30;
+    for (int tn = 1; tn <= 4; ++tn) {
+        const int bn = 32 * tn, pad = (n + bn - 1) / bn * bn;
+        if (pad < best_pad || (pad == best_pad && tn > best)) { best_pad = pad; best = tn; }
+    }
+    const dim3 block(256);
+    const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 32 * best - 1) / (32 * best)));
+#define ADAF_GP(T, TN) hipLaunchKernelGGL((gated_project_kernel<T, TN>), grid, block, 0, s, a)
+    if (dtype == ADAF_DTYPE_F16) {
+        if (best == 1) ADAF_GP(_Float16, 1); else if (best == 2) ADAF_GP(_Float16, 2); else if (best == 3) ADAF_GP(_Float16, 3); else ADAF_GP(_Float16, 4);
+    } else {
+        if (best == 1) ADAF_GP(float, 1); else if (best == 2) ADAF_GP(float, 2); else if (best == 3) ADAF_GP(float, 3); else ADAF_GP(float, 4);
+    }
+#undef ADAF_GP
+    return best;
+}
+
+void adaf_launch_pack_dw_kxk(const float* w, int c, int k, float* o, hipStream_t s) {
+    hipLaunchKernelGGL(pack_dw_kxk_kernel, dim3((unsigned)((k * k * c + 255) / 256)), dim3(256), 0, s, w, c, k * k, o);
+}
+
+// ======================================================================================================================
+// The network object
+// ======================================================================================================================
+struct EfConv {
+    std::string name;     // "stem", "b3.expand", "b3.dw", "b3.project", "head"
+    int cin, cout, k, stride;
+    bool dw;
+    int cin_pad;
+    float* w = nullptr;   // dense: [cout][k][k][cin_pad] fp32; depthwise: [k*k][c]
+    void* w16 = nullptr;  // dense 1x1 filters in fp16 (ADAF_DTYPE_F16)
+    float* scale = nullptr;
+    float* bias = nullptr;
+};
+struct EfBlock {
+    int k, stride, expand_ratio, cin, cout, hid, sq;
+    int expand, dwc, project;       // indices into convs (expand = -1 when the ratio is 1)
+    float* se_wr = nullptr;         // [sq][hid]
+    float* se_br = nullptr;         // [sq]
+    float* se_wet = nullptr;        // [sq][hid] (transposed _se_expand.weight)
+    float* se_be = nullptr;         // [hid]
+};
+
+struct adaf_effnet {
+    adaf_handle* h = nullptr;
+    float width = 1.f, depth = 1.f;
+    std::map<std::string, std::pair<const float*, size_t>> params;
+    std::vector<EfConv> convs;
+    std::vector<EfBlock> blocks;
+    int stem = 0, head = 0, feat = 1280;
+    int dtype = ADAF_DTYPE_F32;
+    bool finalized = false;
+};
+
+namespace {
+
+int efail(adaf_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+// efficientnet_pytorch utils.py round_filters / round_repeats (depth_divisor 8)
+int round_filters(int filters, float width) {
+    const double f = (double)filters * (double)width;
+    int nf = (int)(f + 4.0) / 8 * 8;
+    if (nf < 8) nf = 8;
+    if ((double)nf < 0.9 * f) nf += 8;
+    return nf;
+}
+int round_repeats(int r, float depth) { return (int)std::ceil((double)depth * r - 1e-9); }
+
+// blocks_args of utils.py efficientnet(): repeats, kernel, stride, expand, in, out (se_ratio 0.25 everywhere)
+const int kBase[7][6] = {{1, 3, 1, 1, 32, 16}, {2, 3, 2, 6, 16, 24}, {2, 5, 2, 6, 24, 40}, {3, 3, 2, 6, 40, 80},
+                         {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192}, {1, 3, 1, 6, 192, 320}};
+
+void build(adaf_effnet* net) {
+    net->convs.clear();
+    net->blocks.clear();
+    const int c0 = round_filters(32, net->width);
+    net->stem = 0;
+    net->convs.push_back({"stem", 3, c0, 3, 2, false, 4});
+    int last = c0;
+    for (auto& s : kBase) {
+        const int i0 = round_filters(s[4], net->width), o = round_filters(s[5], net->width), rep = round_repeats(s[0], net->depth);
+        for (int j = 0; j < rep; ++j) {
+            EfBlock b;
+            b.k = s[1]; b.stride = j == 0 ? s[2] : 1; b.expand_ratio = s[3];
+            b.cin = j == 0 ? i0 : o; b.cout = o; b.hid = b.cin * s[3];
+            b.sq = (int)(b.cin * 0.25); if (b.sq < 1) b.sq = 1;
+            char nm[40];
+            const int bi = (int)net->blocks.size();
+            b.expand = -1;
+            if (s[3] != 1) {
+                snprintf(nm, sizeof(nm), "b%d.expand", bi);
+                b.expand = (int)net->convs.size();
+                net->convs.push_back({nm, b.cin, b.hid, 1, 1, false, b.cin});
+            }
+            snprintf(nm, sizeof(nm), "b%d.dw", bi);
+            b.dwc = (int)net->convs.size();
+            net->convs.push_back({nm, b.hid, b.hid, b.k, b.stride, true, b.hid});
+            snprintf(nm, sizeof(nm), "b%d.project", bi);
+            b.project = (int)net->convs.size();
+            net->convs.push_back({nm, b.hid, b.cout, 1, 1, false, b.hid});
+            net->blocks.push_back(b);
+            last = o;
+        }
+    }
+    net->feat = round_filters(1280, net->width);
+    net->head = (int)net->convs.size();
+    net->convs.push_back({"head", last, net->feat, 1, 1, false, last});
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// Conv2dStaticSamePadding (utils.py): padding for an input of `size`; returns pad_before, writes the total
+inline int same_pad(int size, int k, int stride, int* total) {
+    const int out = ceil_div(size, stride);
+    int t = (out - 1) * stride + k - size;
+    if (t < 0) t = 0;
+    *total = t;
+    return t / 2;
+}
+inline int conv_out_len(int in, int k, int stride, int pad_total) { return (in + pad_total - k) / stride + 1; }
+
+// elements per frame of the chunk buffers: io (block input / output, ping-pong), ex (expanded), dw (depthwise output);
+// pc = the largest tiles * hid of a squeeze partial buffer
+void slab_sizes(const adaf_effnet* net, int size, int pad_size, int dtype, size_t* io, size_t* ex, size_t* dw, size_t* pc, size_t* gc) {
+    int tot;
+    (void)same_pad(pad_size, 3, 2, &tot);
+    int hw = conv_out_len(size, 3, 2, tot), ps = ceil_div(pad_size, 2);
+    *io = (size_t)hw * hw * net->convs[net->stem].cout;
+    *ex = *dw = *pc = *gc = 0;
+    for (auto& b : net->blocks) {
+        (void)same_pad(ps, b.k, b.stride, &tot);
+        const int ohw = conv_out_len(hw, b.k, b.stride, tot);
+        if (b.expand >= 0 && (size_t)hw * hw * b.hid > *ex) *ex = (size_t)hw * hw * b.hid;
+        if ((size_t)ohw * ohw * b.hid > *dw) *dw = (size_t)ohw * ohw * b.hid;
+        if ((size_t)ohw * ohw * b.cout > *io) *io = (size_t)ohw * ohw * b.cout;
+        const int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
+        if ((size_t)(tiles > 0 ? tiles : 1) * b.hid > *pc) *pc = (size_t)(tiles > 0 ? tiles : 1) * b.hid;
+        if ((size_t)b.hid > *gc) *gc = b.hid;
+        hw = ohw;
+        ps = ceil_div(ps, b.stride);
+    }
+    // the head's fp32 map is parked in the expanded-map slab when the caller does not want it
+    const size_t headf = (size_t)hw * hw * net->feat * 4 / (dtype == ADAF_DTYPE_F16 ? 2 : 4);
+    if (headf > *ex) *ex = headf;
+}
+
+int chunk_frames(int n) {
+    static int c = [] { const char* e = getenv("ADAF_EFFNET_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    return n < c ? n : c;
+}
+
+int run_dense(adaf_effnet* net, const EfConv& L, const void* in, bool in16, int n, int hh, int ww, int oh, int ow, int pad, int act,
+              void* out, bool out16, hipStream_t st) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = static_cast<const float*>(in); a.w = in16 ? static_cast<const float*>(L.w16) : L.w;
+    a.scale = L.scale; a.bias = L.bias; a.res = nullptr; a.out = static_cast<float*>(out);
+    a.M = n * oh * ow; a.N = L.cout; a.K = L.k * L.k * L.cin_pad;
+    a.cin = L.cin_pad; a.H = hh; a.W = ww; a.OH = oh; a.OW = ow; a.KH = a.KW = L.k; a.stride = L.stride; a.pad = pad;
+    a.ldx = L.cin_pad; a.ldo = L.cout; a.ldr = L.cout; a.act = act;
+    a.zeros = net->h->zeros;
+    a.vec_epi = (L.cout % 4 == 0) ? 1 : 0;
+    a.in16 = in16; a.out16 = out16; a.res16 = 0;
+    return adaf_launch_conv_gemm(a, 0, net->h->cus, st) > 0 ? ADAF_OK : ADAF_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int adaf_effnet_create(adaf_handle* h, float width_coefficient, float depth_coefficient, adaf_effnet** out) {
+    if (!h || !out) return ADAF_E_BADARG;
+    if (!(width_coefficient >= 0.5f && width_coefficient <= 4.f && depth_coefficient >= 0.5f && depth_coefficient <= 8.f))
+        return efail(h, ADAF_E_BADARG, "effnet: width / depth coefficients out of range");
+    adaf_effnet* net = new adaf_effnet();
+    net->h = h;
+    net->width = width_coefficient;
+    net->depth = depth_coefficient;
+    build(net);
+    *out = net;
+    return ADAF_OK;
+}
+
+int adaf_effnet_destroy(adaf_effnet* net) {
+    if (!net) return ADAF_OK;
+    for (auto& L : net->convs) {
+        if (L.w) (void)hipFree(L.w);
+        if (L.w16) (void)hipFree(L.w16);
+        if (L.scale) (void)hipFree(L.scale);
+        if (L.bias) (void)hipFree(L.bias);
+    }
+    for (auto& b : net->blocks) {
+        if (b.se_wr) (void)hipFree(b.se_wr);
+        if (b.se_br) (void)hipFree(b.se_br);
+        if (b.se_wet) (void)hipFree(b.se_wet);
+        if (b.se_be) (void)hipFree(b.se_be);
+    }
+    delete net;
+    return ADAF_OK;
+}
+
+int adaf_effnet_feature_dim(const adaf_effnet* net) { return net ? net->feat : 0; }
+int adaf_effnet_block_count(const adaf_effnet* net) { return net ? (int)net->blocks.size() : 0; }
+
+int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8) {
+    if (!net || !info8 || block < 0 || block >= (int)net->blocks.size()) return ADAF_E_BADARG;
+    const EfBlock& b = net->blocks[block];
+    info8[0] = b.k; info8[1] = b.stride; info8[2] = b.expand_ratio; info8[3] = b.cin; info8[4] = b.cout; info8[5] = b.hid;
+    info8[6] = b.sq; info8[7] = net->convs[net->stem].cout;
+    return ADAF_OK;
+}
+
+int adaf_effnet_set_dtype(adaf_effnet* net, int dtype) {
+    if (!net) return ADAF_E_BADARG;
+    if (dtype != ADAF_DTYPE_F32 && dtype != ADAF_DTYPE_F16) return efail(net->h, ADAF_E_BADARG, "effnet: unknown dtype %d", dtype);
+    if (dtype != net->dtype) net->finalized = false;
+    net->dtype = dtype;
+    return ADAF_OK;
+}
+
+int adaf_effnet_set_param(adaf_effnet* net, const char* name, const float* dev_ptr, size_t numel) {
+    if (!net || !name || !dev_ptr) return ADAF_E_BADARG;
+    net->params[name] = std::make_pair(dev_ptr, numel);
+    net->finalized = false;
+    return ADAF_OK;
+}
+
+int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
+    if (!net) return ADAF_E_BADARG;
+    adaf_handle* h = net->h;
+    hipStream_t st = (hipStream_t)stream;
+    auto get = [&](const std::string& key, size_t numel, const float** p) -> int {
+        auto it = net->params.find(key);
+        if (it == net->params.end()) return efail(h, ADAF_E_STATE, "effnet: missing parameter '%s'", key.c_str());
+        if (it->second.second != numel)
+            return efail(h, ADAF_E_BADARG, "effnet: '%s' has %zu elements, expected %zu", key.c_str(), it->second.second, numel);
+        *p = it->second.first;
+        return ADAF_OK;
+    };
+    auto alloc = [&](float** p, size_t count) -> int {
+        if (!*p && hipMalloc(reinterpret_cast<void**>(p), count * sizeof(float)) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+        return ADAF_OK;
+    };
+    for (auto& L : net->convs) {
+        const float *w, *g, *b, *m, *v;
+        int rc;
+        const size_t wn_in = L.dw ? (size_t)L.cout * L.k * L.k : (size_t)L.cout * L.cin * L.k * L.k;
+        if ((rc = get(L.name + ".weight", wn_in, &w))) return rc;
+        if ((rc = get(L.name + ".bn.weight", L.cout, &g))) return rc;
+        if ((rc = get(L.name + ".bn.bias", L.cout, &b))) return rc;
+        if ((rc = get(L.name + ".bn.running_mean", L.cout, &m))) return rc;
+        if ((rc = get(L.name + ".bn.running_var", L.cout, &v))) return rc;
+        const size_t wn = L.dw ? (size_t)L.k * L.k * L.cout : (size_t)L.cout * L.k * L.k * L.cin_pad;
+        if ((rc = alloc(&L.w, wn)) || (rc = alloc(&L.scale, L.cout)) || (rc = alloc(&L.bias, L.cout))) return rc;
+        if (L.dw) adaf_launch_pack_dw_kxk(w, L.cout, L.k, L.w, st);
+        else adaf_launch_pack_weight(w, L.cout, L.cin, L.k, L.k, L.cin_pad, L.w, st);
+        if (!L.dw && L.k == 1 && net->dtype == ADAF_DTYPE_F16) {
+            if (!L.w16 && hipMalloc(&L.w16, wn * sizeof(unsigned short)) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            adaf_launch_pack_weight_f16(w, L.cout, L.cin, 1, 1, L.cin_pad, L.w16, st);
+        }
+        adaf_launch_fold_bn(g, b, m, v, 1e-3f, L.cout, L.scale, L.bias, st);     // utils.py: batch_norm_epsilon = 1e-3
+    }
+    for (size_t bi = 0; bi < net->blocks.size(); ++bi) {
+        EfBlock& b = net->blocks[bi];
+        char nm[48];
+        const float *wr, *br, *we, *be;
+        int rc;
+        snprintf(nm, sizeof(nm), "b%zu.se_reduce", bi);
+        if ((rc = get(std::string(nm) + ".weight", (size_t)b.sq * b.hid, &wr)) || (rc = get(std::string(nm) + ".bias", b.sq, &br))) return rc;
+        snprintf(nm, sizeof(nm), "b%zu.se_expand", bi);
+        if ((rc = get(std::string(nm) + ".weight", (size_t)b.sq * b.hid, &we)) || (rc = get(std::string(nm) + ".bias", b.hid, &be))) return rc;
+        if ((rc = alloc(&b.se_wr, (size_t)b.sq * b.hid)) || (rc = alloc(&b.se_br, b.sq)) || (rc = alloc(&b.se_wet, (size_t)b.sq * b.hid)) ||
+            (rc = alloc(&b.se_be, b.hid)))
+            return rc;
+        (void)hipMemcpyAsync(b.se_wr, wr, (size_t)b.sq * b.hid * 4, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(b.se_br, br, (size_t)b.sq * 4, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(b.se_be, be, (size_t)b.hid * 4, hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((b.sq * b.hid + 255) / 256)), dim3(256), 0, st, we, b.hid, b.sq, b.se_wet);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return efail(h, ADAF_E_LAUNCH, "effnet finalize: %s", hipGetErrorString(e));
+    net->finalized = true;
+    return ADAF_OK;
+}
+
+size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int pad_size) {
+    if (!net || n <= 0 || size < 32) return 0;
+    size_t io, ex, dw, pc, gc;
+    slab_sizes(net, size, pad_size > 0 ? pad_size : size, net->dtype, &io, &ex, &dw, &pc, &gc);
+    const size_t es = net->dtype == ADAF_DTYPE_F16 ? 2 : 4;
+    const int chunk = chunk_frames(n);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al((size_t)chunk * io * es) * 2 + al((size_t)chunk * ex * es) + al((size_t)chunk * dw * es) + al((size_t)chunk * pc * 4) +
+           al((size_t)chunk * gc * 4);
+}
+
+int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int size, int pad_size, int upto_block, void* block_out,
+                        float* featmap, float* featvec, int ldvec, void* ws, size_t ws_bytes, void* stream) {
+    if (!net) return ADAF_E_BADARG;
+    adaf_handle* h = net->h;
+    if (!net->finalized) return efail(h, ADAF_E_STATE, "effnet: finalize() has not been called");
+    if (!frames_nhwc4 || !ws) return efail(h, ADAF_E_BADARG, "effnet: null pointer");
+    if (n <= 0 || size < 32) return efail(h, ADAF_E_BADARG, "effnet: need n > 0 and size >= 32");
+    if (pad_size <= 0) pad_size = size;
+    if (featvec && ldvec < net->feat) return efail(h, ADAF_E_LAYOUT, "effnet: ldvec >= %d required", net->feat);
+    if (upto_block >= 0 && !block_out) return efail(h, ADAF_E_BADARG, "effnet: upto_block needs block_out");
+    if (ws_bytes < adaf_effnet_workspace_bytes(net, n, size, pad_size)) return efail(h, ADAF_E_NOMEM, "effnet: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const bool f16 = net->dtype == ADAF_DTYPE_F16;
+    const size_t es = f16 ? 2 : 4;
+    size_t io, ex, dws, pc, gc;
+    slab_sizes(net, size, pad_size, net->dtype, &io, &ex, &dws, &pc, &gc);
+    const int chunk = chunk_frames(n);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char* base = static_cast<char*>(ws);
+    char* bufA = base;
+    char* bufB = bufA + al((size_t)chunk * io * es);
+    char* bufE = bufB + al((size_t)chunk * io * es);
+    char* bufD = bufE + al((size_t)chunk * ex * es);
+    float* part = reinterpret_cast<float*>(bufD + al((size_t)chunk * dws * es));
+    float* gate = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + al((size_t)chunk * pc * 4));
+
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int nc = (n - f0) < chunk ? (n - f0) : chunk;
+        int rc, tot;
+        const int pb0 = same_pad(pad_size, 3, 2, &tot);
+        int hw = conv_out_len(size, 3, 2, tot), ps = ceil_div(pad_size, 2);
+        char* cur = bufA;
+        char* nxt = bufB;
+        const EfConv& S = net->convs[net->stem];
+        if ((rc = run_dense(net, S, frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size, hw, hw, pb0, ADAF_ACT_SWISH, cur, f16, st)))
+            return efail(h, rc, "effnet: stem launch");
+        size_t out_elems = (size_t)hw * hw * S.cout;
+        for (size_t bi = 0; bi < net->blocks.size(); ++bi) {
+            if (upto_block >= 0 && (int)bi >= upto_block) break;
+            const EfBlock& b = net->blocks[bi];
+            const void* dw_in = cur;
+            if (b.expand >= 0) {
+                if ((rc = run_dense(net, net->convs[b.expand], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, bufE, f16, st)))
+                    return efail(h, rc, "effnet: expand launch (block %zu)", bi);
+                dw_in = bufE;
+            }
+            const int pbd = same_pad(ps, b.k, b.stride, &tot);
+            const int ohw = conv_out_len(hw, b.k, b.stride, tot);
+            const EfConv& D = net->convs[b.dwc];
+            const int tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
+                                                  D.bias, ADAF_ACT_SWISH, bufD, part, st);
+            if (tiles <= 0) return efail(h, ADAF_E_LAUNCH, "effnet: depthwise launch (block %zu)", bi);
+            adaf_launch_se_gate(part, tiles, ohw * ohw, nc, b.hid, b.se_wr, b.se_br, b.sq, b.se_wet, 1, b.hid, b.se_be, gate, st);
+            const EfConv& P = net->convs[b.project];
+            const bool skip = b.stride == 1 && b.cin == b.cout;
+            if (adaf_launch_gated_project(bufD, net->dtype, nc * ohw * ohw, ohw * ohw, b.hid, gate, f16 ? P.w16 : static_cast<const void*>(P.w),
+                                          b.cout, P.scale, P.bias, skip ? cur : nullptr, nxt, st) < 0)
+                return efail(h, ADAF_E_LAUNCH, "effnet: project launch (block %zu)", bi);
+            char* t = cur; cur = nxt; nxt = t;
+            hw = ohw;
+            ps = ceil_div(ps, b.stride);
+            out_elems = (size_t)hw * hw * b.cout;
+        }
+        if (upto_block >= 0) {
+            (void)hipMemcpyAsync(static_cast<char*>(block_out) + (size_t)f0 * out_elems * es, cur, (size_t)nc * out_elems * es,
+                                 hipMemcpyDeviceToDevice, st);
+            continue;
+        }
+        float* fm = featmap ? featmap + (size_t)f0 * hw * hw * net->feat : reinterpret_cast<float*>(bufE);
+        if ((rc = run_dense(net, net->convs[net->head], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, fm, false, st)))
+            return efail(h, rc, "effnet: head launch");
+        if (featvec) {
+            if (net->feat % 4 == 0 && ldvec % 4 == 0) adaf_launch_avgpool(fm, nc, hw * hw, net->feat, featvec + (size_t)f0 * ldvec, ldvec, st);
+            else hipLaunchKernelGGL((avgpool_any_kernel<float>), dim3((unsigned)(((size_t)nc * net->feat + 255) / 256)), dim3(256), 0, st, fm, nc,
+                                    hw * hw, net->feat, featvec + (size_t)f0 * ldvec, ldvec);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : efail(h, ADAF_E_LAUNCH, "effnet forward: %s", hipGetErrorString(e));
+}
+
+// ---- stand-alone ops (tests, and building blocks for other MBConv networks) ---------------------------------------------
+int adaf_pack_dw_weight_kxk_f32(adaf_handle* h, const float* w_c1kk, int channels, int k, float* w_kkc, void* stream) {
+    if (!h || !w_c1kk || !w_kkc || channels <= 0 || k <= 0) return efail(h, ADAF_E_BADARG, "pack_dw_kxk: bad argument");
+    adaf_launch_pack_dw_kxk(w_c1kk, channels, k, w_kkc, (hipStream_t)stream);
+    return ADAF_OK;
+}
+
+size_t adaf_dwconv_same_workspace_bytes(int n, int hh, int ww, int c, int k, int stride, int dtype) {
+    const int oh = ceil_div(hh, stride), ow = ceil_div(ww, stride);
+    const int tiles = adaf_effnet_dw_tiles(c, oh, ow, k, stride, dtype);
+    return tiles > 0 ? (size_t)n * tiles * c * 4 : 0;
+}
+
+int adaf_dwconv_same_bn_act(adaf_handle* h, const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, const float* w_kkc,
+                            const float* scale, const float* bias, int act, void* out, float* pool_mean, void* ws, size_t ws_bytes,
+                            void* stream) {
+    if (!h || !x || !w_kkc || !scale || !bias || !out) return efail(h, ADAF_E_BADARG, "dwconv_same: null pointer");
+    if (n <= 0 || hh <= 0 || ww <= 0 || c <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2))
+        return efail(h, ADAF_E_BADARG, "dwconv_same: k in {3, 5}, stride in {1, 2}");
+    if (dtype != ADAF_DTYPE_F32 && dtype != ADAF_DTYPE_F16) return efail(h, ADAF_E_BADARG, "dwconv_same: dtype");
+    if (c % (dtype == ADAF_DTYPE_F16 ? 8 : 4)) return efail(h, ADAF_E_LAYOUT, "dwconv_same: channels must fill 16-byte chunks");
+    if (act < ADAF_ACT_NONE || act > ADAF_ACT_SWISH) return efail(h, ADAF_E_BADARG, "dwconv_same: activation");
+    int ty, tx;
+    const int pt = same_pad(hh, k, stride, &ty), pl = same_pad(ww, k, stride, &tx);
+    const int oh = ceil_div(hh, stride), ow = ceil_div(ww, stride);
+    float* part = nullptr;
+    if (pool_mean) {
+        if (!ws || ws_bytes < adaf_dwconv_same_workspace_bytes(n, hh, ww, c, k, stride, dtype)) return efail(h, ADAF_E_NOMEM, "dwconv_same: workspace");
+        part = static_cast<float*>(ws);
+    }
+    const int tiles = adaf_launch_dw_same(x, dtype, n, hh, ww, c, k, stride, pt, pl, oh, ow, w_kkc, scale, bias, act, out, part, (hipStream_t)stream);
+    if (tiles <= 0) return efail(h, ADAF_E_LAYOUT, "dwconv_same: shape not supported");
+    if (pool_mean) adaf_launch_pool_finish(part, n, tiles, c, oh * ow, pool_mean, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : efail(h, ADAF_E_LAUNCH, "dwconv_same: %s", hipGetErrorString(e));
+}
+
+int adaf_se_gate_f32(adaf_handle* h, const float* pool_mean, int n, int c, const float* w_reduce, const float* b_reduce, int squeezed,
+                     const float* w_expand, const float* b_expand, float* gate, void* stream) {
+    if (!h || !pool_mean || !w_reduce || !b_reduce || !w_expand || !b_expand || !gate) return efail(h, ADAF_E_BADARG, "se_gate: null pointer");
+    if (n <= 0 || c <= 0 || squeezed <= 0 || (size_t)(c + squeezed) * 4 > 60 * 1024) return efail(h, ADAF_E_BADARG, "se_gate: extents");
+    adaf_launch_se_gate(pool_mean, 1, 1, n, c, w_reduce, b_reduce, squeezed, w_expand, squeezed, 1, b_expand, gate, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : efail(h, ADAF_E_LAUNCH, "se_gate: %s", hipGetErrorString(e));
+}
+
+int adaf_conv1x1_gated_bn(adaf_handle* h, const void* x, int dtype, int n_images, int hw, int cin, const float* gate, const void* w,
+                          int cout, const float* scale, const float* bias, const void* residual, void* out, void* stream) {
+    if (!h || !x || !w || !out) return efail(h, ADAF_E_BADARG, "conv1x1_gated: null pointer");
+    if (dtype != ADAF_DTYPE_F32 && dtype != ADAF_DTYPE_F16) return efail(h, ADAF_E_BADARG, "conv1x1_gated: dtype");
+    if (n_images <= 0 || hw <= 0 || cin <= 0 || cout <= 0 || cin % (dtype == ADAF_DTYPE_F16 ? 8 : 4))
+        return efail(h, ADAF_E_LAYOUT, "conv1x1_gated: cin must fill 16-byte chunks");
+    if ((long long)n_images * hw > 0x7fffffffLL) return efail(h, ADAF_E_BADARG, "conv1x1_gated: too many rows");
+    if (adaf_launch_gated_project(x, dtype, n_images * hw, hw, cin, gate, w, cout, scale, bias, residual, out, (hipStream_t)stream) < 0)
+        return efail(h, ADAF_E_LAYOUT, "conv1x1_gated: shape not supported");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ADAF_OK : efail(h, ADAF_E_LAUNCH, "conv1x1_gated: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"

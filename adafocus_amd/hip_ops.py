@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, ACT_SWISH, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4  # noqa: F401
 from ._lib import MATH_F32, MATH_F32_SPLIT_BF16  # noqa: F401
 from ._lib import DTYPE_F32, DTYPE_F16  # noqa: F401
 
@@ -606,3 +606,180 @@ def dwconv3x3_bn_act_f16(x, w_33c, scale, bias, stride=1, act=ACT_RELU6):
                                                        L.ptr(scale.contiguous()), L.ptr(bias.contiguous()), act, L.ptr(out),
                                                        L.stream_ptr()), h)
     return out
+
+
+# ---- EfficientNet building blocks and network (BASELINE config 5; parity unpinned -- see include/adafocus.h) ------------
+def _dt(t):
+    if t.dtype == torch.float16:
+        return DTYPE_F16
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    raise L.AdafError("adafocus_amd: fp32 or fp16 storage expected, got %s" % t.dtype)
+
+
+def pack_dw_weight_kxk(w_c1kk):
+    """PyTorch depthwise filter (C,1,K,K) -> (K*K, C)."""
+    L.need_gpu_f32(w_c1kk)
+    w = w_c1kk.contiguous()
+    c, k = w.shape[0], w.shape[-1]
+    out = torch.empty((k * k, c), device=w.device, dtype=torch.float32)
+    h = _h(w)
+    L.check(L.load_library().adaf_pack_dw_weight_kxk_f32(h, L.ptr(w), c, k, L.ptr(out), L.stream_ptr()), h)
+    return out
+
+
+def dwconv_same_bn_act(x, w_kkc, scale, bias, k, stride=1, act=ACT_SWISH, want_pool=False):
+    """Depthwise k x k with TensorFlow-SAME padding + BN affine + activation.  x (N,H,W,C) fp32 | fp16 NHWC ->
+    (N,ceil(H/s),ceil(W/s),C) in x's dtype [, squeeze mean (N,C) fp32]."""
+    _need_gpu(x)
+    L.need_gpu_f32(w_kkc, scale, bias)
+    x = x.contiguous()
+    n, hh, ww, c = x.shape
+    oh, ow = -(-hh // stride), -(-ww // stride)
+    out = torch.empty((n, oh, ow, c), device=x.device, dtype=x.dtype)
+    lib = L.load_library()
+    pool = ws = None
+    need = 0
+    if want_pool:
+        pool = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        need = lib.adaf_dwconv_same_workspace_bytes(n, hh, ww, c, int(k), int(stride), _dt(x))
+        ws = torch.empty(max(need, 16), device=x.device, dtype=torch.uint8)
+    h = _h(x)
+    L.check(lib.adaf_dwconv_same_bn_act(h, L.ptr(x), _dt(x), n, hh, ww, c, int(k), int(stride), L.ptr(w_kkc.contiguous()),
+                                        L.ptr(scale.contiguous()), L.ptr(bias.contiguous()), int(act), L.ptr(out), L.ptr(pool),
+                                        L.ptr(ws), need, L.stream_ptr()), h)
+    return (out, pool) if want_pool else out
+
+
+def se_gate(pool_mean, w_reduce, b_reduce, w_expand, b_expand):
+    """sigmoid(W_e swish(W_r m + b_r) + b_e): pool_mean (N,C), W_r (SQ,C), W_e (C,SQ) -> gate (N,C)."""
+    L.need_gpu_f32(pool_mean, w_reduce, b_reduce, w_expand, b_expand)
+    n, c = pool_mean.shape
+    sq = w_reduce.shape[0]
+    gate = torch.empty((n, c), device=pool_mean.device, dtype=torch.float32)
+    h = _h(pool_mean)
+    L.check(L.load_library().adaf_se_gate_f32(h, L.ptr(pool_mean.contiguous()), n, c, L.ptr(w_reduce.reshape(sq, c).contiguous()),
+                                              L.ptr(b_reduce.contiguous()), sq, L.ptr(w_expand.reshape(c, sq).contiguous()),
+                                              L.ptr(b_expand.contiguous()), L.ptr(gate), L.stream_ptr()), h)
+    return gate
+
+
+def conv1x1_gated_bn(x, gate, w, scale=None, bias=None, residual=None):
+    """x (N,H,W,Cin) fp32 | fp16, gate (N,Cin) fp32 or None, w (Cout,Cin) in x's dtype -> (N,H,W,Cout) in x's dtype."""
+    _need_gpu(x, w)
+    x = x.contiguous()
+    n, hh, ww, cin = x.shape
+    cout = w.shape[0]
+    if w.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
+        raise L.AdafError("conv1x1_gated_bn: w / residual must have x's dtype")
+    out = torch.empty((n, hh, ww, cout), device=x.device, dtype=x.dtype)
+    h = _h(x)
+    L.check(L.load_library().adaf_conv1x1_gated_bn(h, L.ptr(x), _dt(x), n, hh * ww, cin, L.ptr(gate.contiguous() if gate is not None else None),
+                                                   L.ptr(w.reshape(cout, cin).contiguous()), cout,
+                                                   L.ptr(scale.contiguous() if scale is not None else None),
+                                                   L.ptr(bias.contiguous() if bias is not None else None),
+                                                   L.ptr(residual.contiguous() if residual is not None else None), L.ptr(out),
+                                                   L.stream_ptr()), h)
+    return out
+
+
+class EffNetNet:
+    """adaf_effnet: EfficientNet feature extractor (MBConv + squeeze-and-excite + swish; csrc/effnet.hip)."""
+
+    def __init__(self, device, width, depth):
+        self.device = torch.device(device)
+        self._h = L.handle(self.device)
+        self._lib = L.load_library()
+        net = C.c_void_p()
+        L.check(self._lib.adaf_effnet_create(self._h, C.c_float(width), C.c_float(depth), C.byref(net)), self._h)
+        self._net = net
+        self._scratch = _StreamScratch(self.device)
+        self.feature_dim = self._lib.adaf_effnet_feature_dim(net)
+        self.dtype = DTYPE_F32
+
+    def __del__(self):
+        try:
+            if getattr(self, "_net", None):
+                self._lib.adaf_effnet_destroy(self._net)
+                self._net = None
+        except Exception:
+            pass
+
+    def blocks(self):
+        out = []
+        for i in range(self._lib.adaf_effnet_block_count(self._net)):
+            info = (C.c_int * 8)()
+            L.check(self._lib.adaf_effnet_block_info(self._net, i, info), self._h)
+            out.append(dict(zip(("k", "stride", "expand", "cin", "cout", "hid", "sq", "stem"), list(info))))
+        return out
+
+    def set_dtype(self, dtype):
+        code = {"f32": DTYPE_F32, "f16": DTYPE_F16}.get(dtype, dtype)
+        L.check(self._lib.adaf_effnet_set_dtype(self._net, int(code)), self._h)
+        self.dtype = int(code)
+
+    def load(self, params):
+        keep = []
+        for name, t in params.items():
+            L.need_gpu_f32(t)
+            t = t.detach().contiguous()
+            keep.append(t)
+            L.check(self._lib.adaf_effnet_set_param(self._net, name.encode(), L.ptr(t), t.numel()), self._h)
+        L.check(self._lib.adaf_effnet_finalize(self._net, L.stream_ptr()), self._h)
+        del keep
+
+    def out_size(self, size, pad_size=0):
+        """Spatial size of the feature map for an input of `size` (SAME padding computed for pad_size or size)."""
+        ps = pad_size or size
+
+        def step(hw, ps, k, s):
+            tot = max((-(-ps // s) - 1) * s + k - ps, 0)
+            return (hw + tot - k) // s + 1, -(-ps // s)
+        hw, ps = step(size, ps, 3, 2)
+        for b in self.blocks():
+            hw, ps = step(hw, ps, b["k"], b["stride"])
+        return hw
+
+    def forward(self, frames_nhwc4, pad_size=0, want_map=False, want_vec=True, out=None):
+        """(N,S,S,4) fp32 -> (featmap (N,s,s,F) fp32 NHWC or None, featvec (N,F) or None).  `out`: write the vector into
+        this (N, >= F) fp32 view (row stride = its stride(0))."""
+        L.need_gpu_f32(frames_nhwc4)
+        x = frames_nhwc4.contiguous()
+        n, s = x.shape[0], x.shape[1]
+        f = self.feature_dim
+        fs = self.out_size(s, pad_size)
+        fmap = torch.empty((n, fs, fs, f), device=x.device, dtype=torch.float32) if want_map else None
+        fvec, ld = None, f
+        if out is not None:
+            fvec, ld = out, out.stride(0)
+        elif want_vec:
+            fvec = torch.empty((n, f), device=x.device, dtype=torch.float32)
+        need = self._lib.adaf_effnet_workspace_bytes(self._net, n, s, int(pad_size))
+        ws = self._scratch.get(need)
+        L.check(self._lib.adaf_effnet_forward(self._net, L.ptr(x), n, s, int(pad_size), -1, None, L.ptr(fmap), L.ptr(fvec), int(ld),
+                                              L.ptr(ws), need, L.stream_ptr()), self._h)
+        return fmap, fvec
+
+    def forward_blocks(self, frames_nhwc4, upto, pad_size=0):
+        """Output of the first `upto` MBConv blocks (0 = the stem) as (N,h,w,c) in the storage dtype (tests)."""
+        L.need_gpu_f32(frames_nhwc4)
+        x = frames_nhwc4.contiguous()
+        n, s = x.shape[0], x.shape[1]
+        ps = pad_size or s
+
+        def step(hw, ps, k, st):
+            tot = max((-(-ps // st) - 1) * st + k - ps, 0)
+            return (hw + tot - k) // st + 1, -(-ps // st)
+        hw, ps = step(s, ps, 3, 2)
+        blocks = self.blocks()
+        c = blocks[0]["stem"]
+        for b in blocks[:upto]:
+            hw, ps = step(hw, ps, b["k"], b["stride"])
+            c = b["cout"]
+        dt = torch.float16 if self.dtype == DTYPE_F16 else torch.float32
+        out = torch.empty((n, hw, hw, c), device=x.device, dtype=dt)
+        need = self._lib.adaf_effnet_workspace_bytes(self._net, n, s, int(pad_size))
+        ws = self._scratch.get(need)
+        L.check(self._lib.adaf_effnet_forward(self._net, L.ptr(x), n, s, int(pad_size), int(upto), L.ptr(out), None, None, 0,
+                                              L.ptr(ws), need, L.stream_ptr()), self._h)
+        return out

@@ -32,8 +32,10 @@ def synth_tensor(key, shape, seed, kind):
         a = g.normal(0.0, 0.1, shape)
     elif kind == "bn_gamma":
         a = g.uniform(0.5, 1.5, shape)
-        if ".bn3." in key:
+        if ".bn3." in key:          # last BN of a ResNet bottleneck's residual branch
             a = a * 0.25
+        elif "._bn2." in key:       # project BN of an EfficientNet MBConv block: 26 blocks of swish + SE neither blow up nor die out
+            a = a * 0.75
     elif kind == "bn_beta":
         a = g.normal(0.0, 0.1, shape)
     elif kind == "conv":

@@ -7,7 +7,8 @@ must see it: FLOP = 2 x MAC over the real (un-padded) channels; bytes = inputs +
 """
 
 __all__ = ["resnet50_macs_per_patch", "crop_bytes_per_patch", "gru_cls_macs_per_clip", "mobilenetv2_bytes_per_frame",
-           "mobilenetv2_macs_per_frame", "hot_path_flops_per_clip"]
+           "mobilenetv2_macs_per_frame", "hot_path_flops_per_clip", "effnet_blocks", "effnet_macs_per_frame",
+           "effnet_bytes_per_frame"]
 
 _STAGE_BLOCKS = (3, 4, 6, 3)
 _STAGE_PLANES = (64, 128, 256, 512)
@@ -120,3 +121,66 @@ def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_bl
     elems += ohw * last["oup"] + ohw * 1280                   # head 1x1
     elems += ohw * 1280 + 1280                                # mean-pooled vector
     return 4 * elems
+
+
+# ---- EfficientNet (BASELINE config 5; csrc/effnet.hip) -----------------------------------------------------------------
+# efficientnet_pytorch utils.py: (width, depth) per model; blocks_args (repeats, kernel, stride, expand, in, out)
+_EFF_PARAMS = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b1": (1.0, 1.1), "efficientnet-b2": (1.1, 1.2), "efficientnet-b3": (1.2, 1.4),
+               "efficientnet-b4": (1.4, 1.8), "efficientnet-b5": (1.6, 2.2), "efficientnet-b6": (1.8, 2.6), "efficientnet-b7": (2.0, 3.1)}
+_EFF_BLOCKS = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80), (3, 5, 1, 6, 80, 112),
+               (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320))
+
+
+def _eff_round(filters, width):
+    filters *= width
+    new = max(8, int(filters + 4) // 8 * 8)
+    return int(new + 8 if new < 0.9 * filters else new)
+
+
+def effnet_blocks(name, size):
+    """(stem channels, [block dicts with the map sizes at `size` input], head channels); SAME padding: out = ceil(in / stride)."""
+    import math
+    width, depth = _EFF_PARAMS[name]
+    hw = -(-size // 2)
+    blocks = []
+    for r, k, s, e, i, o in _EFF_BLOCKS:
+        i, o, r = _eff_round(i, width), _eff_round(o, width), int(math.ceil(depth * r))
+        for j in range(r):
+            cin, stride = (i if j == 0 else o), (s if j == 0 else 1)
+            ohw = -(-hw // stride)
+            blocks.append(dict(k=k, stride=stride, expand=e, cin=cin, cout=o, hid=cin * e, sq=max(1, int(cin * 0.25)), hw=hw, ohw=ohw))
+            hw = ohw
+    return _eff_round(32, width), blocks, _eff_round(1280, width)
+
+
+def effnet_macs_per_frame(name="efficientnet-b3", size=144):
+    """Multiply-adds of extract_features (+ nothing for the pooling): 0.432 G for B3 at 144^2, 1.83 G at its native 300^2."""
+    c0, blocks, ch = effnet_blocks(name, size)
+    hw = -(-size // 2)
+    macs = hw * hw * c0 * 27
+    for b in blocks:
+        if b["expand"] != 1:
+            macs += b["hw"] ** 2 * b["cin"] * b["hid"]
+        macs += b["ohw"] ** 2 * b["hid"] * b["k"] ** 2 + 2 * b["hid"] * b["sq"] + b["ohw"] ** 2 * b["hid"] * b["cout"]
+    return macs + blocks[-1]["ohw"] ** 2 * blocks[-1]["cout"] * ch
+
+
+def effnet_bytes_per_frame(name="efficientnet-b3", size=144, elem=2):
+    """HBM bytes per frame of the launch plan of csrc/effnet.hip (activation inputs + outputs of every launch; the 12 M
+    parameters are shared by >= 1024 frames per launch and ignored): patch in (fp32 x 4 lanes), stem out; per block expand
+    (in, out), depthwise (in, out), project (in, out, + identity); head (in, fp32 out), pooled vector.  elem = bytes per
+    stored activation (2 = fp16 storage, 4 = fp32)."""
+    c0, blocks, ch = effnet_blocks(name, size)
+    hw = -(-size // 2)
+    b_ = size * size * 16 + hw * hw * c0 * elem
+    for b in blocks:
+        hin, hout = b["hw"] ** 2, b["ohw"] ** 2
+        if b["expand"] != 1:
+            b_ += (hin * b["cin"] + hin * b["hid"]) * elem
+        b_ += (hin * b["hid"] + hout * b["hid"]) * elem                       # depthwise
+        b_ += (hout * b["hid"] + hout * b["cout"]) * elem                      # project
+        if b["stride"] == 1 and b["cin"] == b["cout"]:
+            b_ += hout * b["cout"] * elem
+    last = blocks[-1]
+    b_ += last["ohw"] ** 2 * (last["cout"] * elem + ch * 4) + last["ohw"] ** 2 * ch * 4 + ch * 4
+    return b_

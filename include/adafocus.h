@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ADAF_VERSION 200
+#define ADAF_VERSION 300
 
 enum {
     ADAF_OK = 0,
@@ -43,7 +43,7 @@ enum {
 };
 
 enum { ADAF_LAYOUT_NCHW = 0, ADAF_LAYOUT_NHWC = 1, ADAF_LAYOUT_NHWC4 = 2 /* C=3 padded to 4 with a zero lane */ };
-enum { ADAF_ACT_NONE = 0, ADAF_ACT_RELU = 1, ADAF_ACT_RELU6 = 2, ADAF_ACT_SIGMOID = 3 };
+enum { ADAF_ACT_NONE = 0, ADAF_ACT_RELU = 1, ADAF_ACT_RELU6 = 2, ADAF_ACT_SIGMOID = 3, ADAF_ACT_SWISH = 4 /* x * sigmoid(x) */ };
 
 typedef struct adaf_handle adaf_handle;
 typedef struct adaf_resnet50 adaf_resnet50;
@@ -279,6 +279,62 @@ int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
  * fp32 frames and stores fp16, the 1280-channel head stores fp32 for the consumers downstream; no temporal shift, no
  * fused expand -> depthwise kernels in this mode).  Takes effect at the next finalize(). */
 int adaf_mobilenetv2_set_dtype(adaf_mobilenetv2* net, int dtype);
+
+/* ---- N2 / BASELINE config 5: EfficientNet (MBConv with squeeze-and-excite) as the local CNN --------------------------
+ * PARITY UNPINNED: the reference has no EfficientNet on a live path.  It names the third-party package
+ * `efficientnet_pytorch` in dead AR-Net code (STH/ops/models_ada.py:6,69-75; not vendored, no version pin) and lists
+ * "efficientnet-b3" with feature dimension 1536 and the prior (1.80 GFLOPs, 12 M parameters) in
+ * STH/ops/net_flops_table.py:17,29.  These entry points implement the PUBLISHED algorithm of that package
+ * (efficientnet_pytorch 0.7.x: model.py MBConvBlock.forward / EfficientNet.extract_features; utils.py round_filters,
+ * round_repeats, Conv2dStaticSamePadding, MemoryEfficientSwish; BN eps 1e-3, se_ratio 0.25), restated on the CPU by
+ * oracle/ref_effnet.py.
+ *
+ * Building blocks (also usable on their own; x_dtype / dtype = ADAF_DTYPE_F32 | ADAF_DTYPE_F16 storage, math in fp32):
+ *   adaf_dwconv_same_bn_act   depthwise k x k (k = 3 | 5, stride 1 | 2) with TensorFlow-SAME padding
+ *                             (pad_before = total / 2, the rest after -- Conv2dStaticSamePadding for an input of the size at
+ *                             hand) + BN affine + activation; x, out [n,h,w,c] / [n,ceil(h/s),ceil(w/s),c] NHWC,
+ *                             w_kkc [k*k][c] (adaf_pack_dw_weight_kxk_f32 from PyTorch's [c,1,k,k]); optionally the
+ *                             squeeze pool_mean [n,c] = mean over the output pixels (fp32, summed in a fixed order;
+ *                             needs ws of adaf_dwconv_same_workspace_bytes)
+ *   adaf_se_gate_f32          gate[n,c] = sigmoid(W_e swish(W_r pool_mean[n] + b_r) + b_e); W_r [squeezed,c], W_e [c,squeezed]
+ *                             (_se_reduce / _se_expand weights in PyTorch layout)
+ *   adaf_conv1x1_gated_bn     out[m,co] = (sum_k x[m,k] gate[m / hw, k] w[co,k]) * scale[co] + bias[co] (+ residual[m,co]):
+ *                             `sigmoid(x_squeezed) * x` followed by _project_conv + _bn2 (+ the identity skip); w [cout,cin]
+ *                             in x's element type; gate may be NULL (plain 1x1 conv + BN) */
+int adaf_pack_dw_weight_kxk_f32(adaf_handle* h, const float* w_c1kk, int channels, int k, float* w_kkc, void* stream);
+size_t adaf_dwconv_same_workspace_bytes(int n, int hh, int ww, int c, int k, int stride, int dtype);
+int adaf_dwconv_same_bn_act(adaf_handle* h, const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, const float* w_kkc,
+                            const float* scale, const float* bias, int act, void* out, float* pool_mean, void* ws, size_t ws_bytes,
+                            void* stream);
+int adaf_se_gate_f32(adaf_handle* h, const float* pool_mean, int n, int c, const float* w_reduce, const float* b_reduce, int squeezed,
+                     const float* w_expand, const float* b_expand, float* gate, void* stream);
+int adaf_conv1x1_gated_bn(adaf_handle* h, const void* x, int dtype, int n_images, int hw, int cin, const float* gate, const void* w,
+                          int cout, const float* scale, const float* bias, const void* residual, void* out, void* stream);
+/* The network.  width / depth coefficients of utils.py efficientnet_params(): B0 (1.0, 1.0) ... B3 (1.2, 1.4) ... B7 (2.0, 3.1).
+ * Parameter names are layout-neutral: "stem", "b<i>.expand" (absent when the block's expand ratio is 1), "b<i>.dw",
+ * "b<i>.project", "head", each with ".weight", ".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var";
+ * "b<i>.se_reduce" / "b<i>.se_expand" with ".weight", ".bias"; i counts MBConv blocks from 0 like `_blocks.<i>`.  The Python
+ * mirror (adafocus_amd/efficientnet.py) maps efficientnet_pytorch's state-dict keys onto them.
+ *   adaf_effnet_block_info: info8 = {kernel, stride, expand ratio, cin, cout, hidden, squeezed, stem channels}
+ *   adaf_effnet_set_dtype:  ADAF_DTYPE_F16 = activations and 1x1 filters as fp16 in HBM (BASELINE config 5's "fp16");
+ *                           takes effect at the next finalize()
+ *   forward: frames_nhwc4 [n,size,size,4] fp32 (the gather's output); pad_size = the image size the SAME padding is
+ *            computed for (EfficientNet.from_name(..., image_size=pad_size)); 0 = size itself;
+ *            featmap [n,s,s,feature_dim] fp32 NHWC (extract_features) or NULL; featvec [n, ldvec] fp32 = _avg_pooling +
+ *            flatten, or NULL; upto_block >= 0 (tests): stop after that many MBConv blocks and copy the block output
+ *            [n,h,w,c] in the storage dtype to block_out instead (featmap / featvec untouched). */
+typedef struct adaf_effnet adaf_effnet;
+int adaf_effnet_create(adaf_handle* h, float width_coefficient, float depth_coefficient, adaf_effnet** out);
+int adaf_effnet_destroy(adaf_effnet* net);
+int adaf_effnet_feature_dim(const adaf_effnet* net);
+int adaf_effnet_block_count(const adaf_effnet* net);
+int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8);
+int adaf_effnet_set_dtype(adaf_effnet* net, int dtype);
+int adaf_effnet_set_param(adaf_effnet* net, const char* name, const float* dev_ptr, size_t numel);
+int adaf_effnet_finalize(adaf_effnet* net, void* stream);
+size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int pad_size);
+int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int size, int pad_size, int upto_block, void* block_out,
+                        float* featmap, float* featvec, int ldvec, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a11: policy head -------------------------------------------------------------------
  * idx = argmax_a logits[row, a] (first maximum), action = table_yx[idx] -- the eval branch of

@@ -1,0 +1,315 @@
+"""GPU tests of the EfficientNet path (BASELINE config 5's local CNN; csrc/effnet.hip) through the C ABI.
+
+PARITY UNPINNED: the reference has no EfficientNet on a live path, so the checker is
+oracle/ref_effnet.py -- the published algorithm of the package the reference names -- and plain torch ops for the building
+blocks.  fp32 storage must meet the fp32 bar (1e-3); fp16 storage is held to a measured tolerance, stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adafocus_amd import synth
+from tests.helpers import rnd
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from adafocus_amd import hip_ops
+    return hip_ops
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import ref_effnet
+    return ref_effnet
+
+
+def _smooth(shape, seed):
+    """Inputs with structure at every scale (a coarse random field upsampled + noise): pooled features then differ from
+    sample to sample by much more than the tolerance, which N(0,1) pixel noise alone would not achieve."""
+    n, c, h, w = shape
+    coarse = rnd((n, c, 6, 6), seed, 1.5)
+    return F.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False) + rnd(shape, seed + 1, 0.5)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+# ------------------------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("k,stride,size,c", [(3, 1, 72, 40), (3, 1, 72, 24), (3, 2, 72, 144), (3, 1, 36, 192), (5, 2, 36, 192),
+                                             (5, 1, 18, 288), (3, 2, 18, 288), (3, 1, 9, 576), (5, 1, 9, 816), (5, 2, 9, 816),
+                                             (5, 1, 5, 1392), (3, 1, 5, 2304), (5, 2, 11, 48), (3, 2, 7, 16), (5, 1, 10, 8),
+                                             (3, 1, 13, 200)])
+def test_dwconv_same_vs_torch(dev, ops, R, k, stride, size, c):
+    """Depthwise k x k with SAME padding + BN affine + swish + squeeze mean, fp32 and fp16 storage, against F.conv2d on the
+    explicitly padded input (Conv2dStaticSamePadding)."""
+    n = 3
+    x = rnd((n, c, size, size), 700 + size + c)
+    w = rnd((c, 1, k, k), 701 + c, 0.3)
+    scale = rnd((c,), 702, 0.2) + 1.0
+    bias = rnd((c,), 703, 0.1)
+    pb, pa = R.same_pad(size, k, stride)
+    ref = F.conv2d(F.pad(x, (pb, pa, pb, pa)), w, None, stride, 0, 1, c) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    ref = _swish(ref)
+    wk = ops.pack_dw_weight_kxk(w.to(dev))
+    assert torch.equal(wk.cpu(), w.view(c, k * k).t().contiguous())
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out, pool = ops.dwconv_same_bn_act(xh, wk, scale.to(dev), bias.to(dev), k, stride, ops.ACT_SWISH, want_pool=True)
+    assert out.shape == (n, -(-size // stride), -(-size // stride), c)
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5
+    assert (pool.cpu() - ref.mean([2, 3])).abs().max().item() < 2e-5
+    # no squeeze wanted: same map
+    assert torch.equal(ops.dwconv_same_bn_act(xh, wk, scale.to(dev), bias.to(dev), k, stride, ops.ACT_SWISH), out)
+    if c % 8 == 0:
+        x16 = xh.half()
+        ref16 = F.conv2d(F.pad(x16.float().cpu().permute(0, 3, 1, 2), (pb, pa, pb, pa)), w, None, stride, 0, 1, c)
+        ref16 = _swish(ref16 * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+        o16, p16 = ops.dwconv_same_bn_act(x16, wk, scale.to(dev), bias.to(dev), k, stride, ops.ACT_SWISH, want_pool=True)
+        assert o16.dtype == torch.float16
+        # products and sums are fp32 on fp16 inputs: only the final store rounds (half an ulp of fp16 = 2^-11 relative)
+        assert (o16.float().cpu().permute(0, 3, 1, 2) - ref16).abs().max().item() < 1e-3 * max(1.0, float(ref16.abs().max()))
+        assert (p16.cpu() - ref16.mean([2, 3])).abs().max().item() < 2e-5      # the squeeze sums the fp32 values
+
+
+def test_dwconv_same_rejects_bad_arguments(dev, ops):
+    from adafocus_amd._lib import AdafError
+    x = torch.zeros((1, 8, 8, 8), device=dev)
+    w = torch.zeros((16, 8), device=dev)
+    s = torch.ones(8, device=dev)
+    with pytest.raises(AdafError):
+        ops.dwconv_same_bn_act(x, w, s, s, 4, 1)            # k = 4
+    with pytest.raises(AdafError):
+        ops.dwconv_same_bn_act(x, w, s, s, 3, 3)            # stride 3
+    with pytest.raises(AdafError):
+        ops.dwconv_same_bn_act(torch.zeros((1, 8, 8, 6), device=dev), w, s, s, 3, 1)   # channels do not fill 16-byte chunks
+
+
+@pytest.mark.parametrize("n,c,sq", [(5, 40, 10), (3, 24, 6), (2, 816, 34), (4, 2304, 96), (1, 8, 1)])
+def test_se_gate_vs_torch(dev, ops, n, c, sq):
+    m = rnd((n, c), 710 + c, 0.5)
+    wr, br = rnd((sq, c, 1, 1), 711, 0.2), rnd((sq,), 712, 0.1)
+    we, be = rnd((c, sq, 1, 1), 713, 0.3), rnd((c,), 714, 0.1)
+    s = F.conv2d(_swish(F.conv2d(m.view(n, c, 1, 1), wr, br)), we, be)
+    ref = torch.sigmoid(s).view(n, c)
+    got = ops.se_gate(m.to(dev), wr.to(dev), br.to(dev), we.to(dev), be.to(dev))
+    assert (got.cpu() - ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("hw,cin,cout,res", [(25, 2304, 384, True), (81, 816, 136, True), (324, 288, 48, False), (1296, 144, 32, False),
+                                             (49, 40, 24, False), (10, 24, 24, True), (25, 1392, 232, True), (7, 8, 100, False)])
+def test_conv1x1_gated_bn_vs_torch(dev, ops, hw, cin, cout, res):
+    """sigmoid(x_squeezed) * x -> _project_conv -> _bn2 (+ identity): the gate is applied to the A operand inside the GEMM."""
+    n = 3
+    side = int(round(hw ** 0.5))
+    hh, ww = (side, side) if side * side == hw else (1, hw)
+    x = rnd((n, hh, ww, cin), 720 + cin)
+    gate = torch.sigmoid(rnd((n, cin), 721))
+    w = rnd((cout, cin), 722, (1.0 / cin) ** 0.5)
+    scale, bias = rnd((cout,), 723, 0.2) + 1.0, rnd((cout,), 724, 0.1)
+    r = rnd((n, hh, ww, cout), 725) if res else None
+    ref = ((x * gate.view(n, 1, 1, cin)).reshape(-1, cin).double() @ w.t().double()).float().view(n, hh, ww, cout) * scale + bias
+    if res:
+        ref = ref + r
+    got = ops.conv1x1_gated_bn(x.to(dev), gate.to(dev), w.to(dev), scale.to(dev), bias.to(dev), r.to(dev) if res else None)
+    assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, float(ref.abs().max()))
+    # gate = None: a plain 1x1 conv + BN
+    plain = ops.conv1x1_gated_bn(x.to(dev), None, w.to(dev), scale.to(dev), bias.to(dev))
+    ref_p = (x.reshape(-1, cin).double() @ w.t().double()).float().view(n, hh, ww, cout) * scale + bias
+    assert (plain.cpu() - ref_p).abs().max().item() < 2e-5 * max(1.0, float(ref_p.abs().max()))
+    if cin % 8 == 0:
+        x16, w16 = x.half(), w.half()
+        xg = (x16.float() * gate.view(n, 1, 1, cin)).half()            # the gated operand is rounded to fp16 before the MFMA
+        ref16 = (xg.reshape(-1, cin).double() @ w16.t().double()).float().view(n, hh, ww, cout) * scale + bias
+        if res:
+            ref16 = ref16 + r.half().float()
+        got16 = ops.conv1x1_gated_bn(x16.to(dev), gate.to(dev), w16.to(dev), scale.to(dev), bias.to(dev), r.half().to(dev) if res else None)
+        assert got16.dtype == torch.float16
+        assert (got16.float().cpu() - ref16).abs().max().item() < 2e-3 * max(1.0, float(ref16.abs().max()))
+
+
+def test_conv_engine_swish_epilogue(dev, ops):
+    """ADAF_ACT_SWISH in the MFMA engine's epilogue (expand / head convs): x * sigmoid(x) after the BN affine."""
+    x = rnd((2, 9, 9, 96), 730)
+    w = rnd((576, 96, 1, 1), 731, 0.1)
+    scale, bias = rnd((576,), 732, 0.2) + 1.0, rnd((576,), 733, 0.1)
+    ref = _swish((x.reshape(-1, 96) @ w.view(576, 96).t()) * scale + bias).view(2, 9, 9, 576)
+    wp = ops.pack_conv_weight(w.to(dev))
+    got = ops.conv2d_bn_act(x.to(dev), wp, scale.to(dev), bias.to(dev), act=ops.ACT_SWISH)
+    assert (got.cpu() - ref).abs().max().item() < 2e-5
+    naive = ops.conv2d_bn_act(x.to(dev), wp, scale.to(dev), bias.to(dev), act=ops.ACT_SWISH, naive=True)
+    assert (naive.cpu() - ref).abs().max().item() < 2e-5
+    got16 = ops.conv2d_bn_act_f16(x.half().to(dev), ops.pack_conv_weight_f16(w.to(dev)), scale.to(dev), bias.to(dev), act=ops.ACT_SWISH)
+    ref16 = _swish((x.half().float().reshape(-1, 96) @ w.half().float().view(576, 96).t()) * scale + bias).view(2, 9, 9, 576)
+    assert (got16.float().cpu() - ref16).abs().max().item() < 2e-3 * float(ref16.abs().max())
+
+
+# ------------------------------------------------------------------------------------ the network
+def _net(dev, name, classes, dtype="f32", seed=1007, image_size=None):
+    from adafocus_amd.efficientnet import EfficientNet
+    m = EfficientNet.from_name(name, num_classes=classes, image_size=image_size, dtype=dtype).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev), sd
+
+
+@pytest.mark.parametrize("size", [144, 96, 100, 75])
+def test_b3_fp32_storage_vs_oracle(dev, R, size):
+    """EfficientNet-B3, fp32 storage: every block boundary and the final features against the CPU restatement, at BASELINE
+    config 5's 144^2 patches, at 96^2, and at sizes whose maps go odd (100: 50/25/13/7/4; 75: 38/19/10/5/3) where the
+    SAME padding turns asymmetric in different places."""
+    m, sd = _net(dev, "efficientnet-b3", 200)
+    x = _smooth((2, 3, size, size), 740 + size)
+    from adafocus_amd.utils import nchw_to_nhwc4
+    x4 = nchw_to_nhwc4(x.to(dev))
+    eng = m.engine()
+    with torch.no_grad():
+        for upto in (0, 1, 2, 3, 5, 6, 8, 9, 13, 14, 18, 19, 24, 26):
+            ref = R.extract_features(sd, x, "efficientnet-b3", upto=upto)
+            got = eng.forward_blocks(x4, upto).cpu().permute(0, 3, 1, 2)
+            assert got.shape == ref.shape, (upto, got.shape, ref.shape)
+            assert (got - ref).abs().max().item() < TOL, (size, upto, (got - ref).abs().max().item())
+        ref_map = R.extract_features(sd, x, "efficientnet-b3")
+        ref_vec = R.features_pooled(sd, x, "efficientnet-b3")
+        fmap = m.extract_features(x.to(dev)).cpu()
+        fvec = m.features_nhwc4(x4).cpu()
+        pooled = m.get_featmap(x.to(dev), pooled=True).cpu()
+    assert fmap.shape == ref_map.shape and (fmap - ref_map).abs().max().item() < TOL
+    assert fvec.shape == (2, 1536) and (fvec - ref_vec).abs().max().item() < TOL
+    assert torch.equal(pooled.view(2, -1), fvec)
+    assert (ref_vec[0] - ref_vec[1]).abs().max().item() > 20 * TOL          # the two samples really differ
+
+
+def test_b3_logits_and_static_padding_for_another_resolution(dev, R):
+    """forward() = pooled features -> _fc; and EfficientNet.from_name(..., image_size=300) run on 144^2 input: the SAME
+    padding is the one computed for the 300^2 chain (75 -> 38 pads the 5x5 / stride-2 conv (2, 2), the 36-pixel map would
+    get (1, 2))."""
+    m, sd = _net(dev, "efficientnet-b3", 200)
+    x = _smooth((2, 3, 144, 144), 750)
+    with torch.no_grad():
+        ref = R.features_pooled(sd, x, "efficientnet-b3") @ sd["_fc.weight"].t() + sd["_fc.bias"]
+        got = m(x.to(dev)).cpu()
+    assert (got - ref).abs().max().item() < TOL
+    m300, sd300 = _net(dev, "efficientnet-b3", 200, image_size=300)
+    with torch.no_grad():
+        ref300 = R.extract_features(sd300, x, "efficientnet-b3", image_size=300)
+        got300 = m300.extract_features(x.to(dev)).cpu()
+        plain = R.extract_features(sd300, x, "efficientnet-b3")
+    assert got300.shape == ref300.shape and (got300 - ref300).abs().max().item() < TOL
+    assert (ref300 - plain).abs().max().item() > 10 * TOL
+
+
+def test_b0_fp32_storage_vs_oracle(dev, R):
+    """The same object builds every member of the family from its (width, depth) coefficients."""
+    m, sd = _net(dev, "efficientnet-b0", 10, seed=5)
+    x = _smooth((3, 3, 128, 128), 760)
+    with torch.no_grad():
+        ref = R.extract_features(sd, x, "efficientnet-b0")
+        got = m.extract_features(x.to(dev)).cpu()
+    assert got.shape == ref.shape == (3, 1280, 4, 4) and (got - ref).abs().max().item() < TOL
+
+
+def test_b3_fp16_storage_vs_oracle(dev, R):
+    """fp16 STORAGE of activations and 1x1 filters (fp32 accumulate / BN / swish / SE): measured error against the fp32
+    oracle on the 144^2 patches of config 5.  fp16 carries 11 significant bits: each stored map is rounded by 2^-11
+    relative, and 80 layers of that accumulate to ~1e-2 relative rms at the far end (the network itself, in fp32 storage,
+    lands 1e-6 from the oracle -- test above)."""
+    m16, sd = _net(dev, "efficientnet-b3", 200, dtype="f16")
+    m32, _ = _net(dev, "efficientnet-b3", 200, dtype="f32")
+    x = _smooth((4, 3, 144, 144), 770)
+    from adafocus_amd.utils import nchw_to_nhwc4
+    x4 = nchw_to_nhwc4(x.to(dev))
+    with torch.no_grad():
+        ref = R.features_pooled(sd, x, "efficientnet-b3")
+        v16 = m16.features_nhwc4(x4).cpu()
+        v32 = m32.features_nhwc4(x4).cpu()
+        b16 = m16.engine().forward_blocks(x4, 5)
+        refb = R.extract_features(sd, x, "efficientnet-b3", upto=5)
+    assert b16.dtype == torch.float16
+    relb = ((b16.float().cpu().permute(0, 3, 1, 2) - refb).pow(2).mean().sqrt() / refb.pow(2).mean().sqrt()).item()
+    rel = ((v16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print("effnet-b3 fp16 storage: rel rms after 5 blocks %.2e, pooled features %.2e, max abs %.2e" % (relb, rel, (v16 - ref).abs().max().item()))
+    assert not torch.equal(v16, v32)                        # the fp16 plan really ran
+    assert (v32 - ref).abs().max().item() < TOL
+    assert relb < 5e-3 and rel < 3e-2
+    assert (v16 - ref).abs().max().item() < 5e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_b3_batch_invariance_and_chunking(dev, monkeypatch):
+    """A frame's features do not depend on what else is in the batch (deterministic squeeze sums, no atomics), in both
+    storage modes; rows written into a strided `out` view match."""
+    for dtype in ("f32", "f16"):
+        m, _ = _net(dev, "efficientnet-b3", 200, dtype=dtype)
+        x = _smooth((5, 3, 144, 144), 780)
+        from adafocus_amd.utils import nchw_to_nhwc4
+        x4 = nchw_to_nhwc4(x.to(dev))
+        with torch.no_grad():
+            full = m.features_nhwc4(x4).clone()
+            again = m.features_nhwc4(x4).clone()
+            one = m.features_nhwc4(x4[3:4]).clone()
+            buf = torch.zeros((5, 1280 + 1536), device=dev)
+            m.features_nhwc4(x4, out=buf[:, 1280:])
+        assert torch.equal(full, again) and torch.equal(full[3:4], one)
+        assert torch.equal(buf[:, 1280:], full) and float(buf[:, :1280].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------ BASELINE config 5 as named
+def _act_args(**over):
+    class A:
+        pass
+    a = A()
+    a.__dict__.update(num_segments=16, num_classes=200, reward="random", dataset="actnet", input_size=224, batch_size=2,
+                      patch_size=144, with_glancer=True, feature_map_channels=1280, glance_size=224, action_dim=49,
+                      hidden_state_dim=1024, policy_conv=True, gpu=0, continuous=False, gamma=0.7, policy_lr=0.0003,
+                      random_patch=False, dropout=0.5, consensus="gru", hidden_dim=1024)
+    a.__dict__.update(over)
+    return a
+
+
+def test_config5_efficientnet_b3_t16_p144_end_to_end(dev, R):
+    """BASELINE config 5 as named: EfficientNet-B3 local CNN, T = 16, 144^2 patches, fp16 storage, through GFV.hot_path
+    (gather -> local CNN -> concat with the glancer vector -> GRU classifier).  Checker: the oracle's gather + the
+    EfficientNet restatement + the oracle's GRU classifier in fp32 (parity unpinned, see the module docstring); the same
+    model in fp32 storage meets the fp32 bar."""
+    from adafocus_amd.gfv_net import GFV
+    from oracle import ref_model as O
+    b, t = 3, 16
+    fr = torch.cat([_smooth((1, 3 * t, 224, 224), 790 + i) for i in range(b)])
+    _, act = synth.synth_actions(b * t, 7, seed=52)
+    gvec = rnd((b, t, 1280), 53, 0.5)
+    out = {}
+    for dtype in ("f16", "f32"):
+        m = GFV(_act_args(local_arch="efficientnet-b3", local_dtype=dtype)).eval()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 1007).items()}
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev)
+        assert m.focuser.feature_dim == 1536 and m.classifier.gru.weight_ih_l0.shape[1] == 1280 + 1536
+        with torch.no_grad():
+            lg, last, feat = m.hot_path(fr.view(b * t, 3, 224, 224).to(dev), gvec.to(dev), torch.from_numpy(act).to(dev), b, t)
+        out[dtype] = (lg.cpu(), last.cpu(), feat[:, :, 1280:].cpu())
+    with torch.no_grad():
+        patches = O.get_patch(fr.view(b * t, 3, 224, 224), torch.from_numpy(act), 144)
+        esd = {k[len("focuser.net."):]: v for k, v in sd.items() if k.startswith("focuser.net.")}
+        local = R.features_pooled(esd, patches, "efficientnet-b3").view(b, t, -1)
+        rl, rlast = O.recurrent_classifier(sd, "classifier.", torch.cat([gvec, local], dim=2))
+    lg32, last32, f32 = out["f32"]
+    assert (f32 - local).abs().max().item() < TOL and (lg32 - rl).abs().max().item() < TOL and (last32 - rlast).abs().max().item() < TOL
+    lg16, last16, f16 = out["f16"]
+    relf = ((f16 - local).pow(2).mean().sqrt() / local.pow(2).mean().sqrt()).item()
+    rell = ((lg16 - rl).pow(2).mean().sqrt() / rl.pow(2).mean().sqrt()).item()
+    print("config 5 (EfficientNet-B3, T=16, P=144): fp16 storage rel rms local features %.2e, logits %.2e, max |dlogit| %.2e"
+          % (relf, rell, (lg16 - rl).abs().max().item()))
+    assert relf < 3e-2 and rell < 3e-2
