@@ -62,9 +62,13 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
 }
 
 // sig: 0 = nothing left to do, 1 = sigmoid, 2 = swish (v * sigmoid(v); efficientnet_pytorch utils.py MemoryEfficientSwish)
+// The logistic function is 1 / (1 + 2^(-v log2 e)) on the hardware's exp2 / reciprocal units (v_exp_f32, v_rcp_f32: 1 ulp each,
+// ~2e-7 relative overall) -- expf() + an IEEE division are ~40 VALU instructions per element, which made the swish epilogues
+// of EfficientNet's expand convs (K = 24..384: hardly any MFMA work per output) VALU-bound.  Saturates correctly: v -> -inf
+// gives rcp(inf) = 0, v -> +inf gives rcp(1) = 1.
 __device__ __forceinline__ float finish_act(float v, int sig) {
     if (sig == 0) return v;
-    const float g = 1.f / (1.f + expf(-v));
+    const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
     return sig == 1 ? g : v * g;
 }
 

@@ -59,15 +59,25 @@ template <> struct Chunk<_Float16> {
     }
 };
 
+// logistic function on the exp2 / reciprocal units (1 ulp each; see conv_gemm.hip finish_act)
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == ADAF_ACT_SWISH) return v / (1.f + expf(-v));
-    if (act == ADAF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    if (act == ADAF_ACT_SWISH) return v * fast_sigmoid(v);
+    if (act == ADAF_ACT_SIGMOID) return fast_sigmoid(v);
     if (act == ADAF_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ADAF_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
     return v;
 }
 
 // ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
+// A block owns IMB images x one channel slice (CS = LPP 16-byte chunks) x TH output rows.  Its input rows (with the padding
+// columns, zero-filled) are staged once in LDS; then thread (image, channel chunk cg, pixel-group lane pg) walks the
+// groups of OXT horizontally adjacent outputs pg, pg + PG, ... of its image: every staged value is read and converted once
+// per filter row, the K taps of the row sit in registers.  The squeeze (global average pool of the ACTIVATED output) leaves
+// as per-block partial sums reduced in a fixed order -- thread partials through LDS, one thread per (image, channel) -- so
+// it is deterministic and independent of what else is in the batch.  All index arithmetic inside the loops is incremental
+// (runtime divisions were a third of the first version's instructions).
 struct DwArgs {
     const void* x;       // [n][H][W][C]
     void* out;           // [n][OH][OW][C]
@@ -78,10 +88,13 @@ struct DwArgs {
     int n, H, W, C, OH, OW;
     int pad_t, pad_l;    // padding BEFORE the first row / column (SAME padding is asymmetric: the rest falls off the far edge)
     int act;
-    int TH, tiles;       // output rows per block, blocks per image along y
+    int TH, tiles;       // output rows per block; tiles per image (tiles_y * tiles_x)
+    int TWG, tiles_x;    // x groups (of OXT outputs) per block, blocks per image along x
     int LPP, CS, slices; // lanes (16-byte chunks) per pixel in a block's channel slice, channels per slice, slices per pixel
     int pitch16;         // LDS pixel pitch in 16-byte units (>= LPP; chosen so neighbouring thread groups hit different banks)
-    int WP;              // staged columns: ((ceil(OW / OXT) * OXT - 1) * S + K)
+    int WP;              // staged columns: (TWG * OXT - 1) * S + K
+    int IMB, PG;         // images per block, pixel-group lanes per (image, channel chunk): IMB * PG * LPP <= 256
+    int igroups;         // ceil(n / IMB)
 };
 
 template <int K, int S, int OXT, typename T>
@@ -93,46 +106,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     int bid = blockIdx.x;
     const int slice = bid % a.slices; bid /= a.slices;
     const int tile = bid % a.tiles;
-    const int img = bid / a.tiles;
+    const int img0 = (bid / a.tiles) * a.IMB;
+    const int nimg = min(a.IMB, a.n - img0);
     const int c0 = slice * a.CS;
-    const int oy0 = tile * a.TH;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * a.TH;
     const int th = min(a.TH, a.OH - oy0);
+    const int xg0 = tx * a.TWG;              // first x group of this tile
     const int ihn = (th - 1) * S + K;        // staged input rows
-    const int iy0 = oy0 * S - a.pad_t, ix0 = -a.pad_l;
+    const int ihmax = (a.TH - 1) * S + K;
+    const int iy0 = oy0 * S - a.pad_t, ix0 = xg0 * OXT * S - a.pad_l;
     const int pitchB = a.pitch16 * 16;
-    char* xin = dsm;                                                         // [ihn][WP][pitch16 * 16 B]
-    float* wl = reinterpret_cast<float*>(dsm + (size_t)((a.TH - 1) * S + K) * a.WP * pitchB);   // [K*K][CS]
-    for (int i = tid; i < K * K * a.CS; i += 256) wl[i] = a.wt[(size_t)(i / a.CS) * a.C + c0 + i % a.CS];
-    float* sbl = wl + K * K * a.CS;                                          // [2][CS] BN scale, bias (read back in the epilogue:
-    for (int i = tid; i < 2 * a.CS; i += 256)                                //  16 fewer live registers through the tap loop)
-        sbl[i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
+    const int img_lds = ihmax * a.WP * pitchB;                               // bytes of one image's staged tile
+    char* xin = dsm;                                                         // [IMB][ihmax][WP][pitch16 * 16 B]
+    float* wl = reinterpret_cast<float*>(dsm + (size_t)a.IMB * img_lds);     // [K*K][CS] taps
+    float* sbl = wl + K * K * a.CS;                                          // [2][CS] BN scale, bias
+    for (int i = tid; i < K * K * a.CS; i += 256) {
+        const int tap = i / a.CS;
+        wl[i] = a.wt[(size_t)tap * a.C + c0 + (i - tap * a.CS)];
+    }
+    for (int i = tid; i < 2 * a.CS; i += 256) sbl[i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
     {
-        const T* xb = static_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.C + c0;
-        const int items = ihn * a.WP * a.LPP;
-        for (int i = tid; i < items; i += 256) {
-            const int cg = i % a.LPP, p = i / a.LPP;
-            const int col = p % a.WP, row = p / a.WP;
-            const int iy = iy0 + row, ix = ix0 + col;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.C + cg * V);
-            *reinterpret_cast<u32x4*>(xin + (size_t)p * pitchB + cg * 16) = v;
+        // staging: lane (pixel slot, chunk) walks the tile's pixels slot, slot + PP, ...
+        const int PP = 256 / a.LPP;
+        const int cgl = tid % a.LPP, slot = tid / a.LPP;
+        if (slot < PP) {
+            const int col0 = slot % a.WP, row0 = slot / a.WP;
+            const int dcol = PP % a.WP, drow = PP / a.WP;
+            for (int im = 0; im < nimg; ++im) {
+                const T* xb = static_cast<const T*>(a.x) + (size_t)(img0 + im) * a.H * a.W * a.C + c0 + cgl * V;
+                char* dst = xin + (size_t)im * img_lds + cgl * 16;
+                int col = col0, row = row0;
+                while (row < ihn) {
+                    const int iy = iy0 + row, ix = ix0 + col;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                        v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.C);
+                    *reinterpret_cast<u32x4*>(dst + (size_t)(row * a.WP + col) * pitchB) = v;
+                    col += dcol; row += drow;
+                    if (col >= a.WP) { col -= a.WP; ++row; }
+                }
+            }
         }
     }
     __syncthreads();
-    const int NT = (256 / a.LPP) * a.LPP;   // active threads: a thread keeps ONE channel group for all of its items
-    const int cg = tid % a.LPP;
+    const int TPI = a.LPP * a.PG;            // threads per image
+    const int im = tid / TPI, rem = tid - im * TPI;
+    const int cg = rem % a.LPP, pg = rem / a.LPP;
     float psum[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) psum[e] = 0.f;
-    if (tid < NT) {
-        const int nxg = (a.OW + OXT - 1) / OXT;
-        const int items = th * nxg * a.LPP;
-        T* ob = static_cast<T*>(a.out) + ((size_t)img * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
-        for (int i = tid; i < items; i += NT) {
-            const int g = i / a.LPP;
-            const int xg = g % nxg, r = g / nxg;
-            const int ox0 = xg * OXT;
+    if (im < nimg) {
+        const int nxg = min(a.TWG, (a.OW + OXT - 1) / OXT - xg0);     // x groups in this tile
+        const int dxg = a.PG % nxg, dr = a.PG / nxg;
+        int xg = pg % nxg, r = pg / nxg;
+        T* ob = static_cast<T*>(a.out) + ((size_t)(img0 + im) * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
+        const char* xim = xin + (size_t)im * img_lds + cg * 16;
+        while (r < th) {
+            const int ox0 = (xg0 + xg) * OXT;
             float acc[OXT][V];
 #pragma unroll
             for (int o = 0; o < OXT; ++o)
@@ -142,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             for (int ky = 0; ky < K; ++ky) {
                 // the K taps of this filter row, then every staged column once: column ci feeds output o through tap
                 // kx = ci - o * S (resolved at compile time), so each LDS value is read and converted exactly once
-                const char* rowp = xin + ((size_t)(r * S + ky) * a.WP + ox0 * S) * pitchB + cg * 16;
+                const char* rowp = xim + ((size_t)(r * S + ky) * a.WP + xg * OXT * S) * pitchB;
                 float w[K][V];
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
@@ -186,20 +217,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                     *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.C) = Chunk<T>::pack(v);
                 }
             }
+            xg += dxg; r += dr;
+            if (xg >= nxg) { xg -= nxg; ++r; }
         }
     }
     if (a.pool_part) {
-        // squeeze: sum over the block's pixels per channel, in a fixed order (thread partials in LDS, then one thread per channel)
+        // squeeze: sum over the block's pixels per (image, channel), in a fixed order
         __syncthreads();
-        float* red = reinterpret_cast<float*>(dsm);     // [256][V] (the input tile is dead)
+        float* red = reinterpret_cast<float*>(dsm);     // [256][V] (the input tiles are dead)
 #pragma unroll
         for (int e = 0; e < V; ++e) red[tid * V + e] = psum[e];
         __syncthreads();
-        if (tid < a.CS) {
-            const int g = tid / V, e = tid % V;
+        for (int t = tid; t < nimg * a.CS; t += 256) {          // (IMB * CS can exceed the block: 8 images x 48 channels)
+            const int ri = t / a.CS, c = t - ri * a.CS;
+            const int g = c / V, e = c % V;
             float s = 0.f;
-            for (int t = g; t < NT; t += a.LPP) s += red[t * V + e];
-            a.pool_part[((size_t)img * a.tiles + tile) * a.C + c0 + tid] = s;
+            for (int q = 0; q < a.PG; ++q) s += red[(ri * TPI + q * a.LPP + g) * V + e];
+            a.pool_part[((size_t)(img0 + ri) * a.tiles + tile) * a.C + c0 + c] = s;
         }
     }
 }
@@ -216,37 +250,97 @@ __global__ void pool_finish_kernel(const float* __restrict__ part, int n, int ti
 
 // ---- squeeze-and-excite gate: gate[n][c] = sigmoid(W_e swish(W_r mean[n] + b_r) + b_e) ----------------------------------
 // model.py MBConvBlock.forward: x_squeezed = adaptive_avg_pool2d(x, 1); _se_reduce -> swish -> _se_expand; sigmoid(.) * x.
-// One block per image.  part [n][tiles][C] partial sums (tiles = 1, inv_hw = 1 for a ready-made mean).
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int tiles, float inv_hw, int C,
+// A block owns G images, so every weight it fetches from L2 is used G times (one image per block moved 1.8 GB of filter
+// rows per launch at C = 2304); the two small matrix products run as wave-shuffle dot products / per-channel sums in a fixed
+// order.  part [n][tiles][C] partial sums (tiles = 1, inv_hw = 1 for a ready-made mean).
+template <int G>
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int tiles, float inv_hw, int n, int C,
                                                       const float* __restrict__ wr, const float* __restrict__ br, int SQ,
                                                       const float* __restrict__ we, int we_ldc, int we_ldj,
                                                       const float* __restrict__ be, float* __restrict__ gate) {
+    // (C % 4 == 0: the launcher checks.)  Everything that comes from L2 is fetched as 16-byte vectors in unrolled batches:
+    // the kernel is a chain of dependent L2 round trips otherwise (one block streams up to 1.8 MB of filter rows).
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    float* mean = reinterpret_cast<float*>(dsm);   // [C]
-    float* sq = mean + C;                          // [SQ]
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int t = 0; t < tiles; ++t) s += part[((size_t)img * tiles + t) * C + c];
-        mean[c] = s * inv_hw;
-    }
+    float* mean = reinterpret_cast<float*>(dsm);   // [G][C]
+    float* sq = mean + G * C;                      // [G][SQ]
+    const int img0 = blockIdx.x * G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ng = min(G, n - img0);
+    const int C4 = C >> 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        for (int c4 = tid; c4 < C4; c4 += 256) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (g < ng) {
+                const float* p = part + (size_t)(img0 + g) * tiles * C + 4 * c4;
+#pragma unroll 8
+                for (int t = 0; t < tiles; ++t) s += *reinterpret_cast<const f32x4*>(p + (size_t)t * C);
+            }
+            *reinterpret_cast<f32x4*>(mean + g * C + 4 * c4) = s * inv_hw;
+        }
     __syncthreads();
     for (int j = wave; j < SQ; j += 4) {
         const float* w = wr + (size_t)j * C;
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(mean[c], w[c], s);
+        float s[G];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) {
-            const float v = s + br[j];
-            sq[j] = v / (1.f + expf(-v));
+        for (int g = 0; g < G; ++g) s[g] = 0.f;
+#pragma unroll 4
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * c4);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(mean + g * C + 4 * c4);
+                s[g] = fmaf(m.x, wv.x, fmaf(m.y, wv.y, fmaf(m.z, wv.z, fmaf(m.w, wv.w, s[g]))));
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s[g] += __shfl_xor(s[g], off, 64);
+            if (lane == 0) {
+                const float v = s[g] + br[j];
+                sq[g * SQ + j] = v * fast_sigmoid(v);
+            }
         }
     }
     __syncthreads();
+    if (we_ldc == 1) {
+        // transposed expand filter [SQ][C] (the network's layout): a thread owns 4 consecutive channels
+        for (int c4 = tid; c4 < C4; c4 += 256) {
+            f32x4 s[G];
+            const f32x4 b = *reinterpret_cast<const f32x4*>(be + 4 * c4);
+#pragma unroll
+            for (int g = 0; g < G; ++g) s[g] = b;
+            const float* wp = we + 4 * c4;
+#pragma unroll 8
+            for (int j = 0; j < SQ; ++j) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)j * we_ldj);
+#pragma unroll
+                for (int g = 0; g < G; ++g) s[g] += wv * sq[g * SQ + j];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (g < ng) {
+                    const f32x4 o = {fast_sigmoid(s[g].x), fast_sigmoid(s[g].y), fast_sigmoid(s[g].z), fast_sigmoid(s[g].w)};
+                    *reinterpret_cast<f32x4*>(gate + (size_t)(img0 + g) * C + 4 * c4) = o;
+                }
+        }
+        return;
+    }
     for (int c = tid; c < C; c += 256) {
-        float s = be[c];
-        for (int j = 0; j < SQ; ++j) s = fmaf(sq[j], we[(size_t)c * we_ldc + (size_t)j * we_ldj], s);
-        gate[(size_t)img * C + c] = 1.f / (1.f + expf(-s));
+        float s[G];
+        const float b = be[c];
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[g] = b;
+        const float* wp = we + (size_t)c * we_ldc;
+#pragma unroll 8
+        for (int j = 0; j < SQ; ++j) {
+            const float wv = wp[(size_t)j * we_ldj];
+#pragma unroll
+            for (int g = 0; g < G; ++g) s[g] = fmaf(sq[g * SQ + j], wv, s[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g < ng) gate[(size_t)(img0 + g) * C + c] = fast_sigmoid(s[g]);
     }
 }
 
@@ -365,6 +459,50 @@ __global__ __launch_bounds__(256) void gated_project_kernel(const ProjArgs a) {
     // epilogue.  C layout: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
     T* ob = static_cast<T*>(a.out);
     const T* rs = static_cast<const T*>(a.res);
+    if (a.N % V == 0) {
+        // one 32 x 32 sub-tile at a time through a wave-private LDS slab, so that a lane owns V consecutive channels of a row:
+        // 16-byte identity loads and output stores (scalar stores of 2-byte halfs were the slowest part of the first version)
+        __syncthreads();                         // every wave is done with the operand stage
+        constexpr int SP = 36;                   // slab row pitch in floats
+        float* slab = smem + wave * 32 * SP;
+        constexpr int CPR = 32 / V;              // 16-byte chunks per sub-tile row: 8 (fp32) or 4 (fp16)
+        constexpr int RPI = 64 / CPR;            // rows per wave instruction: 8 or 16
+        const int cq = lane % CPR, rsub = lane / CPR;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) slab[((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * SP + (lane & 31)] = acc[j][i];
+            __builtin_amdgcn_wave_barrier();
+            const int n = n0 + j * 32 + cq * V;
+            if (n >= a.N) continue;
+            float sc[V], bi[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { sc[e] = a.scale ? a.scale[n + e] : 1.f; bi[e] = a.bias ? a.bias[n + e] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 32 / RPI; ++u) {
+                const int row = u * RPI + rsub;
+                const int m = m0 + wave * 32 + row;
+                if (m >= a.M) continue;
+                float v[V];
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(slab + row * SP + cq * V + e);
+                    v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], sc[e], bi[e]);
+                if (rs) {
+                    float r[V];
+                    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rs + (size_t)m * a.N + n), r);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[e] += r[e];
+                }
+                *reinterpret_cast<u32x4*>(ob + (size_t)m * a.N + n) = Chunk<T>::pack(v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
@@ -408,10 +546,13 @@ __global__ void avgpool_any_kernel(const T* __restrict__ x, int n, int hw, int c
 }
 
 // ---- launch planning ---------------------------------------------------------------------------------------------------
-struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, tiles; size_t lds; };
+struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, TWG, tiles_y, tiles_x, tiles, IMB, PG; size_t lds; };
 
-const size_t kDwLdsBudget = 40 * 1024;
+const size_t kDwLdsBudget = 48 * 1024;
 
+// Tile = TH output rows x TWG groups of OXT outputs, of IMB images, for one channel slice.  Chosen by a small cost model:
+// per output, (staged input chunks x the cost of a load + LDS store) + (thread passes x the tap work of a pass), the passes
+// counted with their idle lanes -- a tile whose items do not fill the block's lanes pays for the empty ones.
 bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     p->V = 16 / esize;
     if (C % p->V) return false;
@@ -423,21 +564,35 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     p->slices = C / p->CS;
     p->OXT = OW % 4 == 0 ? 4 : OW % 3 == 0 ? 3 : OW % 5 == 0 ? 5 : 4;
     const int nxg = (OW + p->OXT - 1) / p->OXT;
-    p->WP = (nxg * p->OXT - 1) * S + K;
-    // neighbouring thread groups (x groups, OXT * S pixels apart) should land half an LDS bank cycle (128 B) apart
-    p->pitch16 = p->LPP;
-    for (int t = p->LPP; t <= p->LPP + 8; ++t)
-        if ((p->OXT * S * t) % 16 == 8) { p->pitch16 = t; break; }
+    p->pitch16 = p->LPP | 1;                       // odd pitch: consecutive pixels start in different bank groups
     const size_t fixed = (size_t)(K * K + 2) * p->CS * 4;
-    auto bytes = [&](int th) { return (size_t)((th - 1) * S + K) * p->WP * p->pitch16 * 16 + fixed; };
-    int th = OH;
-    while (th > 1 && bytes(th) > kDwLdsBudget) --th;
-    if (bytes(th) > 64 * 1024) return false;
-    // even tiles
-    p->tiles = (OH + th - 1) / th;
-    p->TH = (OH + p->tiles - 1) / p->tiles;
-    p->tiles = (OH + p->TH - 1) / p->TH;
-    p->lds = bytes(p->TH);
+    const int lanes = 256 / p->LPP;
+    auto img_bytes = [&](int th, int twg) { return (size_t)((th - 1) * S + K) * ((twg * p->OXT - 1) * S + K) * p->pitch16 * 16; };
+    double best = 1e300;
+    p->TH = 0;
+    for (int th = 1; th <= OH; ++th) {
+        const int ty = (OH + th - 1) / th;
+        if ((OH + ty - 1) / ty != th) continue;                 // even tiles only
+        for (int twg = 1; twg <= nxg; ++twg) {
+            const int tx = (nxg + twg - 1) / twg;
+            if ((nxg + tx - 1) / tx != twg) continue;
+            const size_t ib = img_bytes(th, twg);
+            if (ib + fixed > kDwLdsBudget) break;
+            const int groups = th * twg;
+            int pg = groups < lanes ? groups : lanes;
+            int imb = 256 / (p->LPP * pg);
+            while (imb > 1 && (size_t)imb * ib + fixed > kDwLdsBudget) --imb;
+            if (imb < 1) imb = 1;
+            const int passes = (groups + pg - 1) / pg;
+            const double staged = (double)imb * ((th - 1) * S + K) * ((twg * p->OXT - 1) * S + K) * p->LPP;
+            const double cost = (staged * 6.0 + (double)passes * 256 * K * K * p->OXT + 600.0) / ((double)imb * groups * p->OXT * p->LPP);
+            if (cost < best) { best = cost; p->TH = th; p->TWG = twg; p->IMB = imb; p->PG = pg; p->tiles_y = ty; p->tiles_x = tx; }
+        }
+    }
+    if (p->TH == 0) return false;
+    p->tiles = p->tiles_y * p->tiles_x;
+    p->WP = (p->TWG * p->OXT - 1) * S + K;
+    p->lds = (size_t)p->IMB * img_bytes(p->TH, p->TWG) + fixed;
     const size_t red = (size_t)256 * p->V * 4;
     if (p->lds < red) p->lds = red;
     return true;
@@ -445,7 +600,7 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
 
 template <int K, int S, typename T>
 void launch_dw_oxt(const DwArgs& a, int oxt, size_t lds, hipStream_t s) {
-    const dim3 grid((unsigned)((size_t)a.n * a.tiles * a.slices)), block(256);
+    const dim3 grid((unsigned)((size_t)a.igroups * a.tiles * a.slices)), block(256);
     if (oxt == 3) hipLaunchKernelGGL((dw_same_kernel<K, S, 3, T>), grid, block, lds, s, a);
     else if (oxt == 5) hipLaunchKernelGGL((dw_same_kernel<K, S, 5, T>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((dw_same_kernel<K, S, 4, T>), grid, block, lds, s, a);
@@ -481,7 +636,9 @@ int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, 
     memset(&a, 0, sizeof(a));
     a.x = x; a.out = out; a.wt = wt; a.scale = scale; a.bias = bias; a.pool_part = pool_part;
     a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
-    a.TH = p.TH; a.tiles = p.tiles; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices; a.pitch16 = p.pitch16; a.WP = p.WP;
+    a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
+    a.pitch16 = p.pitch16; a.WP = p.WP;
+    a.IMB = p.IMB; a.PG = p.PG; a.igroups = (n + p.IMB - 1) / p.IMB;
     const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.lds, s)
                                             : launch_dw_t<float>(a, k, stride, p.OXT, p.lds, s);
     return ok ? p.tiles : -1;
@@ -494,8 +651,9 @@ void adaf_launch_pool_finish(const float* part, int n, int tiles, int c, int hw,
 
 void adaf_launch_se_gate(const float* part, int tiles, int hw, int n, int c, const float* wr, const float* br, int sq,
                          const float* we, int we_ldc, int we_ldj, const float* be, float* gate, hipStream_t s) {
-    hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), (size_t)(c + sq) * 4, s, part, tiles, 1.f / (float)hw, c, wr, br, sq, we,
-                       we_ldc, we_ldj, be, gate);
+    constexpr int G = 4;
+    hipLaunchKernelGGL((se_gate_kernel<G>), dim3((unsigned)((n + G - 1) / G)), dim3(256), (size_t)G * (c + sq) * 4, s, part, tiles,
+                       1.f / (float)hw, n, c, wr, br, sq, we, we_ldc, we_ldj, be, gate);
 }
 
 int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, const float* gate, const void* w, int n,
@@ -929,7 +1087,7 @@ int adaf_dwconv_same_bn_act(adaf_handle* h, const void* x, int dtype, int n, int
 int adaf_se_gate_f32(adaf_handle* h, const float* pool_mean, int n, int c, const float* w_reduce, const float* b_reduce, int squeezed,
                      const float* w_expand, const float* b_expand, float* gate, void* stream) {
     if (!h || !pool_mean || !w_reduce || !b_reduce || !w_expand || !b_expand || !gate) return efail(h, ADAF_E_BADARG, "se_gate: null pointer");
-    if (n <= 0 || c <= 0 || squeezed <= 0 || (size_t)(c + squeezed) * 4 > 60 * 1024) return efail(h, ADAF_E_BADARG, "se_gate: extents");
+    if (n <= 0 || c <= 0 || c % 4 || squeezed <= 0 || (size_t)(c + squeezed) * 16 > 60 * 1024) return efail(h, ADAF_E_BADARG, "se_gate: extents (c %% 4 == 0)");
     adaf_launch_se_gate(pool_mean, 1, 1, n, c, w_reduce, b_reduce, squeezed, w_expand, squeezed, 1, b_expand, gate, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : efail(h, ADAF_E_LAUNCH, "se_gate: %s", hipGetErrorString(e));

@@ -164,6 +164,8 @@ def extract_features(sd, x, name="efficientnet-b3", image_size=None, upto=None):
             return x
         x = mbconv(sd, "_blocks.%d." % bi, x, b, size)
         size = out_size(size, b["stride"])
+    if upto is not None:
+        return x
     return swish(_bn(sd, "_bn1", F.conv2d(x, sd["_conv_head.weight"])))
 
 
