@@ -137,14 +137,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                 const T* xb = static_cast<const T*>(a.x) + (size_t)(img0 + im) * a.H * a.W * a.C + c0 + cgl * V;
                 char* dst = xin + (size_t)im * img_lds + cgl * 16;
                 int col = col0, row = row0;
+                // batches of four: the loads of a batch are all in flight before the first LDS store waits on one
                 while (row < ihn) {
-                    const int iy = iy0 + row, ix = ix0 + col;
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                        v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.C);
-                    *reinterpret_cast<u32x4*>(dst + (size_t)(row * a.WP + col) * pitchB) = v;
-                    col += dcol; row += drow;
-                    if (col >= a.WP) { col -= a.WP; ++row; }
+                    u32x4 v[4];
+                    int off[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int iy = iy0 + row, ix = ix0 + col;
+                        v[u] = u32x4{0u, 0u, 0u, 0u};
+                        off[u] = row < ihn ? (row * a.WP + col) * pitchB : -1;
+                        if (row < ihn && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                            v[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.C);
+                        col += dcol; row += drow;
+                        if (col >= a.WP) { col -= a.WP; ++row; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) *reinterpret_cast<u32x4*>(dst + off[u]) = v[u];
                 }
             }
         }

@@ -56,20 +56,22 @@ def act_args(t, p, b, **over):
     return a
 
 
-def config5_row(dev, b, streams, frames):
-    """BASELINE config 5's shape (T = 16, P = 144, MBConv local CNN, half-precision storage): the hot path with
-    adafocus_amd.mbconv_local as the local CNN, fp16 and fp32 storage side by side.  No reference implementation exists
-    (EfficientNet is a dead import there): parity unpinned, never the headline."""
-    from adafocus_amd import synth
+def config5_row(dev, b, streams, frames, steps=30):
+    """BASELINE config 5 as named: EfficientNet-B3 local CNN, T = 16, P = 144, fp16 storage -- the hot path (gather ->
+    adafocus_amd.efficientnet on csrc/effnet.hip -> GRU classifier), with fp32 storage beside it, and the local CNN alone
+    priced against HBM.  No reference implementation exists (EfficientNet is a dead import there):
+    parity unpinned (checker = oracle/ref_effnet.py, the published algorithm of efficientnet_pytorch); never the headline."""
+    from adafocus_amd import synth, workload
     from adafocus_amd.gfv_net import GFV
+    from adafocus_amd.utils import get_patch_nhwc4
     t, p = 16, 144
     out = {}
     _, act_np = synth.synth_actions(b * t, 7, seed=5)
     actions = torch.from_numpy(act_np).to(dev)
     gvec = torch.randn((b, t, 1280), device=dev)
     ref = None
-    for arch in ("mbconv_f32", "mbconv_f16"):
-        model = GFV(act_args(t, p, b, local_arch=arch)).eval()
+    for dtype in ("f32", "f16"):
+        model = GFV(act_args(t, p, b, local_arch="efficientnet-b3", local_dtype=dtype)).eval()
         model.load_state_dict(synth_model_state(model, 1007), strict=True)
         model = model.to(dev)
         with torch.no_grad():
@@ -79,19 +81,41 @@ def config5_row(dev, b, streams, frames):
                     model.hot_path(frames, gvec, actions, b, t)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(10):
+            for i in range(steps):
                 with torch.cuda.stream(streams[i % len(streams)]):
                     model.hot_path(frames, gvec, actions, b, t)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-        out[arch] = {"clips_per_s": round(10 * b / dt, 1), "ms_per_step": round(dt * 100, 3)}
+            # the local CNN alone, HIP events on its stream, against the bytes of the launch plan that runs
+            x4 = get_patch_nhwc4(frames, actions, p)
+            net = model.focuser.net
+            for _ in range(2):
+                net.features_nhwc4(x4)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                net.features_nhwc4(x4)
+            e1.record()
+            torch.cuda.synchronize()
+            cnn_ms = e0.elapsed_time(e1) / 10
+        by = float(workload.effnet_bytes_per_frame("efficientnet-b3", p, 2 if dtype == "f16" else 4)) * b * t
+        out[dtype + "_storage"] = {
+            "clips_per_s": round(steps * b / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "local_cnn": {"bound": "hbm", "ms": round(cnn_ms, 3), "achieved": round(by / cnn_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(by / cnn_ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_patch": int(by / (b * t)),
+                          "tflops": round(2.0 * workload.effnet_macs_per_frame("efficientnet-b3", p) * b * t / cnn_ms / 1e9, 1)}}
         if ref is None:
             ref = lg
         else:
-            out[arch]["rel_rms_logit_diff_vs_f32_storage"] = float(((lg - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+            out[dtype + "_storage"]["rel_rms_logit_diff_vs_f32_storage"] = float(((lg - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
         del model
-    out["note"] = ("gather (P=144) + MobileNetV2-style MBConv local CNN over B*T patches + GRU classifier, B=%d, T=16; fp16 = activations "
-                   "and 1x1 weights stored as fp16, fp32 accumulate; parity unpinned (no reference implementation of this config)" % b)
+    out["fp16_over_fp32_storage_speedup"] = {"hot_path": round(out["f16_storage"]["clips_per_s"] / out["f32_storage"]["clips_per_s"], 3),
+                                             "local_cnn": round(out["f32_storage"]["local_cnn"]["ms"] / out["f16_storage"]["local_cnn"]["ms"], 3)}
+    out["gmac_per_patch"] = round(workload.effnet_macs_per_frame("efficientnet-b3", p) / 1e9, 4)
+    out["note"] = ("gather (P=144) + EfficientNet-B3 (MBConv + squeeze-excite + swish, 3x3 / 5x5 depthwise, 26 blocks, 1536-d features) over "
+                   "B*T = %d patches + GRU classifier, B=%d, T=16; fp16 = activations and 1x1 filters stored as fp16, fp32 accumulate; "
+                   "local_cnn = the network alone (HIP events), bytes = activation in + out of every launch (workload.effnet_bytes_per_frame); "
+                   "parity unpinned (no reference implementation of this config)" % (b * t, b))
     return out
 
 
@@ -548,9 +572,9 @@ def main():
                 res["next_rows"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.skip_extras and (t, p) == (16, 96):
             try:
-                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = config5_row(dev, b, streams, frames)
+                res.setdefault("also", {})["config5_T16_P144_efficientnet_b3"] = config5_row(dev, b, streams, frames)
             except Exception as exc:  # never fail the bench on an `also` row
-                res.setdefault("also", {})["config5_T16_P144_mbconv_local"] = {"error": repr(exc)[:300]}
+                res.setdefault("also", {})["config5_T16_P144_efficientnet_b3"] = {"error": repr(exc)[:300]}
         if os.environ.get("ADAF_BENCH_LAUNCHES"):
             res["launches"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()} for e in per_launch]
         if a.full and not a.skip_extras:
