@@ -20,7 +20,7 @@ CONV_TILES = 4
 
 # every symbol include/adafocus.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "adaf_version", "adaf_create", "adaf_destroy", "adaf_last_error", "adaf_device_cus", "adaf_set_gru_persistent", "adaf_set_conv_pos_major",
+    "adaf_version", "adaf_create", "adaf_destroy", "adaf_last_error", "adaf_device_cus", "adaf_set_gru_persistent", "adaf_set_conv_pos_major", "adaf_gru_scan_timeouts",
     "adaf_crop_gather_f32", "adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32", "adaf_pack_conv_weight_f32",
     "adaf_fold_bn_f32", "adaf_maxpool3x3s2_f32", "adaf_global_avgpool_f32", "adaf_temporal_shift_f32",
     "adaf_resnet50_create", "adaf_resnet50_destroy", "adaf_resnet50_set_param", "adaf_resnet50_finalize",
@@ -67,6 +67,7 @@ def load_library():
     lib.adaf_device_cus.argtypes = [vp]
     lib.adaf_set_gru_persistent.argtypes = [vp, ip]
     lib.adaf_set_conv_pos_major.argtypes = [vp, ip]
+    lib.adaf_gru_scan_timeouts.argtypes = [vp, C.POINTER(C.c_uint)]
     lib.adaf_crop_gather_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, ip, vp, vp]
     for name in ("adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32"):
         getattr(lib, name).argtypes = [vp, C.POINTER(ConvParams), vp, vp, vp, vp, vp, vp, vp]

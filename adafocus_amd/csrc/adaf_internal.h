@@ -11,6 +11,8 @@ struct adaf_handle {
     int device = 0;
     int cus = 256;
     float* zeros = nullptr;  // device, 256 bytes of zeros
+    unsigned* scan_timeouts = nullptr;   // device counter: blocks of persistent GRU scans whose grid barrier timed out (they NaN-poison
+                                         // their outputs; adaf_gru_scan_timeouts() makes that visible to the host)
     int conv_pos_major = 1;  // k x k convs may use position-major tiles with padding-tap skipping (conv_gemm.hip PM kernels)
     int gru_persistent = 1;  // GRU scans as one persistent kernel where the shape allows (gru_scan.hip): 0 off, 1 on, 2 on + cooperative launch
     // At most scan_slots persistent scans may execute at once (their grid barriers need every block resident; how many
@@ -101,7 +103,8 @@ int adaf_gru_scan_blocks_per_cu();
 bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int resident_blocks);
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
                                            unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
-                                           float* logits, float* last, int classes, bool cooperative, hipStream_t s);
+                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts,
+                                           hipStream_t s);
 
 // conv_gemm.hip
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0

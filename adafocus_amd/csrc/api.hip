@@ -91,6 +91,8 @@ int adaf_create(int device, adaf_handle** out) {
     (void)hipSetDevice(device);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->zeros), 256);
     if (e == hipSuccess) e = hipMemset(h->zeros, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->scan_timeouts), 256);
+    if (e == hipSuccess) e = hipMemset(h->scan_timeouts, 0, 256);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->scan_done[i], hipEventDisableTiming);
     if (e == hipSuccess) {
         // The occupancy API can report one block per CU too many for kernels in this SGPR range (the scan uses 90;
@@ -109,6 +111,7 @@ int adaf_create(int device, adaf_handle** out) {
 
 int adaf_destroy(adaf_handle* h) {
     if (h && h->zeros) (void)hipFree(h->zeros);
+    if (h && h->scan_timeouts) (void)hipFree(h->scan_timeouts);
     if (h)
         for (int i = 0; i < 4; ++i)
             if (h->scan_done[i]) (void)hipEventDestroy(h->scan_done[i]);
@@ -128,6 +131,17 @@ int adaf_set_gru_persistent(adaf_handle* h, int on) {
     if (on < 0 || on > 2) return fail(h, ADAF_E_BADARG, "set_gru_persistent: mode %d (0 off, 1 on, 2 on + cooperative launch)", on);
     h->gru_persistent = on;
     return ADAF_OK;
+}
+
+int adaf_gru_scan_timeouts(adaf_handle* h, unsigned* count_out) {
+    if (!h || !count_out) return ADAF_E_BADARG;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(h->device);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(count_out, h->scan_timeouts, sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipSetDevice(cur);
+    return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "gru_scan_timeouts");
 }
 
 // ---- crop ------------------------------------------------------------------------------
@@ -820,7 +834,7 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
         h->scan_next = (slot + 1) % h->scan_slots;
         if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan scan_slots launches ago has finished
         hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), batch, steps, fc_w,
-                                                       fc_b, logits_all, last, classes, h->gru_persistent == 2, st);
+                                                       fc_b, logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, st);
         if (e != hipSuccess) return hip_fail(h, e, "gru scan launch");
         (void)hipEventRecord(h->scan_done[slot], st);
         h->scan_used[slot] = true;

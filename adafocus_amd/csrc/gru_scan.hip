@@ -41,6 +41,7 @@ struct GruScanArgs {
     float* logits;       // [B*T, C]
     float* last;         // [B, C] or nullptr
     int C, cpb;          // classes, classes per block
+    unsigned* timeouts;  // device counter bumped by a block whose barrier wait ran out (or nullptr)
 };
 
 template <int H, int JB>
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
             __syncthreads();
             if (timed_out) {   // never observed; refuses to hang the device if the grid cannot become co-resident
+                if (tid == 0 && a.timeouts) atomicAdd(a.timeouts, 1u);     // ... and tells the host (adaf_gru_scan_timeouts)
                 const float nan = __builtin_nanf("");
                 for (int idx = tid; idx < B * JB; idx += 256)
                     for (int tt = t + 1; tt < T; ++tt) a.hs[((size_t)(idx / JB) * T + tt) * H + j0 + idx % JB] = nan;
@@ -185,8 +187,10 @@ bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int residen
 
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
                                            unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
-                                           float* logits, float* last, int classes, bool cooperative, hipStream_t s) {
+                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts,
+                                           hipStream_t s) {
     GruScanArgs a;
+    a.timeouts = timeouts;
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;
     a.fcw = fcw; a.fcb = fcb; a.logits = logits; a.last = last; a.C = fcw ? classes : 0;
     a.cpb = fcw ? (classes + kGrid - 1) / kGrid : 0;

@@ -43,8 +43,10 @@ struct adaf_mobilenetv2 {
     // Two frame chunks travel through the network side by side (the second on this library-owned stream, forked from and
     // joined to the caller's stream by events -- still fully asynchronous): the tail's launches are 30-100 us each and
     // leave the device half empty on their own; a neighbour fills the ramps and tails.
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // One helper stream + event pair PER CALLER STREAM: forwards issued from different streams (pipelined batches,
+    // bench --streams) must not serialise their second chunks on one shared helper.
+    struct Aux { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    std::map<hipStream_t, Aux> aux;
     bool pair = true;
 };
 
@@ -173,9 +175,11 @@ int adaf_mobilenetv2_create(adaf_handle* h, adaf_mobilenetv2** out) {
 
 int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
     if (!net) return ADAF_OK;
-    if (net->aux) (void)hipStreamDestroy(net->aux);
-    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    for (auto& kv : net->aux) {
+        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+        if (kv.second.ev_fork) (void)hipEventDestroy(kv.second.ev_fork);
+        if (kv.second.ev_join) (void)hipEventDestroy(kv.second.ev_join);
+    }
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
         if (L.w16) (void)hipFree(L.w16);
@@ -399,11 +403,16 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
     };
     const size_t per_chunk = (size_t)chunk * (2 * io + ex + dws);
     const bool pair = net->pair && n > chunk;
-    if (pair && !net->aux) {
-        if (hipStreamCreateWithFlags(&net->aux, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess)
-            return mfail(h, ADAF_E_NOMEM, "mobilenetv2: could not create the second-chunk stream");
+    adaf_mobilenetv2::Aux* ax = nullptr;
+    if (pair) {
+        ax = &net->aux[st];
+        if (!ax->stream) {
+            if (net->aux.size() > 16) return mfail(h, ADAF_E_NOMEM, "mobilenetv2: more than 16 caller streams");
+            if (hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ax->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ax->ev_join, hipEventDisableTiming) != hipSuccess)
+                return mfail(h, ADAF_E_NOMEM, "mobilenetv2: could not create the second-chunk stream");
+        }
     }
     float* base2 = static_cast<float*>(ws) + per_chunk;
     for (int f0 = 0; f0 < n; f0 += chunk) {
@@ -412,14 +421,17 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
         if (pair && f0 + chunk < n) {
             const int f1 = f0 + chunk;
             const int nc1 = (n - f1) < chunk ? (n - f1) : chunk;
-            (void)hipEventRecord(net->ev_fork, st);
-            (void)hipStreamWaitEvent(net->aux, net->ev_fork, 0);
-            if ((rc = run_chunk(f0, nc, bufA, bufB, bufE, bufD, st))) return rc;
-            if ((rc = run_chunk(f1, nc1, base2, base2 + (size_t)chunk * io, base2 + (size_t)chunk * 2 * io,
-                                base2 + (size_t)chunk * (2 * io + ex), net->aux)))
-                return rc;
-            (void)hipEventRecord(net->ev_join, net->aux);
-            (void)hipStreamWaitEvent(st, net->ev_join, 0);
+            (void)hipEventRecord(ax->ev_fork, st);
+            (void)hipStreamWaitEvent(ax->stream, ax->ev_fork, 0);
+            rc = run_chunk(f0, nc, bufA, bufB, bufE, bufD, st);
+            if (!rc)
+                rc = run_chunk(f1, nc1, base2, base2 + (size_t)chunk * io, base2 + (size_t)chunk * 2 * io,
+                               base2 + (size_t)chunk * (2 * io + ex), ax->stream);
+            // ALWAYS join, also when a launch failed after the fork: whatever the helper stream still has queued writes the
+            // caller's workspace / outputs, and the caller may reuse them as soon as this call returns
+            (void)hipEventRecord(ax->ev_join, ax->stream);
+            (void)hipStreamWaitEvent(st, ax->ev_join, 0);
+            if (rc) return rc;
             f0 = f1;
         } else if ((rc = run_chunk(f0, nc, bufA, bufB, bufE, bufD, st))) return rc;
     }

@@ -250,6 +250,14 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
         score(*lagging)
     if pending is not None:
         finish(pending)
+    if dev.type == "cuda":
+        # a persistent GRU scan whose grid barrier timed out poisons its logits with NaN and returns hipSuccess:
+        # make that a loud failure of the evaluation, never an accuracy figure
+        from . import hip_ops
+        starved = hip_ops.gru_scan_timeouts(dev)
+        if starved:
+            raise RuntimeError("adafocus_amd.validate: %d GRU scan block(s) timed out at their grid barrier (results are NaN-"
+                               "poisoned); rerun with hip_ops.set_gru_persistent(2) (cooperative launch)" % starved)
     ncls = args.num_classes
     empty = torch.zeros((0, ncls), device=dev)
     all_pred = gather_variable(torch.cat(preds) if preds else empty).cpu()

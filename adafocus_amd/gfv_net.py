@@ -138,7 +138,10 @@ class GFV(nn.Module):
         over.  clips: the loader's stacked uint8 clips (B, H, W, T*3) or normalised pixel-major frames (B*T, H, W, 4).
         Returns (logits, last, idx, done, handoff) -- HIP events: the outputs belong to the back stream until the
         consumer's stream waits on `done` (``torch.cuda.current_stream().wait_event(done)``) or `pipeline_flush()` is
-        called; `clips` may be overwritten once `handoff` has passed (the front half has consumed it)."""
+        called.  `handoff` is the RELEASE event of `clips`: the caller may overwrite the buffer once it has passed.  For
+        uint8 clips that is when the front half has consumed them (ingest makes a fresh frame tensor); for normalised
+        float frames the back stream's gather reads the caller's buffer itself, so `handoff` is `done` (a slot
+        reused at the front-half event raced the crop)."""
         dev = clips.device
         if self._pipe is None or self._pipe[0].device != dev:
             self._pipe = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
@@ -169,9 +172,11 @@ class GFV(nn.Module):
             logits, last, _ = self.hot_path(frames, fvec.view(b, t, -1) if self.with_glancer else None, actions, b, t)
             done = torch.cuda.Event()
             done.record(back)
+            if clips.dtype != torch.uint8:
+                clips.record_stream(back)
         for x in (logits, last, idx):
             x.record_stream(cur)
-        return logits, last, idx, done, handoff
+        return logits, last, idx, done, (handoff if clips.dtype == torch.uint8 else done)
 
     def pipeline_flush(self):
         """Make the current stream wait for everything offline_forward_pipelined has enqueued."""

@@ -194,19 +194,29 @@ class _StreamScratch:
     """One scratch tensor per HIP stream: passes enqueued on different streams (pipelined batches) must not share
     intermediates.  Each tensor is allocated while its stream is current, so the caching allocator only ever reuses
     its memory in that stream's order; the least recently used entries are dropped beyond `cap` streams (short-lived
-    streams would otherwise pin gigabytes each)."""
+    streams would otherwise pin gigabytes each).  `cap` defaults to 6 (bench.py uses 3 streams + the model's own 2) and
+    can be raised with ADAF_SCRATCH_STREAMS; an eviction is reported once per object on stderr, because rotating over
+    more streams than `cap` means a multi-GB reallocation per call."""
 
-    def __init__(self, device, cap=6):
-        self.device, self.cap, self._ws = device, cap, {}
+    def __init__(self, device, cap=None):
+        import os
+        self.device = device
+        self.cap = int(cap or os.environ.get("ADAF_SCRATCH_STREAMS", 6))
+        self._ws, self._warned = {}, False
 
     def get(self, need_bytes):
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._ws.pop(key, None)
         if ws is None or ws.numel() * 4 < need_bytes:
-            ws = torch.empty(max(need_bytes // 4, 1), device=self.device, dtype=torch.float32)
+            ws = torch.empty(max((need_bytes + 3) // 4, 1), device=self.device, dtype=torch.float32)
         self._ws[key] = ws                       # (re)insert as most recently used
         while len(self._ws) > self.cap:
             self._ws.pop(next(iter(self._ws)))
+            if not self._warned:
+                import sys
+                print("adafocus_amd: more than %d streams rotate over one network's scratch space; the least recently used "
+                      "buffer was dropped (set ADAF_SCRATCH_STREAMS to keep more)" % self.cap, file=sys.stderr)
+                self._warned = True
         return ws
 
     def __len__(self):
@@ -307,6 +317,16 @@ def set_gru_persistent(mode, device=None):
     dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
     h = L.handle(dev)
     L.check(L.load_library().adaf_set_gru_persistent(h, int(mode)), h)
+
+
+def gru_scan_timeouts(device=None):
+    """Blocks of persistent GRU scans whose grid barrier timed out since the handle was created (they NaN-poison their
+    outputs).  Synchronises the device; 0 = every scan completed normally."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    h = L.handle(dev)
+    n = C.c_uint(0)
+    L.check(L.load_library().adaf_gru_scan_timeouts(h, C.byref(n)), h)
+    return int(n.value)
 
 
 def set_conv_pos_major(on, device=None):

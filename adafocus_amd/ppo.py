@@ -8,8 +8,9 @@ and out of scope.
 policy input is only the glancer feature map and its own hidden state (ppo.py:67-96), so all T
 actions are computed before any patch is cropped -- 1x1 conv + Linear over all B*T frames at once,
 one GRU scan, one actor GEMM, arg-max + table lookup in one small kernel.  ``act`` (one step,
-reference signature, hidden state carried in ``memory.hidden``) runs the same kernels with T = 1 and
-``h0`` = the previous step's state; nothing on this surface is an ATen / MIOpen op.
+reference signature, hidden state carried in ``memory.hidden`` element for element like the reference: the zero
+state after `restart_batch`, then one entry per step) runs the same kernels with T = 1 and ``h0`` = the previous
+step's state; both encoders (`policy_conv` True / False) run on the engine; nothing on this surface is an ATen / MIOpen op.
 """
 import torch
 from torch import nn
@@ -48,24 +49,35 @@ class ActorCritic(nn.Module):
         """One step, eval branch of ppo.py:67-96 (argmax of the actor's softmax)."""
         if training:
             raise NotImplementedError("adafocus_amd implements the inference branch of the policy only")
-        if not self.policy_conv:
-            raise NotImplementedError("adafocus_amd policy: policy_conv=True (the shipped configs) only")
-        if restart_batch:
-            del memory.hidden[:]
         b = state_ini.size(0)
-        # (B, C, h, w) reference layout -> pixel-major; free when `state_ini` is a permuted view of the HIP glancer's map
-        nhwc = state_ini.permute(0, 2, 3, 1).contiguous()
-        hw = nhwc.shape[1] * nhwc.shape[2]
-        w_enc, w_lin = self._hip_weights(hw)
-        lin, g, actor = self.state_encoder[3], self.gru, self.actor[0]
-        e = hip_ops.conv2d_bn_act(nhwc, w_enc, act=hip_ops.ACT_RELU)
-        e = hip_ops.linear(e.view(b, -1), w_lin, lin.bias.detach(), act=hip_ops.ACT_RELU)
-        h0 = memory.hidden[-1].view(b, -1) if memory.hidden else None       # restart: h0 = 0 (ppo.py:70-73)
+        if restart_batch:
+            # ppo.py:68-70: the list restarts with the zero state, so memory.hidden holds k + 1 entries after k steps
+            del memory.hidden[:]
+            memory.hidden.append(torch.zeros(1, b, self.hidden_state_dim, device=state_ini.device))
+        e = self._encode(state_ini)
+        g, actor = self.gru, self.actor[0]
         hs = hip_ops.gru_seq_forward(e.view(b, 1, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
-                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach(), h0=h0)
+                                     g.bias_ih_l0.detach(), g.bias_hh_l0.detach(), h0=memory.hidden[-1].view(b, -1))
         memory.hidden.append(hs.view(1, b, -1))
         logits = hip_ops.linear(hs.view(b, -1), actor.weight.detach(), actor.bias.detach())
         return hip_ops.argmax_rows(logits)
+
+    def _encode(self, state):
+        """state_encoder on the engine.  policy_conv=True (ppo.py:31-39: MobileNet / EfficientNet / RegNet feature maps):
+        1x1 conv + ReLU + flatten + Linear + ReLU over (N, C, h, w) [reference layout] or (N, h, w, C) [pixel-major];
+        policy_conv=False (ppo.py:40-47: ResNet / DenseNet features): `state.flatten(1)` through two Linear + ReLU."""
+        n = state.shape[0]
+        if not self.policy_conv:
+            l0, l1 = self.state_encoder[0], self.state_encoder[2]
+            e = hip_ops.linear(state.reshape(n, -1).contiguous(), l0.weight.detach(), l0.bias.detach(), act=hip_ops.ACT_RELU)
+            return hip_ops.linear(e, l1.weight.detach(), l1.bias.detach(), act=hip_ops.ACT_RELU)
+        # (B, C, h, w) reference layout -> pixel-major; free when `state` is a permuted view of the HIP glancer's map
+        nhwc = state.permute(0, 2, 3, 1).contiguous() if state.shape[1] == self.feature_dim and state.shape[-1] != self.feature_dim else state
+        hw = nhwc.shape[1] * nhwc.shape[2]
+        w_enc, w_lin = self._hip_weights(hw)
+        lin = self.state_encoder[3]
+        e = hip_ops.conv2d_bn_act(nhwc, w_enc, act=hip_ops.ACT_RELU)
+        return hip_ops.linear(e.view(n, -1), w_lin, lin.bias.detach(), act=hip_ops.ACT_RELU)
 
     def _hip_weights(self, hw):
         """Engine-layout views of the parameters (cached on the parameter versions)."""
@@ -83,28 +95,17 @@ class ActorCritic(nn.Module):
     def act_sequence_nhwc(self, featmap_nhwc, b, t, table):
         """featmap (B*T, h, w, C) pixel-major (the HIP glancer's output) -> (idx (B,T) int64,
         actions (B*T, 2) fp32 = table[idx])."""
-        if not self.policy_conv:
-            raise NotImplementedError("adafocus_amd policy: policy_conv=True (the shipped configs) only")
-        n, hh, ww, _ = featmap_nhwc.shape
-        w_enc, w_lin = self._hip_weights(hh * ww)
-        lin, g, act = self.state_encoder[3], self.gru, self.actor[0]
-        e = hip_ops.conv2d_bn_act(featmap_nhwc, w_enc, act=hip_ops.ACT_RELU)                     # (n, h, w, 32)
-        e = hip_ops.linear(e.view(n, -1), w_lin, lin.bias.detach(), act=hip_ops.ACT_RELU)        # (n, 1024)
+        n = featmap_nhwc.shape[0]
+        g, act = self.gru, self.actor[0]
+        if self.policy_conv:
+            e = self._encode(featmap_nhwc)                                                       # (n, 1024)
+        else:   # the Linear encoder flattens the reference's (C, h, w) order
+            e = self._encode(featmap_nhwc.permute(0, 3, 1, 2))
         hs = hip_ops.gru_seq_forward(e.view(b, t, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
                                      g.bias_ih_l0.detach(), g.bias_hh_l0.detach())
         logits = hip_ops.linear(hs.view(b * t, -1), act.weight.detach(), act.bias.detach())
         idx, actions = hip_ops.grid_actions(logits, table)
         return idx.view(b, t), actions
-
-    @torch.no_grad()
-    def act_sequence(self, states):
-        """states (B,T,C,h,w) -> action indices (B,T): encoder over all B*T frames at once, one GRU
-        scan, one actor call.  Same arithmetic as T calls of act()."""
-        b, t = states.shape[:2]
-        flat = states.reshape(b * t, *states.shape[2:])
-        enc = self.state_encoder(flat if self.policy_conv else flat.flatten(1)).view(b, t, -1).transpose(0, 1)
-        out, _ = self.gru(enc.contiguous(), torch.zeros(1, b, self.hidden_state_dim, device=states.device))
-        return self.actor(out).max(2)[1].transpose(0, 1).contiguous()
 
 
 class PPO(nn.Module):

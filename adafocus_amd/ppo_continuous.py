@@ -62,9 +62,10 @@ class ActorCritic(nn.Module):
         g = self.gru
         h0 = None
         if memory is not None:
-            if restart_batch:
+            if restart_batch:      # ppo_continuous.py:79-81: the list restarts with the zero state (k + 1 entries after k steps)
                 del memory.hidden[:]
-            elif memory.hidden:
+                memory.hidden.append(torch.zeros(1, b, self.hidden_state_dim, device=featmap_nhwc.device))
+            if memory.hidden:
                 h0 = memory.hidden[-1].view(b, -1)
         hs = hip_ops.gru_seq_forward(e.view(b, 1, -1), g.weight_ih_l0.detach(), g.weight_hh_l0.detach(),
                                      g.bias_ih_l0.detach(), g.bias_hh_l0.detach(), h0=h0)

@@ -62,6 +62,12 @@ int adaf_device_cus(const adaf_handle* h);
  *   mode 2 = persistent kernel launched with hipLaunchCooperativeKernel (the runtime itself guarantees co-residency).
  * All forms are deterministic; they differ in summation order. */
 int adaf_set_gru_persistent(adaf_handle* h, int mode);
+/* The persistent scan's grid barrier is a bounded spin: a block that never sees its peers arrive (a grid that could not
+ * become co-resident -- never observed; the launcher budgets the resident blocks) poisons its outputs with NaN instead of
+ * hanging the device, and bumps a device counter.  This call SYNCHRONISES the device and returns the number of such
+ * blocks since adaf_create: 0 means every scan so far completed normally.  Evaluation loops check it once at the end
+ * (adafocus_amd/evaluate.py) so that a starved scan can never pass as a result. */
+int adaf_gru_scan_timeouts(adaf_handle* h, unsigned* count_out);
 /* k x k convolutions on small maps: tiles of the SAME output pixel over consecutive images, so the filter taps that only
  * multiply zero padding are skipped for the whole tile (40 % of the products of a 3x3 conv on a 3x3 map, 21 % on 6x6).
  * Bit-identical to the row-major tiles (a skipped slice contributes exact zeros).  Default on; off for A/B and tests. */

@@ -232,7 +232,9 @@ def test_per_step_surface_golden(dev, ops):
             assert none is None and feat.shape == (2, 2048, 1, 1)
             assert np.array_equal(std_action.cpu().numpy(), g["focuser_action_%d" % s]), s
             assert np.abs(feat.view(2, -1).cpu().numpy() - g["focuser_feat_%d" % s]).max() < TOL
-        assert len(m.focuser.memory.hidden) == 3 and m.focuser.memory.hidden[-1].shape == (1, 2, 1024)
+        # ppo.py:68-79: the zero state appended at restart_batch, then one entry per step
+        assert len(m.focuser.memory.hidden) == 4 and m.focuser.memory.hidden[-1].shape == (1, 2, 1024)
+        assert float(m.focuser.memory.hidden[0].abs().max()) == 0.0
         a = torch.from_numpy(g["sample_action"]).to(dev)
         assert np.array_equal(_sha(m.focuser.patch_sampler.sample(fr5[:, 1].contiguous(), a).cpu().numpy()), g["sample_sha"])
         small = frames[:, :6].contiguous()
@@ -311,7 +313,7 @@ def test_sth_video_div_and_baseline_golden(dev, vd):
             rand = torch.from_numpy(g["vd%d_rand_%d" % (vd, step)]).to(dev)
             total, base, patch = m.action_stage2(fo, fm, glog, step, a, prev_local_patch=prev, training=False, baseline_action=rand)
             hid = m.focuser.memory.hidden[-1]
-            assert hid.shape == (1, 2, 1024) and len(m.focuser.memory.hidden) == step + 1
+            assert hid.shape == (1, 2, 1024) and len(m.focuser.memory.hidden) == step + 2      # zero state + one per step
             assert np.abs(hid[0].cpu().numpy() - g["vd%d_hidden_%d" % (vd, step)]).max() < 1e-3
             if not np.array_equal(patch[:, :, :, :4, :4].cpu().numpy(), g["vd%d_patch_corner_%d" % (vd, step)]):
                 pytest.skip("policy action landed within float noise of a pixel boundary: crop origin differs by one pixel "
@@ -631,6 +633,7 @@ def test_gru_scan_many_streams_with_foreign_kernels(dev, ops):
     torch.cuda.synchronize()
     for i in range(24):
         assert torch.equal(outs[i], refs[i % 8]), i
+    assert ops.gru_scan_timeouts(dev) == 0          # the device-side time-out counter the evaluation loop checks
 
 
 # ------------------------------------------------------------------------------------ streams
@@ -653,6 +656,61 @@ def test_offline_forward_pipelined_equals_serial(dev, ops):
     for i, (lg, last, idx, done, handoff) in enumerate(piped):
         ref = serial[i % 5]
         assert torch.equal(idx, ref[2]) and torch.equal(lg, ref[0]) and torch.equal(last, ref[1]), i
+
+
+def test_pipelined_float_frames_release_event_is_done(dev):
+    """with normalised float frames the back stream's gather reads the CALLER's buffer, so the release event
+    returned as `handoff` must be `done`.  A slot that is overwritten as soon as `handoff` has passed (what evaluate.py
+    does with its landing buffers) must not change the result."""
+    m, _ = _act_model(dev)
+    gen = np.random.Generator(np.random.PCG64([33, 3]))
+    batches = [torch.from_numpy(gen.standard_normal((32, 224, 224, 4), dtype=np.float32)).to(dev) for _ in range(4)]
+    for x in batches:
+        x[..., 3] = 0
+    with torch.no_grad():
+        serial = [m.offline_forward_nhwc4(x, 4, 8)[0].clone() for x in batches]
+        torch.cuda.synchronize()
+        slot = torch.empty_like(batches[0])
+        outs = []
+        side = torch.cuda.Stream(device=dev)
+        for i in range(8):
+            slot.copy_(batches[i % 4])
+            lg, last, idx, done, handoff = m.offline_forward_pipelined(slot, 8)
+            assert handoff is done
+            outs.append(lg)
+            with torch.cuda.stream(side):          # the "loader": reuses the slot the moment the release event fires
+                side.wait_event(handoff)
+                slot.fill_(float("nan"))
+            torch.cuda.current_stream().wait_stream(side)
+        m.pipeline_flush()
+        torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, serial[i % 4]), i
+
+
+def test_policy_linear_encoder_and_hidden_list_like_the_reference(dev):
+    """ActorCritic.act with policy_conv=False (ppo.py:40-47,75-76: the Linear encoder for ResNet / DenseNet features) on the
+    engine, three steps, against the same nn.Modules on the CPU; memory.hidden holds the zero state + one entry per step."""
+    from adafocus_amd.ppo import ActorCritic, Memory
+    ac = ActorCritic(64, 64 * 7 * 7, 49, 1024, policy_conv=False).eval()
+    shapes = {k: tuple(v.shape) for k, v in ac.state_dict().items()}
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 77).items()})
+    states = [rnd((3, 64, 7, 7), 900 + i) for i in range(3)]
+    with torch.no_grad():
+        h = torch.zeros(1, 3, 1024)
+        ref_h, ref_a = [], []
+        for st in states:
+            e = ac.state_encoder(st.flatten(1))
+            o, h = ac.gru(e.view(1, 3, -1), h)
+            ref_h.append(h.clone())
+            ref_a.append(ac.actor(o[0]).max(1)[1])
+    acd = ac.to(dev)
+    mem = Memory()
+    for i, st in enumerate(states):
+        a = acd.act(st.to(dev), mem, restart_batch=(i == 0), training=False)
+        assert len(mem.hidden) == i + 2 and float(mem.hidden[0].abs().max()) == 0.0
+        assert (mem.hidden[-1].cpu() - ref_h[i]).abs().max().item() < 1e-4
+        assert torch.equal(a.cpu(), ref_a[i])
 
 
 def test_full_forward_on_three_streams_no_shared_scratch(dev):
