@@ -241,7 +241,7 @@ int adaf_ingest_u8_f32(adaf_handle* h, const uint8_t* clips_hwc, int n_clips, in
     if (!h) return ADAF_E_BADARG;
     if (n_clips == 0) return ADAF_OK;
     if (!clips_hwc || !mean3 || !std3 || !out_nhwc4) return fail(h, ADAF_E_BADARG, "ingest: null pointer");
-    if (n_clips < 0 || frames <= 0 || height <= 0 || width <= 0) return fail(h, ADAF_E_BADARG, "ingest: non-positive extent");
+    if (n_clips < 0 || frames <= 0 || frames > 64 || height <= 0 || width <= 0) return fail(h, ADAF_E_BADARG, "ingest: non-positive extent (frames <= 64)");
     if (!aligned16(out_nhwc4)) return fail(h, ADAF_E_LAYOUT, "ingest: output must be 16-byte aligned");
     for (int c = 0; c < 3; ++c)
         if (!(std3[c] > 0.f)) return fail(h, ADAF_E_BADARG, "ingest: std must be positive");

@@ -12,6 +12,7 @@
 #include "adaf_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -116,22 +117,44 @@ hipError_t launch_mode(const float* frames, int nf, int C, int H, int W, const f
 // (H, W, T*3) uint8, frame t's RGB at channels 3t..3t+2.  Output: (clip*T + t, H, W, 4) fp32 with
 //   v = ((float(u8) / 255) - mean[c]) / std[c]        (img.float().div(255); t.sub_(m).div_(s), :64-77)
 // computed with IEEE fp32 divide/subtract in that order (bit-exact with the reference), lane 3 = 0.
-// One thread per source pixel: reads T*3 contiguous bytes, writes one 16-byte pixel into each of the
-// T frames (for a fixed t consecutive lanes write consecutive pixels -> coalesced).
-__global__ void ingest_u8_kernel(const uint8_t* __restrict__ u8, long long pixels, int hw, int T, float m0, float m1,
-                                 float m2, float s0, float s1, float s2, float* __restrict__ out) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= pixels) return;
+// A block owns a run of 256 source pixels (256 * 3T contiguous bytes): the bytes are brought into LDS with 16-byte
+// coalesced loads (the first version had every lane walk its own 3T bytes with byte loads: 0.42 of HBM), the 3 x 256
+// possible results are tabulated once per block WITH THE REFERENCE'S OPERATIONS (so the table lookup is bit-exact by
+// construction and the two IEEE divisions per value leave the inner loop), then thread p emits pixel p of every frame:
+// for a fixed t consecutive lanes write consecutive 16-byte pixels.
+__global__ __launch_bounds__(256) void ingest_u8_kernel(const uint8_t* __restrict__ u8, long long pixels, int hw, int T, float m0, float m1,
+                                                        float m2, float s0, float s1, float s2, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ing_sm[];
+    float* lut = reinterpret_cast<float*>(ing_sm);                    // [3][256]
+    unsigned char* bytes = ing_sm + 3 * 256 * sizeof(float);         // [256][3T]
+    const int tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * 256;
+    const int npx = (int)(pixels - p0 < 256 ? pixels - p0 : 256);
+    const int row = 3 * T;
+    {
+        const float v = (float)tid;
+        lut[tid] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), m0), s0);
+        lut[256 + tid] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), m1), s1);
+        lut[512 + tid] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), m2), s2);
+    }
+    const uint8_t* src = u8 + p0 * row;
+    const int nbytes = npx * row;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int nv = nbytes >> 4;
+        for (int i = tid; i < nv; i += 256) reinterpret_cast<u32x4*>(bytes)[i] = reinterpret_cast<const u32x4*>(src)[i];
+        for (int i = (nv << 4) + tid; i < nbytes; i += 256) bytes[i] = src[i];
+    } else {
+        for (int i = tid; i < nbytes; i += 256) bytes[i] = src[i];
+    }
+    __syncthreads();
+    if (tid >= npx) return;
+    const long long idx = p0 + tid;
     const long long clip = idx / hw;
     const int p = (int)(idx - clip * hw);
-    const uint8_t* src = u8 + idx * (3 * T);
     float* dst = out + ((size_t)clip * T * hw + p) * 4;
+    const unsigned char* mine = bytes + tid * row;
     for (int t = 0; t < T; ++t) {
-        f32x4 v;
-        v.x = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[3 * t + 0], 255.f), m0), s0);
-        v.y = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[3 * t + 1], 255.f), m1), s1);
-        v.z = __fdiv_rn(__fsub_rn(__fdiv_rn((float)src[3 * t + 2], 255.f), m2), s2);
-        v.w = 0.f;
+        const f32x4 v = {lut[mine[3 * t]], lut[256 + mine[3 * t + 1]], lut[512 + mine[3 * t + 2]], 0.f};
         *reinterpret_cast<f32x4*>(dst + (size_t)t * hw * 4) = v;
     }
 }
@@ -298,7 +321,8 @@ __global__ void resize_nearest_kernel(const float* __restrict__ frames, int C, i
 void adaf_launch_ingest_u8(const uint8_t* u8, int clips, int T, int H, int W, const float* mean, const float* stdv,
                            float* out, hipStream_t s) {
     const long long pixels = (long long)clips * H * W;
-    hipLaunchKernelGGL(ingest_u8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, u8, pixels, H * W, T, mean[0],
+    const size_t lds = 3 * 256 * sizeof(float) + (size_t)256 * 3 * T;
+    hipLaunchKernelGGL(ingest_u8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), lds, s, u8, pixels, H * W, T, mean[0],
                        mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
 }
 

@@ -2,6 +2,8 @@
 meter helpers of ACT/ops/utils.py and the stage-3 branch of ``validate`` (ACT/main_dist.py:307-422),
 with the one thing the reference lacks -- the validation set is SHARDED over ranks and the logits are
 all-gathered (the reference evaluates the whole set on every rank, main_dist.py:239).
+``validate_sth`` is the Something-Something loop (STH/evaluate.py:165-226): two frame streams, the
+``video_div`` focusing steps, the reward bookkeeping of the (optional) baseline branch.
 
 Metrics run on the host over the gathered logits exactly as in the reference (they are O(N*C) and not
 on the hot path).  ``cal_map`` keeps the reference's label handling, including its re-ranking of the
@@ -15,7 +17,7 @@ import torch.nn.functional as F
 
 from .parallel import gather_variable, shard_range
 
-__all__ = ["AverageMeter", "ProgressMeter", "accuracy", "get_multi_hot", "cal_map", "validate"]
+__all__ = ["AverageMeter", "ProgressMeter", "accuracy", "get_multi_hot", "cal_map", "validate", "validate_sth"]
 
 
 class AverageMeter(object):
@@ -274,3 +276,113 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
         print(summary)
     logs.append(summary + "\n")
     return acc1[0].item(), acc5[0].item(), mean_ap.avg, logs
+
+
+class _TwoStream:
+    """(glancer clip, focuser clip, target) items as ONE tensor per sample, so the prefetcher stages and copies them
+    together; the halves are views again on the device."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, i):
+        g, f, t = self.ds[i]
+        return torch.cat([g, f], 0), torch.as_tensor(t).reshape(-1)[:1]
+
+
+@torch.no_grad()
+def validate_sth(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False, with_baseline=True,
+                 return_logits=False):
+    """Something-Something evaluation (STH/evaluate.py:165-226) over this rank's shard of `dataset` (indexable ->
+    (glancer_images (Tg*3,H,W), focuser_images (Tf*3,H,W), target), normalised fp32 like the reference's loader emits).
+    Per batch: nearest resize of the glancer frames to glance_size (:188), `model.glance`, then for each of the
+    `args.video_div` focusing steps `model.action_stage2(..., training=False)` with the previous steps' patches carried
+    (:198-201), the loss, and -- when `with_baseline` (the reference always computes it; it only feeds the logged reward)
+    -- reward = p_target(pred) - p_target(baseline) (:203-210).  Metrics are those of the WHOLE set on every rank: the last
+    step's logits, the targets and the per-sample rewards are all-gathered once at the end (the reference evaluates the
+    full set on each rank).  Returns (top1, top5, [mean reward per step], logs[, logits, targets])."""
+    bs = batch_size or args.batch_size
+    start, stop = shard_range(len(dataset), rank, world)
+    nb = (stop - start + bs - 1) // bs
+    batch_time, losses = AverageMeter("Time", ":6.3f"), AverageMeter("Loss", ":.4e")
+    top1, top5 = AverageMeter("Acc@1", ":6.2f"), AverageMeter("Acc@5", ":6.2f")
+    reward_list = [AverageMeter("Rew", ":6.5f") for _ in range(args.video_div)]
+    progress = ProgressMeter(nb, batch_time, losses, top1, top5, prefix="Test: ")
+    model.eval()
+    dev = device or next(model.parameters()).device
+    tg3 = 3 * args.num_segments_glancer
+    logs, preds, targets, rewards = [], [], [], [[] for _ in range(args.video_div)]
+    end = time.time()
+    pending = None
+
+    def finish(item):       # one batch late: the GPU never idles on the read-back of three scalars
+        nonlocal end
+        bi_, b_, loss_, acc1_, acc5_, rews_ = item
+        losses.update(loss_.item(), b_)
+        top1.update(acc1_[0].item(), b_)
+        top5.update(acc5_[0].item(), b_)
+        for meter, r in zip(reward_list, rews_):
+            if r is not None:
+                meter.update(r.mean().item(), b_)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        logs.append(progress.print(bi_, quiet=quiet or rank != 0))
+        logs.append(" ".join(str(m.avg) for m in reward_list) + "\n")
+
+    for bi, images, target, stage_next in _Prefetcher(_TwoStream(dataset), start, stop, bs, dev):
+        target = target.to(dev)[:, 0]
+        b = images.shape[0]
+        hh, ww = images.shape[2], images.shape[3]
+        glancer_images = images[:, :tg3]
+        g = getattr(args, "glance_size", hh)
+        if g != hh:         # F.interpolate(glancer_images, (glance_size, glance_size)): nearest (evaluate.py:188)
+            from . import hip_ops
+            glancer_images = hip_ops.resize_nearest(glancer_images.reshape(-1, 1, hh, ww), g).view(b, tg3, g, g)
+        focuser_images = images[:, tg3:].reshape(b, args.num_segments_focuser, 3, hh, ww)
+        fm, glog = model.glance(glancer_images)
+        local_patch, pred, loss, rews = None, None, None, []
+        for step in range(args.video_div):
+            pred, base, local_patch = model.action_stage2(focuser_images, fm, glog, step, args, prev_local_patch=local_patch,
+                                                          training=False, with_baseline=with_baseline)
+            loss = criterion(pred, target)
+            if with_baseline:
+                conf = torch.gather(F.softmax(pred, 1), 1, target.view(-1, 1)).view(-1)
+                bsl = torch.gather(F.softmax(base, 1), 1, target.view(-1, 1)).view(-1)
+                rews.append(conf - bsl)
+                rewards[step].append(rews[-1])
+            else:
+                rews.append(None)
+        stage_next()
+        acc1, acc5 = accuracy(pred, target, topk=(1, 5))
+        preds.append(pred)
+        targets.append(target)
+        if pending is not None:
+            finish(pending)
+        pending = (bi, b, loss, acc1, acc5, rews)
+    if pending is not None:
+        finish(pending)
+    if dev.type == "cuda":
+        from . import hip_ops
+        starved = hip_ops.gru_scan_timeouts(dev)
+        if starved:
+            raise RuntimeError("adafocus_amd.validate_sth: %d GRU scan block(s) timed out at their grid barrier" % starved)
+    ncls = args.num_classes
+    all_pred = gather_variable(torch.cat(preds) if preds else torch.zeros((0, ncls), device=dev)).cpu()
+    all_tgt = gather_variable(torch.cat(targets) if targets else torch.zeros((0,), dtype=torch.int64, device=dev)).cpu()
+    acc1, acc5 = accuracy(all_pred, all_tgt, topk=(1, 5))
+    mean_rewards = []
+    for step in range(args.video_div):
+        if with_baseline:
+            r = gather_variable(torch.cat(rewards[step]) if rewards[step] else torch.zeros((0,), device=dev)).cpu()
+            mean_rewards.append(float(r.mean()) if r.numel() else 0.0)
+        else:
+            mean_rewards.append(None)
+    summary = " * Acc@1 {:.5f} Acc@5 {:.5f} reward of each step: {}".format(acc1[0].item(), acc5[0].item(), mean_rewards)
+    if rank == 0 and not quiet:
+        print(summary)
+    logs.append(summary + "\n")
+    out = (acc1[0].item(), acc5[0].item(), mean_rewards, logs)
+    return out + (all_pred, all_tgt) if return_logits else out

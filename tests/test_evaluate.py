@@ -100,3 +100,90 @@ def test_validate_sharded_equals_single_process():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     for r in range(2):
         assert np.allclose(ret[r], single[:3], atol=1e-4), (ret[r], single[:3])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Something-Something loop (STH/evaluate.py:165-226)
+class _SthArgs:
+    num_segments_glancer, num_segments_focuser, num_classes, batch_size, gpu = 4, 4, 10, 8, None
+    video_div, glance_size, patch_size = 2, 4, 2
+
+
+class _FakeSth(torch.nn.Module):
+    """Stand-in with the STH GFV surface: logits depend on the clip content and on how many focusing steps have been taken;
+    the baseline logits are a fixed function of the clip, so rewards are deterministic too."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.linspace(-1, 1, 10)[None, :], requires_grad=False)
+        self.calls = []
+
+    def glance(self, g):
+        b = g.shape[0]
+        return g.reshape(b, 4, 3, 4, 4), torch.sin(g.reshape(b, -1).mean(1, keepdim=True) * 11.0 + self.w)
+
+    def action_stage2(self, focuser_image, fm, glog, step, args, prev_local_patch=None, training=True, with_baseline=True):
+        assert not training and focuser_image.shape[1:] == (4, 3, 4, 4)
+        assert (prev_local_patch is None) == (step == 0)
+        b = focuser_image.shape[0]
+        nff = args.num_segments_focuser // args.video_div
+        seen = focuser_image[:, :(step + 1) * nff].reshape(b, -1).mean(1, keepdim=True)
+        pred = torch.sin(seen * 23.0 + self.w * 3.0) + glog
+        base = torch.cos(seen * 5.0 + self.w) if with_baseline else None
+        patch = focuser_image[:, :(step + 1) * nff, :, :2, :2]
+        return pred, base, patch
+
+
+class _SthData:
+    def __init__(self, n):
+        g = torch.Generator().manual_seed(7)
+        self.g = torch.randn(n, 12, 4, 4, generator=g)
+        self.f = torch.randn(n, 12, 4, 4, generator=g)
+        self.y = torch.randint(0, 10, (n,), generator=g)
+
+    def __len__(self):
+        return self.g.shape[0]
+
+    def __getitem__(self, i):
+        return self.g[i], self.f[i], self.y[i]
+
+
+def _sth_reference(ds, model, a):
+    """The reference's loop (STH/evaluate.py:180-213), one batch = the whole set."""
+    g, f, y = ds.g, ds.f.view(-1, 4, 3, 4, 4), ds.y
+    fm, glog = model.glance(g)
+    patch, rew = None, []
+    for step in range(a.video_div):
+        pred, base, patch = model.action_stage2(f, fm, glog, step, a, prev_local_patch=patch, training=False)
+        conf = torch.gather(torch.softmax(pred, 1), 1, y.view(-1, 1)).view(-1)
+        bsl = torch.gather(torch.softmax(base, 1), 1, y.view(-1, 1)).view(-1)
+        rew.append(float((conf - bsl).mean()))
+    a1, a5 = E.accuracy(pred, y, topk=(1, 5))
+    return float(a1), float(a5), rew, pred
+
+
+def _sth_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = E.validate_sth(_SthData(37), _FakeSth(), torch.nn.CrossEntropyLoss(), _SthArgs(), rank=rank, world=world, quiet=True)
+    ret[rank] = (out[0], out[1], out[2])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validate_sth_matches_the_reference_loop_and_shards():
+    a1, a5, rew, pred = _sth_reference(_SthData(37), _FakeSth(), _SthArgs())
+    t1, t5, r, logs, lg, tg = E.validate_sth(_SthData(37), _FakeSth(), torch.nn.CrossEntropyLoss(), _SthArgs(), quiet=True,
+                                             return_logits=True)
+    assert abs(t1 - a1) < 1e-4 and abs(t5 - a5) < 1e-4 and np.allclose(r, rew, atol=1e-6)
+    assert torch.allclose(lg, pred) and torch.equal(tg, _SthData(37).y)
+    assert logs[-1].startswith(" * Acc@1") and len(logs) == 2 * 5 + 1          # 5 batches of 8: progress + reward lines
+    nb = E.validate_sth(_SthData(37), _FakeSth(), torch.nn.CrossEntropyLoss(), _SthArgs(), quiet=True, with_baseline=False)
+    assert abs(nb[0] - a1) < 1e-4 and nb[2] == [None, None]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_sth_worker, args=(2, port, ret), nprocs=2, join=True)
+    for rk in range(2):
+        assert abs(ret[rk][0] - a1) < 1e-4 and abs(ret[rk][1] - a5) < 1e-4 and np.allclose(ret[rk][2], rew, atol=1e-6)

