@@ -830,14 +830,24 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
     if (h->gru_persistent && steps + 1 <= batch * 3 * hidden &&
         adaf_gru_scan_persistent_ok(batch, hidden, fc_w ? classes : 0, h->scan_resident)) {
         // the whole recurrence (+ classifier) in one kernel; `gh` only lends its first steps+1 words to the grid barrier
+        // (while `st` is being captured into a HIP graph -- GFV.capture_hot_path, the small-batch latency mode -- the slot
+        // events stay out of it: an event recorded outside a capture cannot be waited on inside one, and a graph is
+        // replayed on ONE stream, where consecutive scans are ordered anyway)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        const bool capturing = cap != hipStreamCaptureStatusNone;
         const int slot = h->scan_next;
-        h->scan_next = (slot + 1) % h->scan_slots;
-        if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan scan_slots launches ago has finished
+        if (!capturing) {
+            h->scan_next = (slot + 1) % h->scan_slots;
+            if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan scan_slots launches ago has finished
+        }
         hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), batch, steps, fc_w,
                                                        fc_b, logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, st);
         if (e != hipSuccess) return hip_fail(h, e, "gru scan launch");
-        (void)hipEventRecord(h->scan_done[slot], st);
-        h->scan_used[slot] = true;
+        if (!capturing) {
+            (void)hipEventRecord(h->scan_done[slot], st);
+            h->scan_used[slot] = true;
+        }
         return ADAF_OK;
     }
     for (int t = 0; t < steps; ++t) {

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 }
 
+// the barrier words are cleared by a kernel, not by hipMemsetAsync: captured into a HIP graph (GFV.capture_hot_path) the memset
+// node did not reliably re-zero them on replay (measured: logits of later steps differed from the eager launch)
+__global__ void zero_words_kernel(unsigned* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
 constexpr int kH = 1024, kJB = 8, kGrid = kH / kJB;
 
 }  // namespace
@@ -194,7 +200,8 @@ hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, co
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;
     a.fcw = fcw; a.fcb = fcb; a.logits = logits; a.last = last; a.C = fcw ? classes : 0;
     a.cpb = fcw ? (classes + kGrid - 1) / kGrid : 0;
-    hipError_t e = hipMemsetAsync(bar, 0, sizeof(unsigned) * (steps + 1), s);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, bar, steps + 1);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (cooperative) {
         void* params[] = {&a};

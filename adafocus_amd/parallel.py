@@ -12,7 +12,7 @@ is RCCL on ROCm; the CPU tests use gloo.
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_range", "gather_logits", "gather_variable"]
+__all__ = ["shard_range", "gather_logits", "gather_logits_async", "gather_variable", "bind_to_gpu_numa"]
 
 
 def shard_range(n_items, rank, world):
@@ -35,6 +35,53 @@ def gather_logits(local, group=None):
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
     dist.all_gather_into_tensor(out, local, group=group)
     return out
+
+
+def gather_logits_async(local, comm_stream, group=None):
+    """gather_logits issued on `comm_stream`, ordered after whatever the CURRENT stream has enqueued (the GRU scan that
+    produced `local`): the collective is ~50 KB per rank and latency-bound on xGMI, so it runs beside the next batch's
+    trunk instead of in front of it.  The result belongs to `comm_stream`: consume it after
+    `torch.cuda.current_stream().wait_stream(comm_stream)` or a device synchronisation.  On a CPU tensor (gloo tests) or with
+    comm_stream=None it is the plain blocking gather."""
+    if comm_stream is None or not local.is_cuda:
+        return gather_logits(local, group)
+    cur = torch.cuda.current_stream(local.device)
+    comm_stream.wait_stream(cur)
+    with torch.cuda.stream(comm_stream):
+        local.record_stream(comm_stream)
+        return gather_logits(local, group)
+
+
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa(device_index):
+    """Pin this process (one rank per GPU) to the CPUs of the NUMA node its GPU hangs off: the rank's Python thread, its
+    staging threads and the pinned host buffers they touch stay next to the device (8 ranks on a 2-socket host otherwise
+    share whatever cores the scheduler picks).  Reads the node from sysfs via the device's PCI address; returns the node
+    number, or None when it cannot be determined (no sysfs entry, node -1, not Linux) -- in which case nothing changes."""
+    import os
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
 
 
 def gather_variable(local, group=None):

@@ -29,7 +29,10 @@ import statistics
 import sys
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the per-GPU processes (before HIP starts)
+# The GPU boxes' host driver only supports dmabuf IPC: without this RCCL (and any cross-process device-memory sharing) fails
+# with `hipIpcGetMemHandle: invalid argument`.  The image exports it already; `setdefault` keeps a bare `python bench.py
+# --gpus N` working from an environment that was rebuilt without it.  It has to be in place before HIP initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -42,18 +45,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 HBM_PEAK_GBS = 8000.0
 
 
-class Args:
-    def __init__(self, **kw):
-        self.__dict__.update(kw)
-
-
-def act_args(t, p, b, **over):
-    a = Args(num_segments=t, num_classes=200, reward="random", dataset="actnet", input_size=224, batch_size=b,
-             patch_size=p, with_glancer=True, feature_map_channels=1280, glance_size=224, action_dim=49,
-             hidden_state_dim=1024, policy_conv=True, gpu=0, continuous=False, gamma=0.7, policy_lr=0.0003,
-             random_patch=False, dropout=0.5, consensus="gru", hidden_dim=1024)
-    a.__dict__.update(over)
-    return a
+import bench_extras as X  # noqa: E402
+from bench_extras import Args, act_args, synth_model_state  # noqa: E402,F401
 
 
 def config5_row(dev, b, streams, frames, steps=30):
@@ -117,12 +110,6 @@ def config5_row(dev, b, streams, frames, steps=30):
                    "local_cnn = the network alone (HIP events), bytes = activation in + out of every launch (workload.effnet_bytes_per_frame); "
                    "parity unpinned (no reference implementation of this config)" % (b * t, b))
     return out
-
-
-def synth_model_state(model, seed):
-    from adafocus_amd import synth
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    return {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed).items()}
 
 
 def load_traffic(t, p, b):
@@ -316,13 +303,18 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    numa_node = None
+    if world > 1 and not dry:
+        from adafocus_amd.parallel import bind_to_gpu_numa
+        numa_node = bind_to_gpu_numa(local)       # the rank's host threads next to its GPU
 
     def sync():
         if not dry:
             torch.cuda.synchronize()
 
     from adafocus_amd import synth, workload
-    from adafocus_amd.parallel import gather_logits
+    from adafocus_amd.parallel import gather_logits, gather_logits_async
+    comm_stream = torch.cuda.Stream(device=dev) if (world > 1 and not dry) else None
 
     b, t, p = a.batch, a.frames, a.patch
     if dry:
@@ -358,8 +350,8 @@ def main():
             return gather_logits(last) if world > 1 else last
         with torch.no_grad(), torch.cuda.stream(streams[i % len(streams)]):
             logits, last, _ = model.hot_path(frames, gvec, actions, b, t)
-            if world > 1:
-                last = gather_logits(last)
+            if world > 1:      # the logits all-gather on its own stream, ordered after this step's scan; the next trunk does not wait for it
+                last = gather_logits_async(last, comm_stream)
         return last
 
     def timed_steps(n):
@@ -404,7 +396,9 @@ def main():
                    "global_batch": b * world, "frames": t, "patch": p, "parallelism": "dp%d" % world,
                    "streams": len(streams)},
         "ranks": world, "backend": ("gloo" if dry else "gloo (all ranks share GPU 0)" if a.share_gpu else "nccl (RCCL)") if world > 1 else None,
-        "rccl_ranks": (dist.get_world_size() if (world > 1 and not dry and not a.share_gpu) else (1 if not dry and world == 1 else 0)),
+        # ranks of an initialised RCCL ("nccl") process group -- taken from torch.distributed, never inferred
+        "rccl_ranks": (dist.get_world_size() if (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl") else 0),
+        "numa_node_rank0": numa_node,
         "per_rank_clips_per_s": [round(b * a.steps / s, 1) for s in per_rank_s],
         "gflop_per_clip": round(workload.hot_path_flops_per_clip(t, p) / 1e9, 2),
     }
@@ -417,9 +411,23 @@ def main():
         res["sustained"] = {"value": round(b * world * a.sustained_steps / s_el, 2), "unit": "clips/s", "steps": a.sustained_steps,
                             "seconds": round(s_el, 3), "ms_per_step": round(1e3 * s_el / a.sustained_steps, 3)}
 
+    if not dry and len(streams) > 1 and not a.skip_extras:
+        # the same steps strictly serial (one stream): `value` overlaps batch i+1's trunk with batch i's latency-bound GRU scan
+        # and launch tails across %d streams, each with its own trunk workspace; this is what a single stream gets
+        saved = streams
+        streams = streams[:1]
+        for i in range(3):
+            step(i)
+        s1, _, _ = timed_steps(a.steps)
+        streams = saved
+        res["serial_value"] = {"value": round(b * world * a.steps / s1, 2), "unit": "clips/s", "streams": 1, "steps": a.steps,
+                               "ms_per_step": round(1e3 * s1 / a.steps, 3),
+                               "note": "`value` uses %d streams (and %d trunk workspaces of %.1f GB); this is the strictly serial rate" % (
+                                   len(saved), len(saved), (trunk._lib.adaf_resnet50_workspace_bytes(trunk._net, b * t, p) / 1e9) if trunk is not None else 0.0)}
+
     if rank == 0 and not dry:
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -------------
-        conv_ms = conv_fl = tot_ms = 0.0
+        conv_ms = conv_fl = tot_ms = conv_by = 0.0
         nconv = 0
         from adafocus_amd.utils import get_patch_nhwc4
         x4 = get_patch_nhwc4(frames, actions, p)
@@ -434,6 +442,7 @@ def main():
             if e["flops"] > 0:
                 conv_ms += ms * nps
                 conv_fl += e["flops"] * nps
+                conv_by += e.get("bytes", 0.0) * nps
                 nconv += nps
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # the same launches back to back (two events around three whole trunk passes): what the event brackets of the
@@ -455,6 +464,7 @@ def main():
                                      "the fused stage-1 / stem kernels), %d launches/step" % (nconv // nps),
                            "avg_launch_ms": round(conv_ms / max(nconv, 1), 4),
                            "flop_per_launch": round(conv_fl / max(nconv, 1), 1),
+                           "algorithmic_bytes_per_launch": round(conv_by / max(nconv, 1), 1),
                            "trunk_ms_per_step": round(tot_ms / nps, 3),
                            "back_to_back": {"trunk_ms": round(wall_ms, 3), "achieved": round(b2b, 2),
                                             "frac": round(b2b / MFMA_F32_PEAK_TFLOPS, 4),
@@ -475,20 +485,22 @@ def main():
         res["gather"] = {"bound": "hbm", "achieved": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(crop_bytes / (crop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "ms": round(crop_ms, 4), "bytes_per_patch": workload.crop_bytes_per_patch(p)}
-        # BASELINE.json configs[1] (same model at T=8, N=512 patches per step), for reference
-        t8 = t // 2 if not a.skip_extras else 0
-        if t8 > 0:
-            fr8, ac8, gv8 = frames[: b * t8], actions[: b * t8], gvec[:, :t8].contiguous()
-            with torch.no_grad():
-                for i in range(2):
-                    model.hot_path(fr8, gv8, ac8, b, t8)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(6):
-                    with torch.cuda.stream(streams[i % len(streams)]):
-                        model.hot_path(fr8, gv8, ac8, b, t8)
-                torch.cuda.synchronize()
-            res["also"] = {"T%d_P%d_B%d_clips_per_s" % (t8, p, b): round(6 * b / (time.perf_counter() - t1), 1)}
+        def extra(group, key, fn):      # an `also` / `next_rows` entry must never fail the bench
+            try:
+                res.setdefault(group, {})[key] = fn()
+            except Exception as exc:
+                res.setdefault(group, {})[key] = {"error": repr(exc)[:300]}
+        if not a.skip_extras and world == 1:
+            # the other BASELINE configurations, hot path per GPU, same protocol as `value` (>= 30 steps, >= 1 s for the short one)
+            extra("also", "config2_T8_P96_act", lambda: X.act_hot_path_row(dev, 8, 96, b, streams, 120))
+            extra("also", "config3_T16_P128_act", lambda: X.act_hot_path_row(dev, 16, 128, b, streams, 40))
+            extra("also", "config4_T8_P128_sth_tsm", lambda: X.sth_hot_path_row(dev, b, streams, 60))
+            extra("also", "latency_small_batch", lambda: X.latency_rows(dev))
+            res["gather_resize"] = None
+            try:
+                res["gather_resize"] = X.gather_resize_row(dev, frames, p)
+            except Exception as exc:
+                res["gather_resize"] = {"error": repr(exc)[:300]}
         if a.math == "f32" and not a.skip_extras and world == 1:   # (step() holds a collective when world > 1)
             # opt-in arithmetic (not the reported configuration): same step with the convs on the bf16 matrix pipe
             with torch.no_grad():
@@ -570,6 +582,10 @@ def main():
                 del u8, u8s, fr4, fmap, fvec
             except Exception as exc:  # upstream of the timed path; never fail the bench on it
                 res["next_rows"] = {"error": repr(exc)[:300]}
+        if world == 1 and not a.skip_extras:
+            eargs = act_args(t, p, b)
+            extra("next_rows", "evaluate_loop", lambda: X.evaluate_loop_row(dev, model, eargs, b, t))
+            extra("also", "validate_sth_loop_T8_P128", lambda: X.validate_sth_row(dev, b))
         if world == 1 and not a.skip_extras and (t, p) == (16, 96):
             try:
                 res.setdefault("also", {})["config5_T16_P144_efficientnet_b3"] = config5_row(dev, b, streams, frames)

@@ -1,0 +1,240 @@
+"""Extra rows of bench.py's JSON line (never `value`): the other BASELINE configurations, the resampling gather, the
+evaluation loops end to end, small-batch latency.  Each function measures on `dev` with inputs resident in HBM (unless it
+says otherwise) and returns a plain dict; bench.py wraps every call so that a failure here can never fail the bench.
+"""
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def act_args(t, p, b, **over):
+    a = Args(num_segments=t, num_classes=200, reward="random", dataset="actnet", input_size=224, batch_size=b,
+             patch_size=p, with_glancer=True, feature_map_channels=1280, glance_size=224, action_dim=49,
+             hidden_state_dim=1024, policy_conv=True, gpu=0, continuous=False, gamma=0.7, policy_lr=0.0003,
+             random_patch=False, dropout=0.5, consensus="gru", hidden_dim=1024)
+    a.__dict__.update(over)
+    return a
+
+
+def sth_args(b, t=8, p=128, video_div=1):
+    """Something-Something V1 configuration (STH/evaluate.py argparse defaults + the README's command line): TSM-MobileNetV2
+    glancer, TSM-ResNet-50 focuser, continuous policy."""
+    return Args(num_segments_glancer=t, num_segments_focuser=t, num_classes=174, batch_size=b, patch_size=p, input_size=224,
+                with_glancer=True, feature_map_channels=1280, video_div=video_div, glance_size=224, action_dim=49,
+                hidden_state_dim=1024, policy_conv=True, gpu=0, ppo_continuous=True, gamma=0.7, policy_lr=0.0003,
+                action_std=0.25, actorcritic_with_bn=True, modality="RGB", base_model="resnet50", partial_bn=False,
+                pretrain="imagenet", is_shift=True, shift_div=8, shift_place="blockres", fc_lr5=False,
+                temporal_pool=False, non_local=False, random_patch=False, dropout=0.5)
+
+
+def synth_model_state(model, seed):
+    from adafocus_amd import synth
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    return {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed).items()}
+
+
+def _clock(fn, streams, steps, warm=None):
+    warm = 2 * len(streams) if warm is None else warm
+    for i in range(warm):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def act_hot_path_row(dev, t, p, b, streams, steps):
+    """ActivityNet hot path (gather -> ResNet-50 -> GRU classifier) at another (T, P): BASELINE config 2 (T=8, P=96) and
+    config 3's per-GPU half (T=16, P=128)."""
+    from adafocus_amd import synth, workload
+    from adafocus_amd.gfv_net import GFV
+    m = GFV(act_args(t, p, b)).eval()
+    m.load_state_dict(synth_model_state(m, 1007), strict=True)
+    m = m.to(dev)
+    frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=1)).to(dev).view(b * t, 3, 224, 224)
+    actions = torch.from_numpy(synth.synth_actions(b * t, 7, seed=2)[1]).to(dev)
+    gvec = torch.randn((b, t, 1280), device=dev)
+    with torch.no_grad():
+        sec = _clock(lambda: m.hot_path(frames, gvec, actions, b, t), streams, steps)
+    flop = workload.hot_path_flops_per_clip(t, p) * b
+    return {"clips_per_s": round(b / sec, 1), "ms_per_step": round(sec * 1e3, 3), "steps": steps, "seconds": round(sec * steps, 3),
+            "B": b, "T": t, "P": p, "streams": len(streams), "tflops": round(flop / sec / 1e12, 1),
+            "frac_of_f32_mfma_peak": round(flop / sec / 1e12 / 157.3, 4)}
+
+
+def sth_hot_path_row(dev, b, streams, steps, t=8, p=128):
+    """BASELINE config 4: Something-Something V1, TSM-ResNet-50 local CNN (temporal shift fused into every Bottleneck conv1's
+    operand load), T = 8, P = 128: gather (one (y, x) per clip) -> TSM trunk -> FC + temporal mean + glancer logits
+    (GFV.action_stage3 in eval mode with the action given: the hot path without its producers)."""
+    from adafocus_amd import synth, workload
+    from adafocus_amd.gfv_net_sth import GFV
+    a = sth_args(b, t, p)
+    m = GFV(a).eval()
+    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])     # STH/evaluate.py:83
+    m.load_state_dict(synth_model_state(m, 1007), strict=True)
+    m = m.to(dev)
+    fo = torch.from_numpy(synth.synth_frames(b, t, 224, seed=4)).view(b, t, 3, 224, 224).to(dev)
+    fm = torch.randn((b, t, 7, 7, 1280), device=dev).permute(0, 1, 4, 2, 3)     # glancer map, reference-layout view
+    glog = torch.randn((b, t, 174), device=dev)
+    forced = torch.rand((b, 2), device=dev)
+    with torch.no_grad():
+        sec = _clock(lambda: m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced), streams, steps)
+    flop = 2.0 * workload.resnet50_macs_per_patch(p) * b * t
+    return {"clips_per_s": round(b / sec, 1), "ms_per_step": round(sec * 1e3, 3), "steps": steps, "seconds": round(sec * steps, 3),
+            "B": b, "T": t, "P": p, "streams": len(streams), "tflops": round(flop / sec / 1e12, 1),
+            "frac_of_f32_mfma_peak": round(flop / sec / 1e12 / 157.3, 4)}
+
+
+def gather_resize_row(dev, frames, patch=96, iters=20):
+    """Row N1: the resampling crop (adaf_crop_resize_f32: window of size S from (y, x) -> bilinear -> patch^2) at S != patch,
+    priced against HBM.  Algorithmic bytes per patch = 3 S^2 4 (the window, read once) + 3 patch^2 4 (the patch, written
+    once).  `frames` (N,3,H,W) fp32 resident on the device."""
+    from adafocus_amd import hip_ops
+    n = frames.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    actions = torch.rand((n, 2), generator=g).to(dev)
+    out = {}
+
+    def run(size):
+        fn = lambda: hip_ops.crop_resize(frames, actions, patch, size=size, layout=hip_ops.LAYOUT_NHWC4)   # noqa: E731
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    for name, size in (("S128_to_P%d" % patch, 128), ("S192_to_P%d" % patch, 192)):
+        ms = run(size)
+        by = float(n) * (3 * size * size * 4 + 3 * patch * patch * 4)
+        out[name] = {"ms": round(ms, 4), "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_patch": int(by / n)}
+    sizes = torch.tensor(np.random.Generator(np.random.PCG64(12)).choice([96, 128, 160, 192], size=n), dtype=torch.int32).to(dev)
+    ms = run(sizes)
+    by = float((3 * sizes.double() ** 2 * 4).sum().item()) + float(n) * 3 * patch * patch * 4
+    out["mixed_S96_128_160_192_to_P%d" % patch] = {"ms": round(ms, 4), "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_patch": int(by / n)}
+    out["note"] = ("adaf_crop_resize_f32, %d frames of %dx%d NCHW fp32 -> (N,%d,%d,4): per-action window size S, bilinear (align_corners="
+                   "False) resample; bytes = window read + patch written (3 channels)" % (n, frames.shape[2], frames.shape[3], patch, patch))
+    return out
+
+
+def evaluate_loop_row(dev, model, args, b, t, batches=8):
+    """Row f3 end to end: evaluate.validate on an in-memory synthetic set of uint8 clips (host tensors -> pinned staging ->
+    H2D -> ingest + glancer + policy + hot path -> loss / accuracy / mAP on the host).  One untimed pass first (pinned
+    buffers, scratch), then the timed pass."""
+    from adafocus_amd import evaluate as E
+    n = b * batches
+    labels = torch.randint(0, args.num_classes, (n, 1))
+    u8 = torch.randint(0, 256, (b, 224, 224, t * 3), dtype=torch.uint8)
+
+    class DS:
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return u8[i % b], labels[i]
+    crit = torch.nn.CrossEntropyLoss()
+    E.validate(DS(), model, crit, args, quiet=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    E.validate(DS(), model, crit, args, quiet=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "clips/s", "clips": n, "seconds": round(dt, 3), "ms_per_batch": round(dt / batches * 1e3, 2),
+            "note": "evaluate.validate (ACT/main_dist.py:307-422 stage-3 branch) from the loader's uint8 (H,W,T*3) clips in host memory: "
+                    "pinned staging + H2D of batch i+1 under batch i's kernels, two-stream forward, metrics (accuracy, cal_map) on the host"}
+
+
+def validate_sth_row(dev, b, t=8, p=128, batches=4):
+    """Something-Something loop end to end (evaluate.validate_sth = STH/evaluate.py:165-226): two fp32 frame streams from
+    host memory, glancer + continuous policy + gather + TSM-ResNet-50 (+ the reward-baseline branch, as the reference runs
+    it) + FC / consensus, accuracy over the set."""
+    from adafocus_amd import evaluate as E
+    from adafocus_amd.gfv_net_sth import GFV
+    a = sth_args(b, t, p)
+    m = GFV(a).eval()
+    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])
+    m.load_state_dict(synth_model_state(m, 1007), strict=True)
+    m = m.to(dev)
+    n = b * batches
+    g = torch.Generator().manual_seed(3)
+    gl = torch.randn((16, t * 3, 224, 224), generator=g)
+    fo = torch.randn((16, t * 3, 224, 224), generator=g)
+    labels = torch.randint(0, 174, (n,), generator=g)
+
+    class DS:
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return gl[i % 16], fo[(i + 5) % 16], labels[i]
+    crit = torch.nn.CrossEntropyLoss()
+    out = {}
+    for name, base in (("with_baseline_branch", True), ("without_baseline_branch", False)):
+        E.validate_sth(DS(), m, crit, a, quiet=True, with_baseline=base)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        E.validate_sth(DS(), m, crit, a, quiet=True, with_baseline=base)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": round(n / dt, 1), "unit": "clips/s", "clips": n, "seconds": round(dt, 3), "ms_per_batch": round(dt / batches * 1e3, 2)}
+    out["note"] = ("evaluate.validate_sth from fp32 (T*3,H,W) clips in host memory (2 x %.0f MB per %d-clip batch over PCIe), T=%d, P=%d, "
+                   "video_div=1; the baseline branch doubles the local-CNN work for a logged-only reward" % (b * t * 3 * 224 * 224 * 4 / 1e6, b, t, p))
+    return out
+
+
+def latency_rows(dev, cases=((1, 8), (2, 8), (2, 16)), p=96, iters=200):
+    """Small-batch latency of the hot path (BASELINE config 1 is B = 2, T = 8; the reference's only published CPU figure is a
+    bs = 1 latency): launches issued one by one from Python vs the same step replayed from a captured HIP graph
+    (GFV.capture_hot_path).  The step is a chain of ~50 dependent launches whose K loops run in a handful of blocks."""
+    from adafocus_amd import synth
+    from adafocus_amd.gfv_net import GFV
+    rows = {}
+    for b, t in cases:
+        m = GFV(act_args(t, p, b)).eval()
+        m.load_state_dict(synth_model_state(m, 1007), strict=True)
+        m = m.to(dev)
+        fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=1)).to(dev).view(b * t, 3, 224, 224)
+        act = torch.from_numpy(synth.synth_actions(b * t, 7, seed=2)[1]).to(dev)
+        gv = torch.randn((b, t, 1280), device=dev)
+        with torch.no_grad():
+            for _ in range(5):
+                lg = m.hot_path(fr, gv, act, b, t)[0]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                lg = m.hot_path(fr, gv, act, b, t)[0]
+            torch.cuda.synchronize()
+            eager = (time.perf_counter() - t0) / iters
+            ref = lg.clone()
+            g = m.capture_hot_path(b, t)
+            g(fr, gv, act)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(g.logits, ref))
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                g.replay()
+            torch.cuda.synchronize()
+            graph = (time.perf_counter() - t0) / iters
+        rows["B%d_T%d_P%d" % (b, t, p)] = {"eager_ms": round(eager * 1e3, 4), "graph_ms": round(graph * 1e3, 4),
+                                            "clips_per_s": round(b / min(eager, graph), 1), "graph_bit_identical_to_eager": same}
+        del g, m
+    rows["note"] = ("one hot-path step (gather + ResNet-50 + GRU classifier) per call, back to back, %d calls; eager = Python-issued "
+                    "launches, graph = GFV.capture_hot_path replay" % iters)
+    return rows

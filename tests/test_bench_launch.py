@@ -38,3 +38,13 @@ def test_bench_single_rank_dry_run_contract():
               "vs_baseline", "dtype", "data", "config"):
         assert k in r, k
     assert r["n_gpus"] == 1 and r["ranks"] == 1 and r["steps"] == 3 and r["warmup"] == 1
+
+
+def test_bench_eight_ranks_dry_run():
+    """The launch the driver makes on an 8-GPU node (`--gpus 8`: self-launch, 8 ranks, barrier, max-over-ranks, one JSON line,
+    logits of all 8 shards gathered), on CPU ranks over gloo."""
+    r = _run(["--gpus", "8"])
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["backend"] == "gloo" and r["rccl_ranks"] == 0
+    assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp8" and r["scaling"] == "weak"
+    assert len(r["per_rank_clips_per_s"]) == 8 and all(v > 0 for v in r["per_rank_clips_per_s"])
+    assert abs(r["value"] - 32 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 0.01

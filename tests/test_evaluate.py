@@ -187,3 +187,17 @@ def test_validate_sth_matches_the_reference_loop_and_shards():
     mp.spawn(_sth_worker, args=(2, port, ret), nprocs=2, join=True)
     for rk in range(2):
         assert abs(ret[rk][0] - a1) < 1e-4 and abs(ret[rk][1] - a5) < 1e-4 and np.allclose(ret[rk][2], rew, atol=1e-6)
+
+
+def test_validate_eight_ranks_ragged_shards():
+    """37 clips over 8 ranks (shards of 5,5,5,5,5,4,4,4; batches of 8 -> every shard is one ragged batch): every rank reports
+    the metrics of the whole set."""
+    single = E.validate(_Data(37), _FakeModel(), torch.nn.CrossEntropyLoss(), _Args(), quiet=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(8, port, ret), nprocs=8, join=True)
+    assert len(ret) == 8
+    for r in range(8):
+        assert np.allclose(ret[r], single[:3], atol=1e-4), (r, ret[r], single[:3])

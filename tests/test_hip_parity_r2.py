@@ -584,6 +584,26 @@ def test_validate_sth_loop_against_golden(dev, vd):
     assert torch.equal(nb[4], lg) and nb[2] == [None] * vd
 
 
+def test_latency_mode_graph_replay_bit_identical(dev):
+    """GFV.capture_hot_path: BASELINE config 1's step (B = 2, T = 8, P = 96) captured into a HIP graph and replayed on new
+    inputs equals the eagerly launched step bit for bit (same kernels, same order), also for B = 1."""
+    m, _ = _act_model(dev)
+    for b in (2, 1):
+        t = 8
+        g = m.capture_hot_path(b, t)
+        for seed in (61, 62, 63):
+            fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=seed)).to(dev).view(b * t, 3, 224, 224)
+            _, act = synth.synth_actions(b * t, 7, seed=seed + 10)
+            act = torch.from_numpy(act).to(dev)
+            gv = rnd((b, t, 1280), seed + 20, 0.5).to(dev)
+            with torch.no_grad():
+                lg, last, _ = m.hot_path(fr, gv, act, b, t)
+                lg, last = lg.clone(), last.clone()
+                glg, glast = g(fr, gv, act)
+            torch.cuda.synchronize()
+            assert torch.equal(glg, lg) and torch.equal(glast, last), (b, seed)
+
+
 # ------------------------------------------------------------------------------------ GRU scan
 def _gru_weights(dev):
     sd = synth_sd("ACT", 606, "classifier.", keep_prefix=False)

@@ -61,3 +61,15 @@ def test_gather_logits_world2_even():
 
 def test_gather_variable_world2_ragged():
     _run(33)
+
+
+def test_numa_binding_helper_is_harmless_without_a_gpu():
+    from adafocus_amd import parallel as P
+    assert P._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and P._cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    assert P.bind_to_gpu_numa(0) is None or isinstance(P.bind_to_gpu_numa(0), int)
+    if not torch.cuda.is_available():
+        assert os.sched_getaffinity(0) == before
+    # on a CPU tensor the side-stream gather degrades to the blocking one
+    x = torch.arange(6.0).view(2, 3)
+    assert torch.equal(P.gather_logits_async(x, None), x)
