@@ -169,8 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 // the barrier words are cleared by a kernel, not by hipMemsetAsync: captured into a HIP graph (GFV.capture_hot_path) the memset
 // node did not reliably re-zero them on replay (measured: logits of later steps differed from the eager launch)
+// ... and with agent-scope atomic stores: the scan's blocks count on these words with device-scope atomics from every XCD, and
+// a plain store is only guaranteed to reach them through the end-of-kernel write-back, which a graph replay need not do between
+// two of its nodes.
 __global__ void zero_words_kernel(unsigned* p, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(p + i, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int kH = 1024, kJB = 8, kGrid = kH / kJB;
