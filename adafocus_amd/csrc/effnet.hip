@@ -95,6 +95,10 @@ struct DwArgs {
     int WP;              // staged columns: (TWG * OXT - 1) * S + K
     int IMB, PG;         // images per block, pixel-group lanes per (image, channel chunk): IMB * PG * LPP <= 256
     int igroups;         // ceil(n / IMB)
+    // pipelined (persistent, double-buffered) form
+    const float* zeros;  // >= 16 bytes of zeros: source of the staged chunks that fall outside the image
+    int tile_bytes;      // bytes of one staged buffer: IMB * ihmax * WP * LPP chunks rounded up to 256 chunks
+    int total;           // work items: igroups * tiles * slices
 };
 
 template <int K, int S, int OXT, typename T>
@@ -104,6 +108,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
+    {
+        // XCD-aware, bijective remap (the hardware places block b on XCD b % 8): every XCD gets a contiguous range of work
+        // items, so the channel slices of one tile -- which read interleaved 16 LPP-byte pieces of the same pixels -- and
+        // neighbouring tiles -- which share halo rows -- meet in ONE L2.  Measured before: the stride-2 layer of block 2
+        // fetched 2.2x its input from the fabric.
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int slice = bid % a.slices; bid /= a.slices;
     const int tile = bid % a.tiles;
     const int img0 = (bid / a.tiles) * a.IMB;
@@ -243,6 +256,175 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             float s = 0.f;
             for (int q = 0; q < a.PG; ++q) s += red[(ri * TPI + q * a.LPP + g) * V + e];
             a.pool_part[((size_t)(img0 + ri) * a.tiles + tile) * a.C + c0 + c] = s;
+        }
+    }
+}
+
+// ---- the same work as dw_same_kernel, software-pipelined ----------------------------------------------------------------
+// Measured on the first version (one tile per block: load -> barrier -> taps -> store): every layer ran at 2-3 TB/s whatever the
+// tile size or the number of resident blocks, because a block spends its load phase, its tap phase and its store phase one after
+// the other and three or four such blocks per CU do not cover each other.  Here a PERSISTENT block walks its work items with two
+// staged buffers: while the taps of item i run out of one buffer, the chunks of item i+1 travel straight from global memory into
+// the other one by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass; chunks outside the image come from a block
+// of zeros, so there is no select either), one barrier per item.  The DMA writes 64 consecutive 16-byte chunks per wave
+// instruction, so the staged image is dense (pixel pitch = LPP chunks) in the order (image, row, column, chunk).
+template <int K, int S, int OXT, typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void dw_same_pipe_kernel(const DwArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int NC = (OXT - 1) * S + K;
+    constexpr int WFL = (K * K + 2);         // weight rows per slice: taps + BN scale + BN bias
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pitchB = a.LPP * 16;
+    const int ihmax = (a.TH - 1) * S + K;
+    const int img_lds = ihmax * a.WP * pitchB;
+    char* bufs[2] = {dsm, dsm + a.tile_bytes};
+    float* wls[2] = {reinterpret_cast<float*>(dsm + 2 * (size_t)a.tile_bytes), reinterpret_cast<float*>(dsm + 2 * (size_t)a.tile_bytes) + WFL * a.CS};
+    float* red = wls[1] + WFL * a.CS;        // [256][V]
+    const int nk = a.tile_bytes >> 12;       // DMA instructions per wave per item (256 chunks = 4 KB per block-wide pass)
+    // per-lane walk over the chunk index q = tid, tid + 256, ...: (chunk in pixel, pixel) -> (column, row, image)
+    const int cg0 = tid % a.LPP, p0 = tid / a.LPP;
+    const int dcg = 256 % a.LPP, dp = 256 / a.LPP;
+    const int col0 = p0 % a.WP, t0 = p0 / a.WP;
+    const int row0 = t0 % ihmax, im0 = t0 / ihmax;
+    const int dcol = dp % a.WP, dt = dp / a.WP;
+    const int drow = dt % ihmax, dim = dt / ihmax;
+    const T* xall = static_cast<const T*>(a.x);
+
+    auto decode = [&](int w, int& slice, int& tile, int& img0) {
+        slice = w % a.slices;
+        const int r = w / a.slices;
+        tile = r % a.tiles;
+        img0 = (r / a.tiles) * a.IMB;
+    };
+    auto issue = [&](int w, int b) {
+        int slice, tile, img0;
+        decode(w, slice, tile, img0);
+        const int nimg = min(a.IMB, a.n - img0);
+        const int c0 = slice * a.CS;
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int iy0 = ty * a.TH * S - a.pad_t, ix0 = tx * a.TWG * OXT * S - a.pad_l;
+        int cg = cg0, col = col0, row = row0, im = im0;
+        char* dst = bufs[b] + wave * 1024;
+        for (int k = 0; k < nk; ++k) {
+            const int iy = iy0 + row, ix = ix0 + col;
+            const bool ok = im < nimg && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const T* src = ok ? xall + (((size_t)(img0 + im) * a.H + iy) * a.W + ix) * a.C + c0 + cg * V : reinterpret_cast<const T*>(a.zeros);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + k * 4096), 16, 0, 0);
+            // next chunk of this lane: q += 256
+            cg += dcg; col += dcol; row += drow; im += dim;
+            if (cg >= a.LPP) { cg -= a.LPP; ++col; }
+            if (col >= a.WP) { col -= a.WP; ++row; }
+            if (row >= ihmax) { row -= ihmax; ++im; }
+        }
+        float* wl = wls[b];
+        for (int i = tid; i < K * K * a.CS; i += 256) {
+            const int tap = i / a.CS;
+            wl[i] = a.wt[(size_t)tap * a.C + c0 + (i - tap * a.CS)];
+        }
+        for (int i = tid; i < 2 * a.CS; i += 256) wl[K * K * a.CS + i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
+    };
+
+    const int TPI = a.LPP * a.PG;
+    const int im = tid / TPI, rem = tid - im * TPI;
+    const int cg = rem % a.LPP, pg = rem / a.LPP;
+    int w = blockIdx.x;
+    if (w < a.total) issue(w, 0);
+    for (int it = 0; w < a.total; ++it, w += gridDim.x) {
+        const int b = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA for item w has landed (and its earlier stores have left)
+        __syncthreads();                                       // ... everyone's has; everyone is done with the other buffer
+        if (w + (int)gridDim.x < a.total) issue(w + gridDim.x, b ^ 1);
+        int slice, tile, img0;
+        decode(w, slice, tile, img0);
+        const int nimg = min(a.IMB, a.n - img0);
+        const int c0 = slice * a.CS;
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int oy0 = ty * a.TH;
+        const int th = min(a.TH, a.OH - oy0);
+        const int xg0 = tx * a.TWG;
+        const float* wl = wls[b];
+        const float* sbl = wl + K * K * a.CS;
+        float psum[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) psum[e] = 0.f;
+        if (im < nimg) {
+            const int nxg = min(a.TWG, (a.OW + OXT - 1) / OXT - xg0);
+            const int dxg = a.PG % nxg, dr = a.PG / nxg;
+            int xg = pg % nxg, r = pg / nxg;
+            T* ob = static_cast<T*>(a.out) + ((size_t)(img0 + im) * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
+            const char* xim = bufs[b] + (size_t)im * img_lds + cg * 16;
+            while (r < th) {
+                const int ox0 = (xg0 + xg) * OXT;
+                float acc[OXT][V];
+#pragma unroll
+                for (int o = 0; o < OXT; ++o)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+                for (int ky = 0; ky < K; ++ky) {
+                    const char* rowp = xim + ((size_t)(r * S + ky) * a.WP + xg * OXT * S) * pitchB;
+                    float wv[K][V];
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const float* wp = wl + (ky * K + kx) * a.CS + cg * V;
+#pragma unroll
+                        for (int e = 0; e < V; e += 4) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
+                            wv[kx][e] = w4.x; wv[kx][e + 1] = w4.y; wv[kx][e + 2] = w4.z; wv[kx][e + 3] = w4.w;
+                        }
+                    }
+#pragma unroll
+                    for (int ci = 0; ci < NC; ++ci) {
+                        float xf[V];
+                        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * pitchB), xf);
+#pragma unroll
+                        for (int o = 0; o < OXT; ++o) {
+                            const int kx = ci - o * S;
+                            if (kx >= 0 && kx < K) {
+#pragma unroll
+                                for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], wv[kx][e], acc[o][e]);
+                            }
+                        }
+                    }
+                }
+                float sc[V], bi[V];
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + cg * V + e), b4 = *reinterpret_cast<const f32x4*>(sbl + a.CS + cg * V + e);
+                    sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
+                    bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
+                }
+#pragma unroll
+                for (int o = 0; o < OXT; ++o) {
+                    if (ox0 + o < a.OW) {
+                        float v[V];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
+                            psum[e] += v[e];
+                        }
+                        *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.C) = Chunk<T>::pack(v);
+                    }
+                }
+                xg += dxg; r += dr;
+                if (xg >= nxg) { xg -= nxg; ++r; }
+            }
+        }
+        if (a.pool_part) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[tid * V + e] = psum[e];
+            __syncthreads();
+            for (int t = tid; t < nimg * a.CS; t += 256) {
+                const int ri = t / a.CS, c = t - ri * a.CS;
+                const int g = c / V, e = c % V;
+                float s = 0.f;
+                for (int q = 0; q < a.PG; ++q) s += red[(ri * TPI + q * a.LPP + g) * V + e];
+                a.pool_part[((size_t)(img0 + ri) * a.tiles + tile) * a.C + c0 + c] = s;
+            }
+            // (the next iteration's barrier separates these reads of `red` from its next writes)
         }
     }
 }
@@ -555,14 +737,33 @@ __global__ void avgpool_any_kernel(const T* __restrict__ x, int n, int hw, int c
 }
 
 // ---- launch planning ---------------------------------------------------------------------------------------------------
-struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, TWG, tiles_y, tiles_x, tiles, IMB, PG; size_t lds; };
+struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, TWG, tiles_y, tiles_x, tiles, IMB, PG; size_t lds; int tile_bytes; bool pipe; };
 
-const size_t kDwLdsBudget = 48 * 1024;
+// ADAF_DW_PIPE=1 selects the persistent double-buffered kernel (measured SLOWER than the one-tile-per-block form: 16.3 vs 12.0 ms
+// for the fp16 network -- kept as the A/B arm that showed the layers are not bound by exposed load latency); default 0
+static int dw_pipe_enabled() {
+    static const int on = [] { const char* e = getenv("ADAF_DW_PIPE"); return e ? atoi(e) : 0; }();
+    return on;
+}
+static size_t dw_pipe_tile_budget() {
+    static const size_t b = [] { const char* e = getenv("ADAF_DW_PIPE_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 28) * 1024; }();
+    return b;
+}
+
+// LDS per block the tile planner may spend (ADAF_DW_LDS_KB overrides, for tuning): the tile size trades halo re-reads and
+// per-block overhead against the number of blocks a CU can hold, i.e. the loads in flight
+static size_t dw_lds_budget() {
+    static const size_t b = [] { const char* e = getenv("ADAF_DW_LDS_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 48) * 1024; }();
+    return b;
+}
+#define kDwLdsBudget dw_lds_budget()
 
 // Tile = TH output rows x TWG groups of OXT outputs, of IMB images, for one channel slice.  Chosen by a small cost model:
 // per output, (staged input chunks x the cost of a load + LDS store) + (thread passes x the tap work of a pass), the passes
 // counted with their idle lanes -- a tile whose items do not fill the block's lanes pays for the empty ones.
 bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
+    p->pipe = dw_pipe_enabled() != 0;
+    const size_t budget = p->pipe ? dw_pipe_tile_budget() : kDwLdsBudget;
     p->V = 16 / esize;
     if (C % p->V) return false;
     const int chunks = C / p->V;
@@ -573,8 +774,8 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     p->slices = C / p->CS;
     p->OXT = OW % 4 == 0 ? 4 : OW % 3 == 0 ? 3 : OW % 5 == 0 ? 5 : 4;
     const int nxg = (OW + p->OXT - 1) / p->OXT;
-    p->pitch16 = p->LPP | 1;                       // odd pitch: consecutive pixels start in different bank groups
-    const size_t fixed = (size_t)(K * K + 2) * p->CS * 4;
+    p->pitch16 = p->pipe ? p->LPP : (p->LPP | 1);  // odd pitch: consecutive pixels start in different bank groups (the DMA form is dense)
+    const size_t fixed = p->pipe ? 0 : (size_t)(K * K + 2) * p->CS * 4;
     const int lanes = 256 / p->LPP;
     auto img_bytes = [&](int th, int twg) { return (size_t)((th - 1) * S + K) * ((twg * p->OXT - 1) * S + K) * p->pitch16 * 16; };
     double best = 1e300;
@@ -586,11 +787,11 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
             const int tx = (nxg + twg - 1) / twg;
             if ((nxg + tx - 1) / tx != twg) continue;
             const size_t ib = img_bytes(th, twg);
-            if (ib + fixed > kDwLdsBudget) break;
+            if (ib + fixed > budget) break;
             const int groups = th * twg;
             int pg = groups < lanes ? groups : lanes;
             int imb = 256 / (p->LPP * pg);
-            while (imb > 1 && (size_t)imb * ib + fixed > kDwLdsBudget) --imb;
+            while (imb > 1 && (size_t)imb * ib + fixed > budget) --imb;
             if (imb < 1) imb = 1;
             const int passes = (groups + pg - 1) / pg;
             const double staged = (double)imb * ((th - 1) * S + K) * ((twg * p->OXT - 1) * S + K) * p->LPP;
@@ -603,24 +804,43 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     p->WP = (p->TWG * p->OXT - 1) * S + K;
     p->lds = (size_t)p->IMB * img_bytes(p->TH, p->TWG) + fixed;
     const size_t red = (size_t)256 * p->V * 4;
-    if (p->lds < red) p->lds = red;
+    if (p->pipe) {
+        p->tile_bytes = (int)(((size_t)p->IMB * img_bytes(p->TH, p->TWG) + 4095) / 4096 * 4096);
+        p->lds = 2 * (size_t)p->tile_bytes + 2 * (size_t)(K * K + 2) * p->CS * 4 + red;
+    } else if (p->lds < red) p->lds = red;
     return true;
 }
 
+template <int K, int S, int OXT, typename T>
+void launch_dw_one(const DwArgs& a, bool pipe, size_t lds, int cus, hipStream_t s) {
+    if (pipe) {
+        static bool attr_set = false;
+        if (!attr_set) {      // dynamic LDS above 64 KB has to be asked for
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_same_pipe_kernel<K, S, OXT, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        int per_cu = (int)((160 * 1024) / lds);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+        const int grid = a.total < cus * per_cu ? a.total : cus * per_cu;
+        hipLaunchKernelGGL((dw_same_pipe_kernel<K, S, OXT, T>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((dw_same_kernel<K, S, OXT, T>), dim3((unsigned)a.total), dim3(256), lds, s, a);
+    }
+}
+
 template <int K, int S, typename T>
-void launch_dw_oxt(const DwArgs& a, int oxt, size_t lds, hipStream_t s) {
-    const dim3 grid((unsigned)((size_t)a.igroups * a.tiles * a.slices)), block(256);
-    if (oxt == 3) hipLaunchKernelGGL((dw_same_kernel<K, S, 3, T>), grid, block, lds, s, a);
-    else if (oxt == 5) hipLaunchKernelGGL((dw_same_kernel<K, S, 5, T>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((dw_same_kernel<K, S, 4, T>), grid, block, lds, s, a);
+void launch_dw_oxt(const DwArgs& a, int oxt, bool pipe, size_t lds, int cus, hipStream_t s) {
+    if (oxt == 3) launch_dw_one<K, S, 3, T>(a, pipe, lds, cus, s);
+    else if (oxt == 5) launch_dw_one<K, S, 5, T>(a, pipe, lds, cus, s);
+    else launch_dw_one<K, S, 4, T>(a, pipe, lds, cus, s);
 }
 
 template <typename T>
-bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, size_t lds, hipStream_t s) {
-    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T>(a, oxt, lds, s);
-    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T>(a, oxt, lds, s);
-    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T>(a, oxt, lds, s);
-    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T>(a, oxt, lds, s);
+bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, bool pipe, size_t lds, int cus, hipStream_t s) {
+    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T>(a, oxt, pipe, lds, cus, s);
+    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T>(a, oxt, pipe, lds, cus, s);
+    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T>(a, oxt, pipe, lds, cus, s);
+    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T>(a, oxt, pipe, lds, cus, s);
     else return false;
     return true;
 }
@@ -638,7 +858,7 @@ int adaf_effnet_dw_tiles(int c, int oh, int ow, int k, int stride, int dtype) {
 
 int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, int pad_t, int pad_l, int oh,
                         int ow, const float* wt, const float* scale, const float* bias, int act, void* out, float* pool_part,
-                        hipStream_t s) {
+                        const float* zeros, int cus, hipStream_t s) {
     DwPlan p;
     if (!plan_dw(c, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
     DwArgs a;
@@ -648,8 +868,9 @@ int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, 
     a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
     a.pitch16 = p.pitch16; a.WP = p.WP;
     a.IMB = p.IMB; a.PG = p.PG; a.igroups = (n + p.IMB - 1) / p.IMB;
-    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.lds, s)
-                                            : launch_dw_t<float>(a, k, stride, p.OXT, p.lds, s);
+    a.zeros = zeros; a.tile_bytes = p.tile_bytes; a.total = a.igroups * a.tiles * a.slices;
+    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.pipe, p.lds, cus, s)
+                                            : launch_dw_t<float>(a, k, stride, p.OXT, p.pipe, p.lds, cus, s);
     return ok ? p.tiles : -1;
 }
 
@@ -1025,7 +1246,7 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             const int ohw = conv_out_len(hw, b.k, b.stride, tot);
             const EfConv& D = net->convs[b.dwc];
             const int tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
-                                                  D.bias, ADAF_ACT_SWISH, bufD, part, st);
+                                                  D.bias, ADAF_ACT_SWISH, bufD, part, net->h->zeros, net->h->cus, st);
             if (tiles <= 0) return efail(h, ADAF_E_LAUNCH, "effnet: depthwise launch (block %zu)", bi);
             adaf_launch_se_gate(part, tiles, ohw * ohw, nc, b.hid, b.se_wr, b.se_br, b.sq, b.se_wet, 1, b.hid, b.se_be, gate, st);
             const EfConv& P = net->convs[b.project];
@@ -1086,7 +1307,8 @@ int adaf_dwconv_same_bn_act(adaf_handle* h, const void* x, int dtype, int n, int
         if (!ws || ws_bytes < adaf_dwconv_same_workspace_bytes(n, hh, ww, c, k, stride, dtype)) return efail(h, ADAF_E_NOMEM, "dwconv_same: workspace");
         part = static_cast<float*>(ws);
     }
-    const int tiles = adaf_launch_dw_same(x, dtype, n, hh, ww, c, k, stride, pt, pl, oh, ow, w_kkc, scale, bias, act, out, part, (hipStream_t)stream);
+    const int tiles = adaf_launch_dw_same(x, dtype, n, hh, ww, c, k, stride, pt, pl, oh, ow, w_kkc, scale, bias, act, out, part, h->zeros, h->cus,
+                                          (hipStream_t)stream);
     if (tiles <= 0) return efail(h, ADAF_E_LAYOUT, "dwconv_same: shape not supported");
     if (pool_mean) adaf_launch_pool_finish(part, n, tiles, c, oh * ow, pool_mean, (hipStream_t)stream);
     hipError_t e = hipGetLastError();

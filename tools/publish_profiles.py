@@ -37,6 +37,23 @@ def counter_rows(path, counter):
     return disp, total, passes
 
 
+EXTRA = {   # round 3: summaries that are copied as they are (tools/profile_r3.sh)
+    "effnet_f16_trace": "rocprofv3 --kernel-trace --stats -- python tools/effnet_probe.py 1024 144 5 f16   (EfficientNet-B3 local CNN, fp16 storage, 3 warm-up + 5 timed forwards)",
+    "effnet_f32_trace": "rocprofv3 --kernel-trace --stats -- python tools/effnet_probe.py 1024 144 5 f32   (fp32 storage)",
+    "effnet_f16_sq": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -- python tools/effnet_probe.py 1024 144 5 f16",
+    "effnet_f16_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB; x2 for wide coalesced reads on gfx950, MI355X_MICROARCH.md)",
+    "effnet_f16_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB)",
+    "resize_trace": "rocprofv3 --kernel-trace --stats -- python tools/crop_resize_probe.py 5   (adaf_crop_resize_f32, 1024 frames, S = 128 / 192 / mixed -> 96^2)",
+    "resize_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/crop_resize_probe.py 5   (KB; x2 for wide coalesced reads)",
+    "resize_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/crop_resize_probe.py 5   (KB)",
+}
+for short, cmd in EXTRA.items():
+    src = os.path.join(OUT, "%s_%s.md" % (tag, short))
+    if os.path.exists(src):
+        body = open(src).read().split("\n", 1)[1]
+        open(os.path.join(PROF, "%s_%s.md" % (tag, short)), "w").write("# %s\n%s" % (cmd, body))
+        print("published", short)
+
 for short, name in NAMES.items():
     src = os.path.join(OUT, "%s_%s.md" % (tag, short))
     if not os.path.exists(src):
