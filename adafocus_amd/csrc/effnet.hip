@@ -429,6 +429,227 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 }
 
+// ---- fused expand 1x1 (+BN+swish) -> depthwise k x k (+BN+swish) + squeeze partial sums ---------------------------------
+// For the blocks whose input is narrow (cin <= 64: blocks 2..7 of B3), so that the 6x-expanded map never exists in HBM -- it is
+// the largest tensor of the network (1.5 GB per 1024 patches in block 2 alone) and would be written by one launch only to be
+// read back by the next.  A block owns one image x one output tile x one slice of HS = 32 TN hidden channels:
+//   phase 0  the input pixels the tile's depthwise windows touch (halo included) go to LDS once, k padded to a whole MFMA step
+//            (zeros), together with the slice's rows of the expand filter and a per-pixel "inside the image" flag;
+//   phase 1  expand on the matrix cores: bands of 32 staged pixels x the slice's channels, the SAME instruction and k order as
+//            the stand-alone expand launch (v_mfma_f32_32x32x2_f32 over k, or v_mfma_f32_32x32x16_f16), BN affine + swish in the
+//            epilogue, rounded to the storage type, pixels outside the image forced to 0 (the depthwise conv pads the EXPANDED
+//            map), into the LDS image E[pixel][HS];
+//   phase 2  the depthwise taps out of E exactly as dw_same_kernel does them, the squeeze partial sums, the stores.
+// Every value is produced by the same arithmetic in the same order as by the two-launch plan: the results are bit-identical
+// (tests/test_effnet.py::test_b3_fused_expand_dw_bit_identical).  Halo pixels are expanded more than once (1.13x at 8x8
+// stride-2 tiles, 1.4-1.6x at stride 1); the expand is a few per cent of the block's work on the fp16 pipe.
+struct EfFuseArgs {
+    const void* x;        // [n][H][W][cin]
+    const void* we;       // [hid][cin] expand filter (storage type)
+    const float* se;      // [hid] expand BN
+    const float* be;
+    const float* wd;      // [K*K][hid] depthwise taps
+    const float* sd;      // [hid] depthwise BN
+    const float* bd;
+    void* out;            // [n][OH][OW][hid]
+    float* pool_part;     // [n][tiles][hid]
+    int n, H, W, cin, hid, OH, OW, pad_t, pad_l, act;
+    int TH, TWG, tiles_x, tiles, slices;
+    int NPW, NPH;         // staged pixels per row / rows
+    int KP;               // cin padded to a whole MFMA k step (elements)
+};
+
+template <int K, int S, int OXT, typename T, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 : 4, 8))) void ef_expand_dw_kernel(const EfFuseArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int NC = (OXT - 1) * S + K;
+    constexpr int HS = 32 * TN, LPP = HS / V;
+    constexpr int KSTEP = sizeof(T) == 2 ? 16 : 8;        // k elements per 16-byte-per-lane step
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int slice = bid % a.slices; bid /= a.slices;
+    const int tile = bid % a.tiles;
+    const int img = bid / a.tiles;
+    const int c0 = slice * HS;
+    const int cvalid = min(LPP, (a.hid - c0) / V);        // 16-byte chunks of this slice that exist
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * a.TH, xg0 = tx * a.TWG;
+    const int th = min(a.TH, a.OH - oy0);
+    const int iy0 = oy0 * S - a.pad_t, ix0 = xg0 * OXT * S - a.pad_l;
+    const int NP = a.NPW * a.NPH;
+    const int NB = (NP + 31) >> 5;                        // 32-pixel bands
+    const int xpitch = a.KP * (int)sizeof(T) + 16;        // bytes per staged pixel / filter row (+16: the 32 rows a fragment read
+    const int epitch = HS * (int)sizeof(T) + 16;          //  touches start in different banks)
+    char* xl = dsm;                                                   // [NB*32][xpitch]
+    char* wel = xl + (size_t)NB * 32 * xpitch;                        // [HS][xpitch]
+    char* el = wel + (size_t)HS * xpitch;                             // [NB*32][epitch]
+    float* wl = reinterpret_cast<float*>(el + (size_t)NB * 32 * epitch);   // [K*K][HS] taps
+    float* sbl = wl + K * K * HS;                                     // [4][HS]: dw scale, dw bias, expand scale, expand bias
+    unsigned char* inside = reinterpret_cast<unsigned char*>(sbl + 4 * HS);   // [NB*32]
+
+    // ---- phase 0 ----
+    const int CPP = xpitch / 16 - 1;                       // 16-byte chunks per padded pixel row
+    const int cin_chunks = a.cin / V;
+    {
+        const T* xb = static_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.cin;
+        for (int i = tid; i < NB * 32 * CPP; i += 256) {
+            const int p = i / CPP, c = i - p * CPP;
+            const int py = p / a.NPW, px = p - py * a.NPW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool in = p < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (in && c < cin_chunks) v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.cin + c * V);
+            *reinterpret_cast<u32x4*>(xl + (size_t)p * xpitch + c * 16) = v;
+            if (c == 0) inside[p] = in ? 1 : 0;
+        }
+        const T* wb = static_cast<const T*>(a.we);
+        for (int i = tid; i < HS * CPP; i += 256) {
+            const int h = i / CPP, c = i - h * CPP;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (c0 + h < a.hid && c < cin_chunks) v = *reinterpret_cast<const u32x4*>(wb + (size_t)(c0 + h) * a.cin + c * V);
+            *reinterpret_cast<u32x4*>(wel + (size_t)h * xpitch + c * 16) = v;
+        }
+        for (int i = tid; i < K * K * HS; i += 256) {
+            const int tap = i / HS, h = i - tap * HS;
+            wl[i] = c0 + h < a.hid ? a.wd[(size_t)tap * a.hid + c0 + h] : 0.f;
+        }
+        for (int i = tid; i < 4 * HS; i += 256) {
+            const int which = i / HS, h = i - which * HS;
+            const float* src = which == 0 ? a.sd : which == 1 ? a.bd : which == 2 ? a.se : a.be;
+            sbl[i] = c0 + h < a.hid ? src[c0 + h] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: E = act(BN(X We^T)) for every staged pixel ----
+    {
+        const int nl = lane & 31, half = lane >> 5;
+        const int ksteps = a.KP / KSTEP;
+        for (int band = wave; band < NB; band += 4) {
+            f32x16 acc[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+            const char* arow = xl + (size_t)(band * 32 + nl) * xpitch + half * 16;
+            for (int kk = 0; kk < ksteps; ++kk) {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(arow + kk * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 bf = *reinterpret_cast<const f32x4*>(wel + (size_t)(j * 32 + nl) * xpitch + half * 16 + kk * 32);
+                    if constexpr (sizeof(T) == 2) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf), acc[j], 0, 0, 0);
+                    } else {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int h = j * 32 + nl;
+                const float sc = sbl[2 * HS + h], bi = sbl[3 * HS + h];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int p = band * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    const float v = inside[p] ? act_apply(fmaf(acc[j][i], sc, bi), a.act) : 0.f;
+                    *reinterpret_cast<T*>(el + (size_t)p * epitch + h * sizeof(T)) = (T)v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: depthwise taps out of E ----
+    const int nxg = min(a.TWG, (a.OW + OXT - 1) / OXT - xg0);
+    const int groups = th * nxg;
+    const int PG = 256 / LPP;
+    const int cg = tid % LPP, pg = tid / LPP;
+    float psum[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) psum[e] = 0.f;
+    if (cg < cvalid && pg < PG) {
+        T* ob = static_cast<T*>(a.out) + ((size_t)img * a.OH + oy0) * a.OW * a.hid + c0 + cg * V;
+        const char* xim = el + cg * 16;
+        for (int g = pg; g < groups; g += PG) {
+            const int r = g / nxg, xg = g - r * nxg;
+            const int ox0 = (xg0 + xg) * OXT;
+            float acc[OXT][V];
+#pragma unroll
+            for (int o = 0; o < OXT; ++o)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                const char* rowp = xim + ((size_t)(r * S + ky) * a.NPW + xg * OXT * S) * epitch;
+                float wv[K][V];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* wp = wl + (ky * K + kx) * HS + cg * V;
+#pragma unroll
+                    for (int e = 0; e < V; e += 4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
+                        wv[kx][e] = w4.x; wv[kx][e + 1] = w4.y; wv[kx][e + 2] = w4.z; wv[kx][e + 3] = w4.w;
+                    }
+                }
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) {
+                    float xf[V];
+                    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * epitch), xf);
+#pragma unroll
+                    for (int o = 0; o < OXT; ++o) {
+                        const int kx = ci - o * S;
+                        if (kx >= 0 && kx < K) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], wv[kx][e], acc[o][e]);
+                        }
+                    }
+                }
+            }
+            float sc[V], bi[V];
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + cg * V + e), b4 = *reinterpret_cast<const f32x4*>(sbl + HS + cg * V + e);
+                sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
+                bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
+            }
+#pragma unroll
+            for (int o = 0; o < OXT; ++o) {
+                if (ox0 + o < a.OW) {
+                    float v[V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
+                        psum[e] += v[e];
+                    }
+                    *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.hid) = Chunk<T>::pack(v);
+                }
+            }
+        }
+    }
+    if (a.pool_part) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(dsm);      // [256][V] (the staged input is dead)
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[tid * V + e] = psum[e];
+        __syncthreads();
+        if (tid < cvalid * V) {
+            const int g = tid / V, e = tid % V;
+            float s = 0.f;
+            for (int q = 0; q < PG; ++q) s += red[(q * LPP + g) * V + e];
+            a.pool_part[((size_t)img * a.tiles + tile) * a.hid + c0 + tid] = s;
+        }
+    }
+}
+
 // mean[n][c] = sum_t part[n][t][c] / hw  (the stand-alone op's squeeze output)
 __global__ void pool_finish_kernel(const float* __restrict__ part, int n, int tiles, int c, float inv_hw, float* __restrict__ mean) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,6 +1095,108 @@ int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, 
     return ok ? p.tiles : -1;
 }
 
+// ---- fused expand -> depthwise: planning and launch ---------------------------------------------------------------------
+namespace {
+struct EfPlan { int OXT, TN, HS, slices, KP, TH, TWG, tiles_x, tiles_y, tiles, NPW, NPH; size_t lds; };
+
+static size_t ef_lds_budget() {
+    static const size_t b = [] { const char* e = getenv("ADAF_EF_LDS_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 52) * 1024; }();
+    return b;
+}
+
+bool plan_ef(int cin, int hid, int OH, int OW, int K, int S, int esize, EfPlan* p) {
+    const int V = 16 / esize;
+    if (cin % V || hid % V || cin > 64) return false;
+    const int kstep = esize == 2 ? 16 : 8;
+    p->KP = (cin + kstep - 1) / kstep * kstep;
+    p->TN = (esize == 2 && hid % 64 == 0) ? 2 : 1;
+    p->HS = 32 * p->TN;
+    p->slices = (hid + p->HS - 1) / p->HS;
+    // outputs per thread along x: the fused kernel's tiles are small (the expanded tile has to fit LDS), so a thread takes as
+    // few outputs as it needs for the block's 256 lanes to be busy in the depthwise phase (ADAF_EF_OXT overrides, tuning)
+    static const int oxt_env = [] { const char* e = getenv("ADAF_EF_OXT"); return e ? atoi(e) : 0; }();
+    p->OXT = oxt_env > 0 ? oxt_env : (S == 2 ? 1 : 2);
+    const int nxg = (OW + p->OXT - 1) / p->OXT;
+    const int LPP = p->HS / V;
+    const size_t xpitch = (size_t)p->KP * esize + 16, epitch = (size_t)p->HS * esize + 16;
+    auto lds = [&](int th, int twg) {
+        const int npw = (twg * p->OXT - 1) * S + K, nph = (th - 1) * S + K;
+        const size_t nb32 = (size_t)((npw * nph + 31) / 32) * 32;
+        return nb32 * (xpitch + epitch + 1) + p->HS * xpitch + (size_t)(K * K + 4) * p->HS * 4;
+    };
+    long best = -1;
+    p->TH = 0;
+    for (int th = 1; th <= OH; ++th) {
+        const int ty = (OH + th - 1) / th;
+        if ((OH + ty - 1) / ty != th) continue;
+        for (int twg = 1; twg <= nxg; ++twg) {
+            const int tx = (nxg + twg - 1) / twg;
+            if ((nxg + tx - 1) / tx != twg) continue;
+            if (lds(th, twg) > ef_lds_budget()) break;
+            // the more outputs per staged pixel the better (less halo to expand again); among equals, tiles whose depthwise
+            // phase fills the block's lanes
+            const int groups = th * twg, lanes = 256 / LPP;
+            const int passes = (groups + lanes - 1) / lanes;
+            const int npw = (twg * p->OXT - 1) * S + K, nph = (th - 1) * S + K;
+            const long score = (long)(1000.0 * (double)(groups * p->OXT) / (double)(npw * nph) * ((double)groups / (double)(passes * lanes) * 0.5 + 0.5));
+            if (score > best) { best = score; p->TH = th; p->TWG = twg; p->tiles_y = ty; p->tiles_x = tx; }
+        }
+    }
+    if (p->TH == 0) return false;
+    p->tiles = p->tiles_x * p->tiles_y;
+    p->NPW = (p->TWG * p->OXT - 1) * S + K;
+    p->NPH = (p->TH - 1) * S + K;
+    p->lds = lds(p->TH, p->TWG);
+    const size_t red = (size_t)256 * V * 4;
+    if (p->lds < red) p->lds = red;
+    return true;
+}
+
+template <int K, int S, int OXT, typename T>
+void launch_ef_tn(const EfFuseArgs& a, int tn, unsigned grid, size_t lds, hipStream_t s) {
+    if (tn == 2) hipLaunchKernelGGL((ef_expand_dw_kernel<K, S, OXT, T, 2>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((ef_expand_dw_kernel<K, S, OXT, T, 1>), dim3(grid), dim3(256), lds, s, a);
+}
+template <int K, int S, typename T>
+void launch_ef_oxt(const EfFuseArgs& a, int oxt, int tn, unsigned grid, size_t lds, hipStream_t s) {
+    if (oxt == 1) launch_ef_tn<K, S, 1, T>(a, tn, grid, lds, s);
+    else if (oxt == 2) launch_ef_tn<K, S, 2, T>(a, tn, grid, lds, s);
+    else launch_ef_tn<K, S, 4, T>(a, tn, grid, lds, s);
+}
+template <typename T>
+bool launch_ef_t(const EfFuseArgs& a, int K, int S, int oxt, int tn, unsigned grid, size_t lds, hipStream_t s) {
+    if (K == 3 && S == 1) launch_ef_oxt<3, 1, T>(a, oxt, tn, grid, lds, s);
+    else if (K == 3 && S == 2) launch_ef_oxt<3, 2, T>(a, oxt, tn, grid, lds, s);
+    else if (K == 5 && S == 1) launch_ef_oxt<5, 1, T>(a, oxt, tn, grid, lds, s);
+    else if (K == 5 && S == 2) launch_ef_oxt<5, 2, T>(a, oxt, tn, grid, lds, s);
+    else return false;
+    return true;
+}
+}  // namespace
+
+// tiles per image of the fused launch's squeeze partial sums (> 0), or < 0 when the shape is not eligible
+int adaf_effnet_ef_tiles(int cin, int hid, int oh, int ow, int k, int stride, int dtype) {
+    EfPlan p;
+    if (!plan_ef(cin, hid, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
+    return p.tiles;
+}
+
+int adaf_launch_ef_expand_dw(const void* x, int dtype, int n, int hh, int ww, int cin, const void* we, const float* se, const float* be,
+                             int hid, int k, int stride, int pad_t, int pad_l, int oh, int ow, const float* wd, const float* sd,
+                             const float* bd, int act, void* out, float* pool_part, hipStream_t s) {
+    EfPlan p;
+    if (!plan_ef(cin, hid, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
+    EfFuseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.we = we; a.se = se; a.be = be; a.wd = wd; a.sd = sd; a.bd = bd; a.out = out; a.pool_part = pool_part;
+    a.n = n; a.H = hh; a.W = ww; a.cin = cin; a.hid = hid; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
+    a.TH = p.TH; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.tiles = p.tiles; a.slices = p.slices; a.NPW = p.NPW; a.NPH = p.NPH; a.KP = p.KP;
+    const unsigned grid = (unsigned)((size_t)n * p.tiles * p.slices);
+    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_ef_t<_Float16>(a, k, stride, p.OXT, p.TN, grid, p.lds, s)
+                                            : launch_ef_t<float>(a, k, stride, p.OXT, p.TN, grid, p.lds, s);
+    return ok ? p.tiles : -1;
+}
+
 void adaf_launch_pool_finish(const float* part, int n, int tiles, int c, int hw, float* mean, hipStream_t s) {
     hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)(((size_t)n * c + 255) / 256)), dim3(256), 0, s, part, n, tiles, c,
                        1.f / (float)hw, mean);
@@ -944,6 +1267,11 @@ struct adaf_effnet {
     std::vector<EfBlock> blocks;
     int stem = 0, head = 0, feat = 1280;
     int dtype = ADAF_DTYPE_F32;
+    // expand -> depthwise in one kernel for the blocks with a narrow input (ef_expand_dw_kernel).  OFF by default: measured on
+    // 1024 patches of 144^2 it is SLOWER than the two launches it replaces (fp16: block 2 1.96 ms vs 0.88 + 0.95, blocks 3-4
+    // 0.82 vs 0.61, block 5 1.05 vs 0.51; network 13.7 vs 11.9 ms) -- these layers are bound by their instruction streams
+    // (swish on every expanded value incl. the re-expanded halo, the depthwise taps), not by the HBM round trip fusion removes.
+    bool fuse = false;
     bool finalized = false;
 };
 
@@ -1035,7 +1363,11 @@ void slab_sizes(const adaf_effnet* net, int size, int pad_size, int dtype, size_
         if (b.expand >= 0 && (size_t)hw * hw * b.hid > *ex) *ex = (size_t)hw * hw * b.hid;
         if ((size_t)ohw * ohw * b.hid > *dw) *dw = (size_t)ohw * ohw * b.hid;
         if ((size_t)ohw * ohw * b.cout > *io) *io = (size_t)ohw * ohw * b.cout;
-        const int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
+        int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
+        if (b.expand >= 0) {
+            const int ft = adaf_effnet_ef_tiles(b.cin, b.hid, ohw, ohw, b.k, b.stride, dtype);
+            if (ft > tiles) tiles = ft;
+        }
         if ((size_t)(tiles > 0 ? tiles : 1) * b.hid > *pc) *pc = (size_t)(tiles > 0 ? tiles : 1) * b.hid;
         if ((size_t)b.hid > *gc) *gc = b.hid;
         hw = ohw;
@@ -1109,6 +1441,12 @@ int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8) {
     const EfBlock& b = net->blocks[block];
     info8[0] = b.k; info8[1] = b.stride; info8[2] = b.expand_ratio; info8[3] = b.cin; info8[4] = b.cout; info8[5] = b.hid;
     info8[6] = b.sq; info8[7] = net->convs[net->stem].cout;
+    return ADAF_OK;
+}
+
+int adaf_effnet_set_fusion(adaf_effnet* net, int on) {
+    if (!net) return ADAF_E_BADARG;
+    net->fuse = on != 0;
     return ADAF_OK;
 }
 
@@ -1237,16 +1575,25 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             if (upto_block >= 0 && (int)bi >= upto_block) break;
             const EfBlock& b = net->blocks[bi];
             const void* dw_in = cur;
-            if (b.expand >= 0) {
-                if ((rc = run_dense(net, net->convs[b.expand], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, bufE, f16, st)))
-                    return efail(h, rc, "effnet: expand launch (block %zu)", bi);
-                dw_in = bufE;
-            }
             const int pbd = same_pad(ps, b.k, b.stride, &tot);
             const int ohw = conv_out_len(hw, b.k, b.stride, tot);
             const EfConv& D = net->convs[b.dwc];
-            const int tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
-                                                  D.bias, ADAF_ACT_SWISH, bufD, part, net->h->zeros, net->h->cus, st);
+            int tiles = -1;
+            if (b.expand >= 0 && net->fuse && hw >= 16) {
+                // narrow input, wide hidden map: expand -> depthwise in one launch, the expanded map stays in LDS
+                const EfConv& E = net->convs[b.expand];
+                tiles = adaf_launch_ef_expand_dw(cur, net->dtype, nc, hw, hw, b.cin, f16 ? E.w16 : static_cast<const void*>(E.w), E.scale, E.bias,
+                                                 b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale, D.bias, ADAF_ACT_SWISH, bufD, part, st);
+            }
+            if (tiles <= 0) {
+                if (b.expand >= 0) {
+                    if ((rc = run_dense(net, net->convs[b.expand], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, bufE, f16, st)))
+                        return efail(h, rc, "effnet: expand launch (block %zu)", bi);
+                    dw_in = bufE;
+                }
+                tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
+                                            D.bias, ADAF_ACT_SWISH, bufD, part, net->h->zeros, net->h->cus, st);
+            }
             if (tiles <= 0) return efail(h, ADAF_E_LAUNCH, "effnet: depthwise launch (block %zu)", bi);
             adaf_launch_se_gate(part, tiles, ohw * ohw, nc, b.hid, b.se_wr, b.se_br, b.sq, b.se_wet, 1, b.hid, b.se_be, gate, st);
             const EfConv& P = net->convs[b.project];

@@ -97,6 +97,7 @@ class EfficientNet(nn.Module):
         self.last_layer_name = "_fc"            # STH/ops/models_ada.py:73
         self.feature_dim = ch
         self.storage = dtype                    # "f32" | "f16": HBM storage of activations and 1x1 filters
+        self.fusion = False                     # expand -> depthwise in one kernel for the narrow-input blocks (adaf_effnet_set_fusion): measured slower, opt-in
         self._net, self._sig = None, None
 
     @classmethod
@@ -138,6 +139,7 @@ class EfficientNet(nn.Module):
             self._net.set_dtype(self.storage)
             self._net.load(self._neutral(sd))
             self._sig = sig
+        self._net.set_fusion(self.fusion)
         return self._net
 
     def _check_eval(self):

