@@ -149,6 +149,90 @@ def host_cpu():
     return model, (len(cores) or None), (os.cpu_count() or 1)
 
 
+def numa_cpu_sets():
+    """[(node, sorted physical-core representatives, all logical cpus)] from sysfs; one entry for the whole machine if there
+    is no NUMA information.  A physical core is represented by the lowest-numbered of its hardware threads."""
+    nodes = []
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if not d.startswith("node") or not d[4:].isdigit():
+                continue
+            cpus = set()
+            for part in open("/sys/devices/system/node/%s/cpulist" % d).read().strip().split(","):
+                if part:
+                    lo, _, hi = part.partition("-")
+                    cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= os.sched_getaffinity(0)
+            reps = set()
+            for c in cpus:
+                try:
+                    sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+                    reps.add(int(sib.replace("-", ",").split(",")[0]))
+                except OSError:
+                    reps.add(c)
+            if cpus:
+                nodes.append((int(d[4:]), sorted(reps & cpus) or sorted(cpus), sorted(cpus)))
+    except OSError:
+        pass
+    if not nodes:
+        allc = sorted(os.sched_getaffinity(0))
+        nodes = [(0, allc, allc)]
+    return nodes
+
+
+def cpu_worker(spec):
+    """`bench.py --cpu-worker T,P,B,threads,seconds,cpu,cpu,...`: one process of the "all cores" CPU row -- pins itself to the
+    given CPUs, runs the oracle's batched hot path for ~seconds after two warm-ups, prints {"clips_per_s": ...}."""
+    vals = [int(v) for v in spec.split(",")]
+    t, p, b, threads, seconds, cpus = vals[0], vals[1], vals[2], vals[3], vals[4], vals[5:]
+    if cpus:
+        os.sched_setaffinity(0, set(cpus))
+    torch.set_num_threads(threads)
+    from adafocus_amd import synth
+    from oracle import ref_model as O
+    from tests.helpers import manifest
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(manifest()["ACT"], 1007).items()}
+    frames = torch.from_numpy(synth.synth_frames(b, t, 224, seed=1)).view(b * t, 3, 224, 224)
+    act = torch.from_numpy(synth.synth_actions(b * t, 7, seed=2)[1])
+    gvec = torch.randn(b, t, 1280)
+    with torch.no_grad():
+        for _ in range(2):
+            O.act_hot_path(sd, frames, gvec, act, p)
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or time.perf_counter() - t0 < seconds:
+            O.act_hot_path(sd, frames, gvec, act, p)
+            n += 1
+        dt = time.perf_counter() - t0
+    print(json.dumps({"clips_per_s": n * b / dt, "runs": n}), flush=True)
+
+
+def cpu_all_cores_row(t, p, threads, seconds=6):
+    """The whole host: one process per group of `threads` physical cores (each pinned inside ONE NUMA node), all running the
+    oracle's batched hot path at B = 2 at the same time; the row is the SUM of their rates."""
+    import subprocess
+    groups = []
+    for _, phys, _ in numa_cpu_sets():
+        for i in range(0, len(phys) - threads + 1, threads):
+            groups.append(phys[i:i + threads])
+    groups = groups[:16]
+    if not groups:
+        return None
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                               ",".join(str(v) for v in [t, p, 2, threads, seconds] + g)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for g in groups]
+    rates = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=300)
+        for ln in out.splitlines():
+            if ln.startswith("{"):
+                rates.append(json.loads(ln)["clips_per_s"])
+    if not rates:
+        return None
+    return {"clips_per_s": round(sum(rates), 2), "processes": len(rates), "threads_per_process": threads, "cores": len(rates) * threads,
+            "B": 2, "T": t, "P": p, "structure": "batched, %d processes x %d threads pinned to disjoint physical cores, concurrent" % (len(rates), threads),
+            "per_process_clips_per_s": [round(r, 2) for r in rates]}
+
+
 def cpu_baseline(sd, t, p, threads):
     """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host, SURVEY.md §8(d)
     protocol: fp32, `torch.set_num_threads(n)`, 2 warm-ups + the MEDIAN of 7 runs with `time.perf_counter`, at B = 2
@@ -193,6 +277,15 @@ def cpu_baseline(sd, t, p, threads):
         return round(nc / med, 3), round(med, 4)
 
     rows = []
+    # the single-process rows run inside ONE NUMA node (its physical cores): a thread team that straddles sockets is what made
+    # B = 8 slower than B = 2 on the 2-socket hosts
+    old_aff = os.sched_getaffinity(0)
+    node0 = numa_cpu_sets()[0]
+    try:
+        os.sched_setaffinity(0, set(node0[1]))
+    except OSError:
+        pass
+    ncpu = min(ncpu, len(node0[1]))
     with torch.no_grad():
         sweep = {}
         if threads > 0:
@@ -212,11 +305,21 @@ def cpu_baseline(sd, t, p, threads):
                     rate, med = median_rate(per_step(nc, tt, pp), nc)
                     rows.append({"T": tt, "P": pp, "B": nc, "structure": "reference loop (per time step)", "clips_per_s": rate,
                                  "median_s": med})
+    try:
+        os.sched_setaffinity(0, old_aff)
+    except OSError:
+        pass
+    allrow = None
+    try:
+        allrow = cpu_all_cores_row(t, p, min(16, best_thr))
+    except Exception as exc:
+        allrow = {"error": repr(exc)[:200]}
     head = [r for r in rows if (r["T"], r["P"]) == (t, p)]
     best = max(head, key=lambda r: r["clips_per_s"])
     return {"value": best["clips_per_s"], "unit": "clips/s", "cores": best_thr, "kind": "port",
             "cpu_model": model, "physical_cores": phys, "logical_cpus": ncpu, "threads": best_thr,
             "thread_sweep_B8_clips_per_s": sweep or None, "value_is": "B=%d, %s" % (best["B"], best["structure"]),
+            "pinned_to_numa_node": node0[0], "all_cores": allrow,
             "rows": rows,
             "sample": "oracle.act_hot_path (crop -> ResNet-50 -> GRU; torch-CPU fp32 restatement of the reference, pinned by "
                       "tests/golden), T=%d P=%d, B=2 and B=8 clips per call, %d threads, 2 warm-ups + median of 7 runs; `value` = the "
@@ -273,11 +376,15 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the steps are round-robined over (batch i+1's "
                     "trunk overlaps batch i's latency-bound GRU scan); 1 = strictly serial steps")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in for the step: tests the launcher and the protocol")
+    ap.add_argument("--cpu-worker", type=str, default="", help="(internal) one process of the all-cores CPU baseline row")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks run the real step on GPU 0 and gather over gloo (RCCL refuses "
                     "two ranks on one device): exercises the N > 1 path on a single-GPU box; not a scaling measurement")
     a = ap.parse_args()
     if a.cpu_clips is not None and a.cpu_clips <= 0:
         a.cpu_baseline = 0
+    if a.cpu_worker:
+        cpu_worker(a.cpu_worker)
+        return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a.gpus)                       # does not return
