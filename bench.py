@@ -113,15 +113,16 @@ def config5_row(dev, b, streams, frames, steps=30):
 
 
 def load_traffic(t, p, b):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r2_traffic.json, tools/profile_bench.sh);
-    only reported when it was collected on this very workload."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-        w = d["workload"]
-        if (w["frames"], w["patch"], w["batch"]) == (t, p, b):
-            return d["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r<N>_traffic.json, tools/profile_bench.sh +
+    tools/publish_profiles.py; newest round first); only reported when it was collected on this very workload."""
+    for tag in ("r3", "r2"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)))
+            w = d["workload"]
+            if (w["frames"], w["patch"], w["batch"]) == (t, p, b):
+                return d["hbm_bytes_per_launch"]
+        except Exception:
+            pass
     return None
 
 
