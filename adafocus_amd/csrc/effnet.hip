@@ -63,8 +63,12 @@ template <> struct Chunk<_Float16> {
 __device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == ADAF_ACT_SWISH) return v * fast_sigmoid(v);
-    if (act == ADAF_ACT_SIGMOID) return fast_sigmoid(v);
+    // (one logistic evaluation whichever of the two activations wants it: written as two separate branches the compiler
+    // if-converted them and every element paid for both exp2 / rcp pairs)
+    if (act == ADAF_ACT_SWISH || act == ADAF_ACT_SIGMOID) {
+        const float g = fast_sigmoid(v);
+        return act == ADAF_ACT_SWISH ? v * g : g;
+    }
     if (act == ADAF_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ADAF_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
     return v;
@@ -146,10 +150,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         if (slot < PP) {
             const int col0 = slot % a.WP, row0 = slot / a.WP;
             const int dcol = PP % a.WP, drow = PP / a.WP;
+            // all offsets advance by precomputed steps (no multiplies in the loop): pixel slot -> slot + PP
+            const int lstep = (drow * a.WP + dcol) * pitchB;                  // LDS bytes per step
+            const int gstep = (drow * a.W + dcol) * a.C;                      // source elements per step
+            const int gwrap = (a.W - a.WP) * a.C;                             // extra source elements when the column wraps into the next row
             for (int im = 0; im < nimg; ++im) {
                 const T* xb = static_cast<const T*>(a.x) + (size_t)(img0 + im) * a.H * a.W * a.C + c0 + cgl * V;
                 char* dst = xin + (size_t)im * img_lds + cgl * 16;
                 int col = col0, row = row0;
+                int loff = (row0 * a.WP + col0) * pitchB;
+                long long goff = ((long long)(iy0 + row0) * a.W + (ix0 + col0)) * a.C;
                 // batches of four: the loads of a batch are all in flight before the first LDS store waits on one
                 while (row < ihn) {
                     u32x4 v[4];
@@ -158,11 +168,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                     for (int u = 0; u < 4; ++u) {
                         const int iy = iy0 + row, ix = ix0 + col;
                         v[u] = u32x4{0u, 0u, 0u, 0u};
-                        off[u] = row < ihn ? (row * a.WP + col) * pitchB : -1;
+                        off[u] = row < ihn ? loff : -1;
                         if (row < ihn && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                            v[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.C);
-                        col += dcol; row += drow;
-                        if (col >= a.WP) { col -= a.WP; ++row; }
+                            v[u] = *reinterpret_cast<const u32x4*>(xb + goff);
+                        col += dcol; row += drow; loff += lstep; goff += gstep;
+                        if (col >= a.WP) { col -= a.WP; ++row; goff += gwrap; }
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
@@ -183,9 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         const int dxg = a.PG % nxg, dr = a.PG / nxg;
         int xg = pg % nxg, r = pg / nxg;
         T* ob = static_cast<T*>(a.out) + ((size_t)(img0 + im) * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
-        const char* xim = xin + (size_t)im * img_lds + cg * 16;
+        const char* xim = xin + im * img_lds + cg * 16;
+        const int rowstride = a.WP * pitchB;                  // LDS bytes per staged row
         while (r < th) {
             const int ox0 = (xg0 + xg) * OXT;
+            const char* rowp = xim + (r * S * a.WP + xg * OXT * S) * pitchB;
+            T* op = ob + (r * a.OW + ox0) * a.C;
             float acc[OXT][V];
 #pragma unroll
             for (int o = 0; o < OXT; ++o)
@@ -195,7 +208,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             for (int ky = 0; ky < K; ++ky) {
                 // the K taps of this filter row, then every staged column once: column ci feeds output o through tap
                 // kx = ci - o * S (resolved at compile time), so each LDS value is read and converted exactly once
-                const char* rowp = xim + ((size_t)(r * S + ky) * a.WP + xg * OXT * S) * pitchB;
                 float w[K][V];
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                         }
                     }
                 }
+                rowp += rowstride;
             }
             float sc[V], bi[V];
 #pragma unroll
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                         v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
                         psum[e] += v[e];
                     }
-                    *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.C) = Chunk<T>::pack(v);
+                    *reinterpret_cast<u32x4*>(op + o * a.C) = Chunk<T>::pack(v);
                 }
             }
             xg += dxg; r += dr;
