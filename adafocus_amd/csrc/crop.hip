@@ -9,6 +9,8 @@
 // through LDS and writes the contiguous output with 16-byte stores.
 //
 // HBM-bound: algorithmic bytes per patch = 2 * C * P * P * 4 (read window + write patch).
+#include <cstdlib>
+
 #include "adaf_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -360,7 +362,10 @@ static hipError_t launch_resize_mode(const float* frames, int nf, int C, int H, 
                                      int size_default, int fpa, int P, float* out, int32_t* coords, hipStream_t s) {
     const int smax = sizes ? H : (size_default < H ? size_default : H);
     size_t lds = 0;
-    const int rbr = resize_rows_per_block(IN4 ? 4 : C, smax, P, 60 * 1024, &lds);
+    static const size_t budget = [] { const char* e = getenv("ADAF_RESIZE_LDS_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 20) * 1024; }();
+    // (20 KB of staged source rows per block: measured against 12 / 32 / 60 KB on 1024 frames -- 3.5 / 3.8 / 3.4 TB/s at S = 128 / 192 /
+    // mixed vs 3.1 / 2.2 / 1.9 with 60 KB: seven resident blocks per CU hide each other's load -> interpolate -> store phases)
+    const int rbr = resize_rows_per_block(IN4 ? 4 : C, smax, P, budget, &lds);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(nf, (P + rbr - 1) / rbr);
     const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(frames) & 15) == 0);

@@ -321,6 +321,9 @@ def cpu_baseline(sd, t, p, threads):
             "cpu_model": model, "physical_cores": phys, "logical_cpus": ncpu, "threads": best_thr,
             "thread_sweep_B8_clips_per_s": sweep or None, "value_is": "B=%d, %s" % (best["B"], best["structure"]),
             "pinned_to_numa_node": node0[0], "all_cores": allrow,
+            "all_cores_note": "N processes x `threads` pinned to disjoint physical cores, run at the same time and summed; on the gpurun "
+                              "boxes the per-process rate collapses (a container CPU quota and/or shared memory bandwidth), so the sum is "
+                              "not N x the single-process row -- reported as measured",
             "rows": rows,
             "sample": "oracle.act_hot_path (crop -> ResNet-50 -> GRU; torch-CPU fp32 restatement of the reference, pinned by "
                       "tests/golden), T=%d P=%d, B=2 and B=8 clips per call, %d threads, 2 warm-ups + median of 7 runs; `value` = the "

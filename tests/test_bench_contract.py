@@ -34,6 +34,23 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0
+    # round 3: everything the DESIGN claims is in the line the driver records
+    assert rf["algorithmic_bytes_per_launch"] > 0 and r["serial_value"]["value"] > 0 and r["serial_value"]["streams"] == 1
+    also = r["also"]
+    for k in ("config2_T8_P96_act", "config3_T16_P128_act", "config4_T8_P128_sth_tsm"):
+        assert also[k]["clips_per_s"] > 0 and also[k]["steps"] >= 30, (k, also[k])
+    assert also["config2_T8_P96_act"]["T"] == 8 and also["config3_T16_P128_act"]["P"] == 128
+    lat = also["latency_small_batch"]
+    assert lat["B2_T8_P96"]["graph_bit_identical_to_eager"] is True and lat["B1_T8_P96"]["eager_ms"] > 0
+    c5 = also["config5_T16_P144_efficientnet_b3"]
+    assert c5["f16_storage"]["clips_per_s"] > 0 and c5["f32_storage"]["local_cnn"]["bound"] == "hbm"
+    assert c5["f16_storage"]["local_cnn"]["frac"] == pytest.approx(c5["f16_storage"]["local_cnn"]["achieved"] / 8000.0, abs=1e-3)
+    assert also["validate_sth_loop_T8_P128"]["with_baseline_branch"]["value"] > 0
+    gr = r["gather_resize"]
+    assert gr["S128_to_P96"]["achieved"] > 0 and gr["mixed_S96_128_160_192_to_P96"]["unit"] == "GB/s"
+    nr = r["next_rows"]
+    assert nr["evaluate_loop"]["value"] > 0 and nr["f1_ingest_u8"]["frac"] > 0 and nr["full_forward_from_uint8"]["value"] > 0
+    assert cb["all_cores"] is None or "error" in cb["all_cores"] or cb["all_cores"]["clips_per_s"] > 0
 
 
 @pytest.mark.gpu
