@@ -949,6 +949,118 @@ __global__ __launch_bounds__(256) void gated_project_kernel(const ProjArgs a) {
     }
 }
 
+// ---- stem: 3x3 / stride 2, 3 (4) -> C0 channels, SAME padding, + BN + swish ------------------------------------------------
+// On the generic engine this layer is a K = 36 gather GEMM with per-chunk tap arithmetic (0.75 ms per 1024 patches of 144^2,
+// 9x its HBM time).  Here a block owns 8 x 16 output pixels: their 17 x 33 input pixels (16 bytes each: the gather's pixel-major
+// fp32 frames) are staged once in LDS; wave w owns output rows 2w, 2w+1 = one 32-row MFMA band whose A value for
+// k = (tap, channel) is element `channel` of the staged pixel at a compile-time tap offset from the lane's window origin -- one
+// ds_read_b128 per tap, two v_mfma_f32_32x32x2_f32 steps per tap (channels 0|1, then 2|3: the k-lane picks its element), the
+// filter bank in registers.  Exact fp32 products in both storage modes; the epilogue goes through a wave-private LDS slab so
+// every lane stores 16 bytes of consecutive channels.
+struct StemArgs {
+    const float* x4;      // [n][S][S][4]
+    const float* w;       // [C0][3][3][4]
+    const float* scale;   // [C0]
+    const float* bias;
+    void* out;            // [n][OH][OW][C0]
+    int n, S, OH, OW, C0, pad, act;
+    int tiles_x, tiles_y;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int TH = 8, TW = 16, IH = 2 * TH + 1, IW = 2 * TW + 1;
+    constexpr int SP = 68;                                   // slab pitch in floats (64 columns + 4)
+    __shared__ __attribute__((aligned(16))) float xin[IH * IW * 4];
+    __shared__ __attribute__((aligned(16))) float slab[4][32 * SP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // a block walks the tiles of one 8-row band of one image: the filter bank is fetched once per band
+    const int ty = blockIdx.x % a.tiles_y;
+    const int img = blockIdx.x / a.tiles_y;
+    const int oy0 = ty * TH;
+    const float* xb = a.x4 + (size_t)img * a.S * a.S * 4;
+    // filter bank: lane (column, k-lane) keeps w[col][2 s + half] for the 18 steps of both 32-column tiles; it travels through
+    // the slab (coalesced 16-byte loads) instead of 36 scalar loads per lane
+    const int nl = lane & 31, half = lane >> 5;
+    float wreg[2][18];
+    {
+        float* wl = &slab[0][0];
+        for (int i = tid; i < a.C0 * 9; i += 256) *reinterpret_cast<f32x4*>(wl + 4 * i) = *reinterpret_cast<const f32x4*>(a.w + 4 * (size_t)i);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + nl;
+#pragma unroll
+            for (int st = 0; st < 18; ++st) wreg[j][st] = col < a.C0 ? wl[col * 36 + 2 * st + half] : 0.f;
+        }
+        __syncthreads();
+    }
+    float sc[2], bi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + nl;
+        sc[j] = col < a.C0 ? a.scale[col] : 0.f;
+        bi[j] = col < a.C0 ? a.bias[col] : 0.f;
+    }
+    const int cpr = a.C0 / V;                                // 16-byte chunks per output pixel
+    T* ob = static_cast<T*>(a.out) + (size_t)img * a.OH * a.OW * a.C0;
+    float* sl = slab[wave];
+    // this lane's pixel of the band: row 2 wave + (nl >> 4), column nl & 15
+    const float* win = xin + ((2 * (2 * wave + (nl >> 4))) * IW + 2 * (nl & 15)) * 4;
+    for (int tx = 0; tx < a.tiles_x; ++tx) {
+        const int ox0 = tx * TW;
+        const int iy0 = oy0 * 2 - a.pad, ix0 = ox0 * 2 - a.pad;
+        if (tx) __syncthreads();                              // the previous tile's window has been consumed
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int r = i / IW, c = i - r * IW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S) v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * a.S + ix) * 4);
+            *reinterpret_cast<f32x4*>(xin + i * 4) = v;
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const f32x4 px = *reinterpret_cast<const f32x4*>(win + ((tap / 3) * IW + (tap % 3)) * 4);
+            const float a0 = half ? px.y : px.x, a1 = half ? px.w : px.z;       // k = 4 tap + {0|1}, then 4 tap + {2|3}
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wreg[j][2 * tap], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wreg[j][2 * tap + 1], acc[j], 0, 0, 0);
+            }
+        }
+        // epilogue: BN + activation, through the wave's slab, 16-byte stores of V consecutive channels
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + nl;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                sl[((i & 3) + 8 * (i >> 2) + 4 * half) * SP + col] = act_apply(fmaf(acc[j][i], sc[j], bi[j]), a.act);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 32 * cpr; i += 64) {
+            const int p = i / cpr, cq = i - p * cpr;
+            const int oy = oy0 + 2 * wave + (p >> 4), ox = ox0 + (p & 15);
+            if (oy < a.OH && ox < a.OW) {
+                float v[V];
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(sl + p * SP + cq * V + e);
+                    v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+                }
+                *reinterpret_cast<u32x4*>(ob + ((size_t)oy * a.OW + ox) * a.C0 + cq * V) = Chunk<T>::pack(v);
+            }
+        }
+    }
+}
+
 // [C,1,K,K] (PyTorch depthwise) -> [K*K][C]
 __global__ void pack_dw_kxk_kernel(const float* __restrict__ w, int c, int kk, float* __restrict__ o) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1250,6 +1362,20 @@ int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, co
     }
 #undef ADAF_GP
     return best;
+}
+
+// returns false when the shape is not the one the stem kernel is written for (C0 <= 64, chunks of whole 16 bytes)
+bool adaf_launch_ef_stem(const float* x4, int dtype, int n, int size, int oh, int ow, int pad, const float* w, const float* scale,
+                         const float* bias, int c0, int act, void* out, hipStream_t s) {
+    const int v = dtype == ADAF_DTYPE_F16 ? 8 : 4;
+    if (c0 > 64 || c0 % v) return false;
+    StemArgs a;
+    a.x4 = x4; a.w = w; a.scale = scale; a.bias = bias; a.out = out; a.n = n; a.S = size; a.OH = oh; a.OW = ow; a.C0 = c0; a.pad = pad; a.act = act;
+    a.tiles_x = (ow + 15) / 16; a.tiles_y = (oh + 7) / 8;
+    const dim3 grid((unsigned)((size_t)n * a.tiles_y)), block(256);
+    if (dtype == ADAF_DTYPE_F16) hipLaunchKernelGGL((ef_stem_kernel<_Float16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((ef_stem_kernel<float>), grid, block, 0, s, a);
+    return true;
 }
 
 void adaf_launch_pack_dw_kxk(const float* w, int c, int k, float* o, hipStream_t s) {
@@ -1587,7 +1713,10 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
         char* cur = bufA;
         char* nxt = bufB;
         const EfConv& S = net->convs[net->stem];
-        if ((rc = run_dense(net, S, frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size, hw, hw, pb0, ADAF_ACT_SWISH, cur, f16, st)))
+        static const int own_stem = [] { const char* e = getenv("ADAF_EF_STEM"); return e ? atoi(e) : 1; }();   // 0 = the generic engine (A/B)
+        if (!(own_stem && adaf_launch_ef_stem(frames_nhwc4 + (size_t)f0 * size * size * 4, net->dtype, nc, size, hw, hw, pb0, S.w, S.scale, S.bias,
+                                              S.cout, ADAF_ACT_SWISH, cur, st)) &&
+            (rc = run_dense(net, S, frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size, hw, hw, pb0, ADAF_ACT_SWISH, cur, f16, st)))
             return efail(h, rc, "effnet: stem launch");
         size_t out_elems = (size_t)hw * hw * S.cout;
         for (size_t bi = 0; bi < net->blocks.size(); ++bi) {
