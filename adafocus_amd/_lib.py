@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libadafocus_hip.so")
+# (ADAF_LIB points at another build of the same library: A/B runs of two kernel versions on one box)
+LIB_PATH = os.environ.get("ADAF_LIB") or os.path.join(_HERE, "csrc", "libadafocus_hip.so")
 
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC4 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3, 4

@@ -74,79 +74,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-// ---- the tap loop and the output epilogue of a thread item, as functions -----------------------------------------------------
-// (used by the two opt-in kernels -- the pipelined and the fused form; the default dw_same_kernel keeps the same code written out
-// in place: routed through these functions it measured 2.5 % slower on the fp16 network, 11.5 vs 11.2 ms, from different
-// register allocation around the inlined bodies)
-// One thread item = OXT horizontally adjacent outputs x V channels.  `rowp` points at the item's first staged input pixel (its
-// 16-byte chunk), rows are `rowstride` bytes apart, pixels `pitchB`; `wl` holds the slice's taps [K*K][CS] in LDS, `wofs` = the
-// thread's first channel inside the slice.  Per filter row the K taps sit in registers and every staged column is read and
-// converted ONCE: column ci feeds output o through tap kx = ci - o S, resolved at compile time.
-template <int K, int S, int OXT, typename T>
-__device__ __forceinline__ void dw_taps(const char* rowp, int rowstride, int pitchB, const float* wl, int CS, int wofs,
-                                        float (&acc)[OXT][Chunk<T>::V]) {
-    constexpr int V = Chunk<T>::V;
-    constexpr int NC = (OXT - 1) * S + K;
-#pragma unroll
-    for (int o = 0; o < OXT; ++o)
-#pragma unroll
-        for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
-#pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {
-        float w[K][V];
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const float* wp = wl + (ky * K + kx) * CS + wofs;
-#pragma unroll
-            for (int e = 0; e < V; e += 4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
-                w[kx][e] = w4.x; w[kx][e + 1] = w4.y; w[kx][e + 2] = w4.z; w[kx][e + 3] = w4.w;
-            }
-        }
-#pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-            float xf[V];
-            Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * pitchB), xf);
-#pragma unroll
-            for (int o = 0; o < OXT; ++o) {
-                const int kx = ci - o * S;
-                if (kx >= 0 && kx < K) {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], w[kx][e], acc[o][e]);
-                }
-            }
-        }
-        rowp += rowstride;
-    }
-}
-
-// BN affine (scale at sbl[wofs..], bias at sbl[CS + wofs..]) + activation, the squeeze partial sums, 16-byte stores of the
-// item's outputs that exist (`nvalid` of OXT), `ostep` elements apart.
-template <int OXT, typename T>
-__device__ __forceinline__ void dw_emit(float (&acc)[OXT][Chunk<T>::V], const float* sbl, int CS, int wofs, int act, int nvalid, T* op,
-                                        int ostep, float (&psum)[Chunk<T>::V]) {
-    constexpr int V = Chunk<T>::V;
-    float sc[V], bi[V];
-#pragma unroll
-    for (int e = 0; e < V; e += 4) {
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + wofs + e), b4 = *reinterpret_cast<const f32x4*>(sbl + CS + wofs + e);
-        sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
-        bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
-    }
-#pragma unroll
-    for (int o = 0; o < OXT; ++o) {
-        if (o < nvalid) {
-            float v[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), act);
-                psum[e] += v[e];
-            }
-            *reinterpret_cast<u32x4*>(op + o * ostep) = Chunk<T>::pack(v);
-        }
-    }
-}
-
 // ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
 // A block owns IMB images x one channel slice (CS = LPP 16-byte chunks) x TH output rows.  Its input rows (with the padding
 // columns, zero-filled) are staged once in LDS; then thread (image, channel chunk cg, pixel-group lane pg) walks the
@@ -357,6 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
 template <int K, int S, int OXT, typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void dw_same_pipe_kernel(const DwArgs a) {
     constexpr int V = Chunk<T>::V;
+    constexpr int NC = (OXT - 1) * S + K;
     constexpr int WFL = (K * K + 2);         // weight rows per slice: taps + BN scale + BN bias
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -444,8 +372,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             while (r < th) {
                 const int ox0 = (xg0 + xg) * OXT;
                 float acc[OXT][V];
-                dw_taps<K, S, OXT, T>(xim + (r * S * a.WP + xg * OXT * S) * pitchB, a.WP * pitchB, pitchB, wl, a.CS, cg * V, acc);
-                dw_emit<OXT, T>(acc, sbl, a.CS, cg * V, a.act, a.OW - ox0, ob + (r * a.OW + ox0) * a.C, a.C, psum);
+#pragma unroll
+                for (int o = 0; o < OXT; ++o)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+                for (int ky = 0; ky < K; ++ky) {
+                    const char* rowp = xim + ((size_t)(r * S + ky) * a.WP + xg * OXT * S) * pitchB;
+                    float wv[K][V];
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const float* wp = wl + (ky * K + kx) * a.CS + cg * V;
+#pragma unroll
+                        for (int e = 0; e < V; e += 4) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
+                            wv[kx][e] = w4.x; wv[kx][e + 1] = w4.y; wv[kx][e + 2] = w4.z; wv[kx][e + 3] = w4.w;
+                        }
+                    }
+#pragma unroll
+                    for (int ci = 0; ci < NC; ++ci) {
+                        float xf[V];
+                        Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * pitchB), xf);
+#pragma unroll
+                        for (int o = 0; o < OXT; ++o) {
+                            const int kx = ci - o * S;
+                            if (kx >= 0 && kx < K) {
+#pragma unroll
+                                for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], wv[kx][e], acc[o][e]);
+                            }
+                        }
+                    }
+                }
+                float sc[V], bi[V];
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + cg * V + e), b4 = *reinterpret_cast<const f32x4*>(sbl + a.CS + cg * V + e);
+                    sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
+                    bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
+                }
+#pragma unroll
+                for (int o = 0; o < OXT; ++o) {
+                    if (ox0 + o < a.OW) {
+                        float v[V];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
+                            psum[e] += v[e];
+                        }
+                        *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.C) = Chunk<T>::pack(v);
+                    }
+                }
                 xg += dxg; r += dr;
                 if (xg >= nxg) { xg -= nxg; ++r; }
             }
@@ -499,6 +475,7 @@ struct EfFuseArgs {
 template <int K, int S, int OXT, typename T, int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 : 4, 8))) void ef_expand_dw_kernel(const EfFuseArgs a) {
     constexpr int V = Chunk<T>::V;
+    constexpr int NC = (OXT - 1) * S + K;
     constexpr int HS = 32 * TN, LPP = HS / V;
     constexpr int KSTEP = sizeof(T) == 2 ? 16 : 8;        // k elements per 16-byte-per-lane step
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -619,8 +596,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             const int r = g / nxg, xg = g - r * nxg;
             const int ox0 = (xg0 + xg) * OXT;
             float acc[OXT][V];
-            dw_taps<K, S, OXT, T>(xim + (r * S * a.NPW + xg * OXT * S) * epitch, a.NPW * epitch, epitch, wl, HS, cg * V, acc);
-            dw_emit<OXT, T>(acc, sbl, HS, cg * V, a.act, a.OW - ox0, ob + (r * a.OW + ox0) * a.hid, a.hid, psum);
+#pragma unroll
+            for (int o = 0; o < OXT; ++o)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                const char* rowp = xim + ((size_t)(r * S + ky) * a.NPW + xg * OXT * S) * epitch;
+                float wv[K][V];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* wp = wl + (ky * K + kx) * HS + cg * V;
+#pragma unroll
+                    for (int e = 0; e < V; e += 4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
+                        wv[kx][e] = w4.x; wv[kx][e + 1] = w4.y; wv[kx][e + 2] = w4.z; wv[kx][e + 3] = w4.w;
+                    }
+                }
+#pragma unroll
+                for (int ci = 0; ci < NC; ++ci) {
+                    float xf[V];
+                    Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * epitch), xf);
+#pragma unroll
+                    for (int o = 0; o < OXT; ++o) {
+                        const int kx = ci - o * S;
+                        if (kx >= 0 && kx < K) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], wv[kx][e], acc[o][e]);
+                        }
+                    }
+                }
+            }
+            float sc[V], bi[V];
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + cg * V + e), b4 = *reinterpret_cast<const f32x4*>(sbl + HS + cg * V + e);
+                sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
+                bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
+            }
+#pragma unroll
+            for (int o = 0; o < OXT; ++o) {
+                if (ox0 + o < a.OW) {
+                    float v[V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
+                        psum[e] += v[e];
+                    }
+                    *reinterpret_cast<u32x4*>(ob + ((size_t)r * a.OW + ox0 + o) * a.hid) = Chunk<T>::pack(v);
+                }
+            }
         }
     }
     if (a.pool_part) {
