@@ -653,8 +653,8 @@ __global__ void pool_finish_kernel(const float* __restrict__ part, int n, int ti
 // A block owns G images, so every weight it fetches from L2 is used G times (one image per block moved 1.8 GB of filter
 // rows per launch at C = 2304); the two small matrix products run as wave-shuffle dot products / per-channel sums in a fixed
 // order.  part [n][tiles][C] partial sums (tiles = 1, inv_hw = 1 for a ready-made mean).
-template <int G>
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int tiles, float inv_hw, int n, int C,
+template <int G, int NT>
+__global__ __launch_bounds__(NT) void se_gate_kernel(const float* __restrict__ part, int tiles, float inv_hw, int n, int C,
                                                       const float* __restrict__ wr, const float* __restrict__ br, int SQ,
                                                       const float* __restrict__ we, int we_ldc, int we_ldj,
                                                       const float* __restrict__ be, float* __restrict__ gate) {
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     const int C4 = C >> 2;
 #pragma unroll
     for (int g = 0; g < G; ++g)
-        for (int c4 = tid; c4 < C4; c4 += 256) {
+        for (int c4 = tid; c4 < C4; c4 += NT) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             if (g < ng) {
                 const float* p = part + (size_t)(img0 + g) * tiles * C + 4 * c4;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
             *reinterpret_cast<f32x4*>(mean + g * C + 4 * c4) = s * inv_hw;
         }
     __syncthreads();
-    for (int j = wave; j < SQ; j += 4) {
+    for (int j = wave; j < SQ; j += NT / 64) {
         const float* w = wr + (size_t)j * C;
         float s[G];
 #pragma unroll
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     __syncthreads();
     if (we_ldc == 1) {
         // transposed expand filter [SQ][C] (the network's layout): a thread owns 4 consecutive channels
-        for (int c4 = tid; c4 < C4; c4 += 256) {
+        for (int c4 = tid; c4 < C4; c4 += NT) {
             f32x4 s[G];
             const f32x4 b = *reinterpret_cast<const f32x4*>(be + 4 * c4);
 #pragma unroll
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
         }
         return;
     }
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
         float s[G];
         const float b = be[c];
 #pragma unroll
@@ -1309,9 +1309,16 @@ void adaf_launch_pool_finish(const float* part, int n, int tiles, int c, int hw,
 
 void adaf_launch_se_gate(const float* part, int tiles, int hw, int n, int c, const float* wr, const float* br, int sq,
                          const float* we, int we_ldc, int we_ldj, const float* be, float* gate, hipStream_t s) {
+    // one block per G images is one block per CU at n = 1024: the squeeze FC is a chain of L2 round trips per wave (SQ / waves filter
+    // rows of C floats each), so the wide layers (C >= 512: SQ = 24..96) run 16 waves per block instead of 4
     constexpr int G = 4;
-    hipLaunchKernelGGL((se_gate_kernel<G>), dim3((unsigned)((n + G - 1) / G)), dim3(256), (size_t)G * (c + sq) * 4, s, part, tiles,
-                       1.f / (float)hw, n, c, wr, br, sq, we, we_ldc, we_ldj, be, gate);
+    static const int wide = [] { const char* e = getenv("ADAF_SE_WIDE"); return e ? atoi(e) : 512; }();
+    if (c >= wide)
+        hipLaunchKernelGGL((se_gate_kernel<G, 1024>), dim3((unsigned)((n + G - 1) / G)), dim3(1024), (size_t)G * (c + sq) * 4, s, part, tiles,
+                           1.f / (float)hw, n, c, wr, br, sq, we, we_ldc, we_ldj, be, gate);
+    else
+        hipLaunchKernelGGL((se_gate_kernel<G, 256>), dim3((unsigned)((n + G - 1) / G)), dim3(256), (size_t)G * (c + sq) * 4, s, part, tiles,
+                           1.f / (float)hw, n, c, wr, br, sq, we, we_ldc, we_ldj, be, gate);
 }
 
 int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, const float* gate, const void* w, int n,
@@ -1702,7 +1709,8 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             const int ohw = conv_out_len(hw, b.k, b.stride, tot);
             const EfConv& D = net->convs[b.dwc];
             int tiles = -1;
-            if (b.expand >= 0 && net->fuse && hw >= 16) {
+            static const unsigned fuse_mask = [] { const char* e = getenv("ADAF_EF_FUSE_MASK"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();   // per-block A/B
+            if (b.expand >= 0 && (net->fuse || ((fuse_mask >> bi) & 1u)) && hw >= 16) {
                 // narrow input, wide hidden map: expand -> depthwise in one launch, the expanded map stays in LDS
                 const EfConv& E = net->convs[b.expand];
                 tiles = adaf_launch_ef_expand_dw(cur, net->dtype, nc, hw, hw, b.cin, f16 ? E.w16 : static_cast<const void*>(E.w), E.scale, E.bias,
