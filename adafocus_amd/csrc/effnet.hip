@@ -638,6 +638,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     }
 }
 
+// ---- expand 1x1 (+BN+activation) for narrow inputs (cin <= 64: blocks 2..8 of B3) ------------------------------------------
+// A GEMM with K = 24..48 and N = 6 K is all epilogue: on the conv engine a 128 x 32 tile issues one DMA slice, waits out its
+// latency, runs two MFMAs per wave and then spends its life in the epilogue -- 0.9 ms for block 2's expand (1.5 GB of fp16 output,
+// 2 TB/s), with no wasted traffic (WRITE_SIZE = the algorithmic bytes).  Here the filter (all N rows, k padded to a whole MFMA
+// step) and the BN affine live in LDS for the lifetime of a PERSISTENT block, every wave walks its own 32-row strips with no block
+// barrier after the staging, the A fragments of strip i+1 are in flight (plain 16-byte global loads into registers: the fragment
+// of a lane is contiguous in memory) while strip i is multiplied, and a strip's outputs leave through a wave-private slab as
+// 16-byte pieces of 64 consecutive channels.  Same MFMA instruction and k order as the engine's launch: bit-identical.
+struct ExpArgs {
+    const void* x;        // [M][K]
+    const void* w;        // [N][K] (storage type)
+    const float* scale;   // [N]
+    const float* bias;
+    void* out;            // [M][N]
+    int M, K, N, act;
+    int KP;               // K padded to a whole MFMA k step (elements)
+    int NP;               // N padded to 32
+    int strips;           // ceil(M / 32)
+};
+
+// WHOLE: a row of the output is not a whole number of 128-byte lines (N = 144 or 288 halfs): 128-byte pieces would straddle lines and
+// HBM sees twice as many partial-line writes (measured: block 2 at 2.5 TB/s of stores against 4.4 for the aligned N = 192).  The
+// wave then keeps its whole strip (32 rows x N: one contiguous, line-aligned range of the output) in its slab and copies it out
+// linearly, 1 KB per store instruction.
+template <typename T, int KS, bool WHOLE>
+__global__ __launch_bounds__(1024) void ef_expand_kernel(const ExpArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int KSTEP = 2 * V;                          // k elements per MFMA step group (16 bytes per lane, two lane halves)
+    const int SROW = (WHOLE ? a.NP : 64) * (int)sizeof(T) + 16;   // slab row: 64 channels (WHOLE: all of them) + a 16-byte skew
+    constexpr int CPR = 64 / V;                           // 16-byte pieces per 64-channel slab row
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int wpitch = a.KP * (int)sizeof(T) + 16;
+    char* wl = dsm;                                                          // [NP][wpitch]
+    float* sb = reinterpret_cast<float*>(wl + (size_t)a.NP * wpitch);      // [2][NP]
+    char* slab = reinterpret_cast<char*>(sb + 2 * a.NP) + (size_t)wave * 32 * SROW;
+    {
+        const int CPP = wpitch / 16 - 1, kchunks = a.K / V;
+        const T* wb = static_cast<const T*>(a.w);
+        for (int i = tid; i < a.NP * CPP; i += blockDim.x) {
+            const int h = i / CPP, c = i - h * CPP;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (h < a.N && c < kchunks) v = *reinterpret_cast<const u32x4*>(wb + (size_t)h * a.K + c * V);
+            *reinterpret_cast<u32x4*>(wl + (size_t)h * wpitch + c * 16) = v;
+        }
+        for (int i = tid; i < 2 * a.NP; i += blockDim.x) {
+            const int which = i / a.NP, h = i - which * a.NP;
+            sb[i] = h < a.N ? (which ? a.bias[h] : a.scale[h]) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nl = lane & 31, half = lane >> 5;
+    const T* xb = static_cast<const T*>(a.x);
+    const int stride = gridDim.x * nwaves;
+    int strip = blockIdx.x * nwaves + wave;
+    auto load = [&](int st, u32x4 (&f)[KS]) {
+        const long long row = (long long)st * 32 + nl;
+        const bool ok = st < a.strips && row < a.M;
+        const T* src = xb + (size_t)(ok ? row : 0) * a.K + half * V;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            f[kk] = (ok && kk * KSTEP + half * V < a.K) ? *reinterpret_cast<const u32x4*>(src + kk * KSTEP) : u32x4{0u, 0u, 0u, 0u};
+    };
+    u32x4 af[KS], an[KS];
+    load(strip, af);
+    const int npairs = (a.NP + 63) >> 6;
+    const int c = lane % CPR, rsub = lane / CPR;
+    for (; strip < a.strips; strip += stride) {
+        load(strip + stride, an);
+        const long long m0 = (long long)strip * 32;
+        for (int cp = 0; cp < npairs; ++cp) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n0 = cp * 64 + j * 32;
+                if (n0 < a.NP) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                    const char* brow = wl + (size_t)(n0 + nl) * wpitch + half * 16;
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) {
+                        const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + kk * 32);
+                        if constexpr (sizeof(T) == 2) {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kk]), __builtin_bit_cast(f16x8, bf), acc, 0, 0, 0);
+                        } else {
+                            const f32x4 a4 = __builtin_bit_cast(f32x4, af[kk]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bf.x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bf.y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bf.z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bf.w, acc, 0, 0, 0);
+                        }
+                    }
+                    const float sc = sb[n0 + nl], bi = sb[a.NP + n0 + nl];
+                    char* srow = slab + (size_t)((WHOLE ? n0 : j * 32) + nl) * sizeof(T);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int p = (i & 3) + 8 * (i >> 2) + 4 * half;
+                        *reinterpret_cast<T*>(srow + p * SROW) = (T)act_apply(fmaf(acc[i], sc, bi), a.act);
+                    }
+                }
+            }
+            if (!WHOLE) {
+                __builtin_amdgcn_wave_barrier();
+                const int col = cp * 64 + c * V;
+                if (col < a.N) {
+                    T* ob = static_cast<T*>(a.out) + col;
+#pragma unroll
+                    for (int r = rsub; r < 32; r += 64 / CPR) {
+                        if (m0 + r < a.M)
+                            *reinterpret_cast<u32x4*>(ob + (size_t)(m0 + r) * a.N) = *reinterpret_cast<const u32x4*>(slab + r * SROW + c * 16);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (WHOLE) {
+            // the strip is one contiguous range of the output: piece q = (row q / PPR, chunk q % PPR), lane q = lane, lane + 64, ...
+            __builtin_amdgcn_wave_barrier();
+            const int PPR = a.N / V;
+            const int rows = (int)min((long long)32, a.M - m0);
+            const int total = rows * PPR;
+            const int dr = 64 / PPR, dc = 64 - dr * PPR;
+            int r = lane / PPR, cc = lane - r * PPR;
+            T* ob = static_cast<T*>(a.out) + (size_t)m0 * a.N;
+            for (int q = lane; q < total; q += 64) {
+                *reinterpret_cast<u32x4*>(ob + (size_t)q * V) = *reinterpret_cast<const u32x4*>(slab + r * SROW + cc * 16);
+                r += dr; cc += dc;
+                if (cc >= PPR) { cc -= PPR; ++r; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) af[kk] = an[kk];
+    }
+}
+
 // mean[n][c] = sum_t part[n][t][c] / hw  (the stand-alone op's squeeze output)
 __global__ void pool_finish_kernel(const float* __restrict__ part, int n, int tiles, int c, float inv_hw, float* __restrict__ mean) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1302,6 +1439,51 @@ int adaf_launch_ef_expand_dw(const void* x, int dtype, int n, int hh, int ww, in
     return ok ? p.tiles : -1;
 }
 
+// expand 1x1 with K <= 64 on the persistent strip kernel; false = not eligible (the caller falls back to the conv engine)
+template <typename T, bool WHOLE>
+static bool launch_ef_expand_t(const ExpArgs& a, int blocks, int waves, size_t lds, hipStream_t s) {
+    const int ks = a.KP / (2 * Chunk<T>::V);
+#define ADAF_EXP(KS_) case KS_: \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ef_expand_kernel<T, KS_, WHOLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((ef_expand_kernel<T, KS_, WHOLE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), lds, s, a); return true;
+    switch (ks) {
+        ADAF_EXP(1) ADAF_EXP(2) ADAF_EXP(3) ADAF_EXP(4) ADAF_EXP(5) ADAF_EXP(6) ADAF_EXP(7) ADAF_EXP(8)
+        default: return false;
+    }
+#undef ADAF_EXP
+}
+
+bool adaf_launch_ef_expand(const void* x, int dtype, long long m, int k, const void* w, const float* scale, const float* bias, int n, int act,
+                           void* out, int cus, hipStream_t s) {
+    const bool f16 = dtype == ADAF_DTYPE_F16;
+    const int v = f16 ? 8 : 4, es = f16 ? 2 : 4;
+    if (k > 64 || k % v || n % v || m <= 0 || m > (1ll << 31) - 64) return false;
+    ExpArgs a;
+    a.x = x; a.w = w; a.scale = scale; a.bias = bias; a.out = out; a.M = (int)m; a.K = k; a.N = n; a.act = act;
+    a.KP = (k + 2 * v - 1) / (2 * v) * (2 * v);
+    a.NP = (n + 31) / 32 * 32;
+    a.strips = (int)((m + 31) / 32);
+    static const int whole_pol = [] { const char* e = getenv("ADAF_EF_EXPAND_WHOLE"); return e ? atoi(e) : -1; }();   // -1 auto, 0 never, 1 always (A/B)
+    const bool whole = whole_pol < 0 ? (f16 && ((size_t)n * es) % 128 != 0) : whole_pol != 0;   // (fp32 rows: measured no better)
+    const size_t fixed = (size_t)a.NP * (a.KP * es + 16) + (size_t)2 * a.NP * 4;
+    const size_t slab = (size_t)32 * ((whole ? a.NP : 64) * es + 16);
+    // waves per block / blocks per CU: the most resident waves the LDS allows (each block carries its own copy of the filter)
+    int waves = 0, per_cu = 0;
+    for (int w = 2; w <= 16; ++w) {
+        const size_t need = fixed + w * slab;
+        if (need > 150 * 1024) break;
+        int b = (int)((160 * 1024) / need);
+        if (b * w > 32) b = 32 / w;
+        if (b >= 1 && b * w > waves * per_cu) { waves = w; per_cu = b; }
+    }
+    if (!waves) return false;
+    const size_t lds = fixed + waves * slab;
+    int blocks = cus * per_cu;
+    if ((long long)blocks * waves > a.strips) blocks = (a.strips + waves - 1) / waves;
+    if (f16) return whole ? launch_ef_expand_t<_Float16, true>(a, blocks, waves, lds, s) : launch_ef_expand_t<_Float16, false>(a, blocks, waves, lds, s);
+    return whole ? launch_ef_expand_t<float, true>(a, blocks, waves, lds, s) : launch_ef_expand_t<float, false>(a, blocks, waves, lds, s);
+}
+
 void adaf_launch_pool_finish(const float* part, int n, int tiles, int c, int hw, float* mean, hipStream_t s) {
     hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)(((size_t)n * c + 255) / 256)), dim3(256), 0, s, part, n, tiles, c,
                        1.f / (float)hw, mean);
@@ -1720,7 +1902,11 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
                 if (b.expand >= 0) {
                     // (the expand GEMM stays on the conv engine: routed through gated_project_kernel -- 128 x 128 tiles, swish in its
                     // 16-byte epilogue -- the fp16 network measured 12.6 instead of 11.5 ms)
-                    if ((rc = run_dense(net, net->convs[b.expand], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, bufE, f16, st)))
+                    const EfConv& E = net->convs[b.expand];
+                    static const int own_expand = [] { const char* e = getenv("ADAF_EF_EXPAND"); return e ? atoi(e) : 1; }();   // 0 = the conv engine for every expand (A/B)
+                    if (!(own_expand && adaf_launch_ef_expand(cur, net->dtype, (long long)nc * hw * hw, b.cin, f16 ? E.w16 : static_cast<const void*>(E.w),
+                                                              E.scale, E.bias, b.hid, ADAF_ACT_SWISH, bufE, net->h->cus, st)) &&
+                        (rc = run_dense(net, E, cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, bufE, f16, st)))
                         return efail(h, rc, "effnet: expand launch (block %zu)", bi);
                     dw_in = bufE;
                 }
