@@ -109,6 +109,7 @@ hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, co
 // conv_gemm.hip
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0
 int adaf_pick_conv_tile(int M, int N, int K, int cus);
+int adaf_launch_conv_lat(const ConvArgs& a, hipStream_t s);   // conv_lat.hip: small-batch form (tile id 95), 1 = launched, 0 = not eligible
 bool adaf_conv_tile_exists(int tile);   // is `tile` an id adaf_launch_conv_gemm has a kernel for
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
 // conv2 3x3 (64 -> 64) -> conv3 1x1 (+ identity, ReLU) [-> the next block's conv1 1x1] in one launch (stage 1 of the trunk);

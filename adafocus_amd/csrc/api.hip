@@ -257,7 +257,7 @@ int adaf_conv2d_bn_act_f32(adaf_handle* h, const adaf_conv_params* p, const floa
     ConvArgs a;
     int rc = make_conv_args(h, p, x, w_ohwi, scale, bias, residual, out, &a);
     if (rc) return rc;
-    if (p->tile < 0 || p->tile > 80 || (p->tile && !adaf_conv_tile_exists(p->tile)))
+    if (p->tile < 0 || (p->tile > 80 && p->tile != 95) || (p->tile && !adaf_conv_tile_exists(p->tile)))
         return fail(h, ADAF_E_BADARG, "conv: no kernel variant with tile id %d", p->tile);
     if (adaf_launch_conv_gemm(a, p->tile, h->cus, (hipStream_t)stream) < 0) return fail(h, ADAF_E_LAUNCH, "conv: no tile");
     hipError_t e = hipGetLastError();
@@ -470,6 +470,12 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     const size_t need = adaf_resnet50_workspace_bytes(net, n, P);
     if (ws_bytes < need) return fail(h, ADAF_E_NOMEM, "resnet50: workspace %zu < %zu bytes", ws_bytes, need);
 
+    // Small problems (BASELINE config 1: B*T = 16 patches -> 576 / 144 output pixels in stages 3 / 4): a conv whose GEMM has at most
+    // `lat_rows` rows is as long as ONE accumulator chain on the engine, and runs on the latency form instead (conv_lat.hip:
+    // v_mfma_f32_16x16x4_f32 chains, 3.2x shorter and bit-identical).  ADAF_LATENCY_ROWS: the row limit (0 = never).
+    static const int lat_rows = [] { const char* e = getenv("ADAF_LATENCY_ROWS"); return e ? atoi(e) : 1536; }();
+    const bool lat_ok = lat_rows > 0 && tsm_T == 0 && net->math == ADAF_MATH_F32;
+    const bool fuse = net->fuse;
     const size_t slab = adaf_resnet50_workspace_bytes(net, n, P) / (5 * sizeof(float));  // largest activation, floats
     float* buf[5];
     for (int i = 0; i < 5; ++i) buf[i] = static_cast<float*>(ws) + i * slab;
@@ -496,7 +502,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         const double macs = (double)a.M * L.cout * L.k * L.k * L.cin;   // algorithmic: un-padded cin
         const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
         mark(2.0 * macs, bytes, 0);
-        const int used = adaf_launch_conv_gemm(a, p.tile, h->cus, st);
+        const int used = adaf_launch_conv_gemm(a, (lat_ok && a.M <= lat_rows && li > 0 && !net->tiles[li]) ? 95 : p.tile, h->cus, st);
         if (used < 0) return fail(h, ADAF_E_LAUNCH, "resnet50: no kernel for tile id %d (conv launch %d)", p.tile, li);
         if (info && !info->empty()) info->back().tile = used;
         *oh = a.OH; *ow = a.OW;
@@ -539,7 +545,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             const int i_next = li + 3 + (b == 0 ? 1 : 0);          // the next block's conv1 (or convs.size())
             // conv1 (1x1, optional fused temporal shift) -> conv2 (3x3, stride) -> conv3 (1x1) + identity
             bool ds_done = false;
-            if (s == 0 && b == 0 && !c1_done && net->fuse && net->l10_w && tsm_T == 0 && net->math == ADAF_MATH_F32 &&
+            if (s == 0 && b == 0 && !c1_done && fuse && net->l10_w && tsm_T == 0 && net->math == ADAF_MATH_F32 &&
                 !net->tiles[li] && !net->tiles[i_ds]) {
                 // layer1.0: conv1 and the downsample conv in ONE launch (same input, same 1x1 geometry; N = 64 + 256): the
                 // pooled map is read once instead of twice and a 0.07 ms launch disappears.  128x64 tiles: column tile 0 is conv1.
@@ -575,7 +581,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             }
             li = i_c2;
             const ConvLayer& L2 = net->convs[i_c2];
-            const bool fusable = net->fuse && net->math == ADAF_MATH_F32 && L2.cin == 64 && L2.cout == 64 && L2.stride == 1 &&
+            const bool fusable = fuse && net->math == ADAF_MATH_F32 && L2.cin == 64 && L2.cout == 64 && L2.stride == 1 &&
                                  !net->tiles[i_c2] && !net->tiles[i_c3];
             if (fusable) {
                 const ConvLayer& L3 = net->convs[i_c3];

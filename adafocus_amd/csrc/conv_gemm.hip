@@ -1640,6 +1640,7 @@ bool adaf_conv_tile_exists(int tile) {
         case 61: case 62: case 63: case 64: case 65: case 66: case 67:
         case 71: case 72: case 73: case 74:
         case 81: case 82: case 83: case 84: case 88:      // fp16 operands (adaf_conv2d_bn_act_f16 only)
+        case 95:                                          // small-batch form on v_mfma_f32_16x16x4_f32 (conv_lat.hip)
             return true;
         default:
             return false;
@@ -1683,6 +1684,7 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 2, 2, 32, false, 0, 1>), dim3(b.nblocks), dim3(256), 0, s, b);
         return 2;
     }
+    if (tile == 95) return adaf_launch_conv_lat(a, s) ? 95 : -1;     // the small-batch form (conv_lat.hip; bit-identical)
     const bool bsp_ok = a.wsp != nullptr && (a.K & 31) == 0 && adaf_conv_glds_ok(a);
     if (tile == 40) {   // split tiles, automatic: the bigger the wave tile the fewer split instructions per product
         tile = 0;
