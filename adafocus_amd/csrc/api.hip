@@ -421,6 +421,7 @@ struct adaf_resnet50 {
     int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
     bool fuse = true;              // stage 1: conv2 -> conv3 (-> next conv1) in one launch; stem + max-pool in one launch
     bool fuse_stem_always = false; // (tests) take the fused stem launch at every patch size, not only where it is faster
+    int lat_rows = -1;             // convs with at most this many GEMM rows take the small-batch form (-1 = ADAF_LATENCY_ROWS / 1536)
     float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
     bool finalized = false;
 };
@@ -473,7 +474,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     // Small problems (BASELINE config 1: B*T = 16 patches -> 576 / 144 output pixels in stages 3 / 4): a conv whose GEMM has at most
     // `lat_rows` rows is as long as ONE accumulator chain on the engine, and runs on the latency form instead (conv_lat.hip:
     // v_mfma_f32_16x16x4_f32 chains, 3.2x shorter and bit-identical).  ADAF_LATENCY_ROWS: the row limit (0 = never).
-    static const int lat_rows = [] { const char* e = getenv("ADAF_LATENCY_ROWS"); return e ? atoi(e) : 1536; }();
+    static const int lat_rows_env = [] { const char* e = getenv("ADAF_LATENCY_ROWS"); return e ? atoi(e) : 1536; }();
+    const int lat_rows = net->lat_rows >= 0 ? net->lat_rows : lat_rows_env;
     const bool lat_ok = lat_rows > 0 && tsm_T == 0 && net->math == ADAF_MATH_F32;
     const bool fuse = net->fuse;
     const size_t slab = adaf_resnet50_workspace_bytes(net, n, P) / (5 * sizeof(float));  // largest activation, floats
@@ -791,6 +793,12 @@ int adaf_resnet50_set_fusion(adaf_resnet50* net, int on) {
     if (!net) return ADAF_E_BADARG;
     net->fuse = on != 0;
     net->fuse_stem_always = on == 2;
+    return ADAF_OK;
+}
+
+int adaf_resnet50_set_latency_rows(adaf_resnet50* net, int rows) {
+    if (!net) return ADAF_E_BADARG;
+    net->lat_rows = rows;          // < 0: back to the default
     return ADAF_OK;
 }
 

@@ -300,6 +300,10 @@ class ResNet50Trunk:
         """Stage-1 conv2 -> conv3 (-> next conv1) and stem + max-pool as single launches (default on; bit-identical)."""
         L.check(self._lib.adaf_resnet50_set_fusion(self._net, int(on)), self._h)   # 2 = also the fused stem where it does not pay (tests)
 
+    def set_latency_rows(self, rows):
+        """Convs whose GEMM has at most `rows` rows take the small-batch form (conv_lat.hip; bit-identical); 0 = never, < 0 = default."""
+        L.check(self._lib.adaf_resnet50_set_latency_rows(self._net, int(rows)), self._h)
+
     def set_tiles(self, tiles):
         arr = (C.c_int * len(tiles))(*tiles)
         L.check(self._lib.adaf_resnet50_set_tiles(self._net, arr, len(tiles)), self._h)

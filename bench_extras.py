@@ -232,9 +232,27 @@ def latency_rows(dev, cases=((1, 8), (2, 8), (2, 16)), p=96, iters=200):
                 g.replay()
             torch.cuda.synchronize()
             graph = (time.perf_counter() - t0) / iters
+            # the same step with every conv on the engine's batched tiles (the round-2 plan): what the small-batch form buys
+            trunk = m.focuser.net._sync()
+            trunk.set_latency_rows(0)
+            for _ in range(5):
+                lg = m.hot_path(fr, gv, act, b, t)[0]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                lg = m.hot_path(fr, gv, act, b, t)[0]
+            torch.cuda.synchronize()
+            batched = (time.perf_counter() - t0) / iters
+            same_bits = bool(torch.equal(lg, ref))
+            trunk.set_latency_rows(-1)
         rows["B%d_T%d_P%d" % (b, t, p)] = {"eager_ms": round(eager * 1e3, 4), "graph_ms": round(graph * 1e3, 4),
-                                            "clips_per_s": round(b / min(eager, graph), 1), "graph_bit_identical_to_eager": same}
+                                            "clips_per_s": round(b / min(eager, graph), 1), "graph_bit_identical_to_eager": same,
+                                            "batched_tiles_only_ms": round(batched * 1e3, 4),
+                                            "speedup_over_batched_tiles": round(batched / min(eager, graph), 3),
+                                            "bit_identical_to_batched_tiles": same_bits}
         del g, m
     rows["note"] = ("one hot-path step (gather + ResNet-50 + GRU classifier) per call, back to back, %d calls; eager = Python-issued "
-                    "launches, graph = GFV.capture_hot_path replay" % iters)
+                    "launches, graph = GFV.capture_hot_path replay; convs with <= 1536 GEMM rows run on the small-batch form "
+                    "(csrc/conv_lat.hip: v_mfma_f32_16x16x4_f32 chains in the engine's k order), batched_tiles_only_ms = the same step "
+                    "with that switched off (adaf_resnet50_set_latency_rows(net, 0))" % iters)
     return rows

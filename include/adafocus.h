@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ADAF_VERSION 300
+#define ADAF_VERSION 301
 
 enum {
     ADAF_OK = 0,
@@ -152,7 +152,11 @@ typedef struct adaf_conv_params {
                            40 = choose automatically among the split tiles, 41..47 / 51..54 = split tiles: fp32
                            operands decomposed into three bf16 parts after the LDS read and multiplied on the bf16
                            matrix pipe with 6 (4x) or 9 (5x) products per element pair, fp32 accumulate
-                           (see ADAF_MATH_F32_SPLIT_BF16) */
+                           (see ADAF_MATH_F32_SPLIT_BF16)
+                           95 = the small-batch form (csrc/conv_lat.hip): 32x32 block tiles of four 16x16 wave tiles on
+                           v_mfma_f32_16x16x4_f32, whose accumulator chain is 3.2x shorter per k than the 32x32x2 chain of
+                           every other fp32 tile and visits k in the same order -- bit-identical results; fp32 only,
+                           cin % 64 == 0, no temporal shift (anything else: ADAF_E_LAUNCH) */
 } adaf_conv_params;
 
 #define ADAF_CONV_TILES 4
@@ -241,6 +245,13 @@ int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
  *     faster plan (on = 2: at every size, for tests).
  * Results are bit-identical to the unfused launches (same k order in every product).  ADAF_MATH_F32 only. */
 int adaf_resnet50_set_fusion(adaf_resnet50* net, int on);
+/* Small batches (BASELINE config 1 is B = 2, T = 8: 16 patches).  A conv launch whose GEMM has at most `rows` output pixels
+ * (default 1536, env ADAF_LATENCY_ROWS; 0 = never) runs on the small-batch form (tile id 95 of adaf_conv_params.tile) instead
+ * of the engine's batched tiles: at 16 patches stages 3 and 4 are 576 / 144 rows, a few dozen blocks whose duration is one
+ * accumulator chain.  Bit-identical to the batched plan: a clip's logits do not depend on the size of the batch it came in
+ * (tests/test_hip_parity_r3.py).  ADAF_MATH_F32 without temporal shift only.  No reference counterpart (the reference's
+ * published latency is a CPU bs = 1 figure). */
+int adaf_resnet50_set_latency_rows(adaf_resnet50* net, int rows);
 /* Arithmetic of the trunk's convolutions (no reference counterpart; the reference is plain fp32).
  *   ADAF_MATH_F32            (default) v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain per output.
  *   ADAF_MATH_F32_SPLIT_BF16 (opt-in)  every fp32 operand x is decomposed EXACTLY into bf16 parts h + m + l (round-to-

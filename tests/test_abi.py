@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     lib.adaf_version.restype = ctypes.c_int
-    assert lib.adaf_version() == 300
+    assert lib.adaf_version() == 301
 
 
 def test_loader_declares_prototypes():
