@@ -828,6 +828,10 @@ static int linear_launch(adaf_handle* h, const float* x, int rows, int ldx, int 
     ConvArgs a;
     int rc = make_conv_args(h, &p, x, w, nullptr, bias, nullptr, out, &a);
     if (rc) return rc;
+    // a few rows (config 1's GRU projection: 16 x 3328 -> 3072) are one accumulator chain per block on the engine: the
+    // small-batch form's chain is 3.2x shorter and bit-identical (conv_lat.hip; ADAF_LATENCY_LINEAR_ROWS, 0 = never)
+    static const int lat_rows = [] { const char* e = getenv("ADAF_LATENCY_LINEAR_ROWS"); return e ? atoi(e) : 128; }();
+    if (rows <= lat_rows && in >= 512 && adaf_launch_conv_gemm(a, 95, h->cus, st) > 0) return ADAF_OK;
     if (adaf_launch_conv_gemm(a, 0, h->cus, st) < 0) return fail(h, ADAF_E_LAUNCH, "linear: no kernel for this shape");
     return ADAF_OK;
 }
