@@ -370,7 +370,14 @@ void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int strid
     const int oh = (h + 2 - 3) / stride + 1, ow = (w + 2 - 3) / stride + 1;
     const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
     const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
-    if (stride == 1) {   // 4 x 2 outputs share 6 input columns x 4 input rows (24 loads for 8 outputs instead of 36)
+    // thread tile at stride 1: 4 x 4 outputs share 6 x 6 input chunks (2.25 loads per output; measured on the glancer's maps at
+    // 512 frames, ADAF_DW3_VARIANT: 4x2 (3 loads per output, round 2's shape) 3.7-4.4 TB/s, 2x2 3.2-4.2, 4x1 3.0-3.6, 7x2 3.8-4.5,
+    // 4x4 4.3-4.9 -- fewer, fatter threads with 36 independent loads in flight each win although 14 = 3.5 x 4 wastes an eighth of them)
+    static const int var = [] { const char* e = getenv("ADAF_DW3_VARIANT"); return e ? atoi(e) : 4; }();
+    if (stride == 1 && var == 4) {
+        const long long total = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 4>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt, scale, bias, lo, hi, o);
+    } else if (stride == 1) {   // 4 x 2 outputs share 6 input columns x 4 input rows (24 loads for 8 outputs instead of 36)
         const long long total = (long long)n * ((oh + 1) / 2) * ((ow + 3) / 4) * (c / 4);
         hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 2>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
                            scale, bias, lo, hi, o);
@@ -415,8 +422,8 @@ void adaf_launch_dwconv3x3_f16(const void* x, int n, int h, int w, int c, int st
     const _Float16* xi = static_cast<const _Float16*>(x);
     _Float16* oo = static_cast<_Float16*>(o);
     if (stride == 1) {
-        const long long total = (long long)n * ((oh + 1) / 2) * ((ow + 3) / 4) * (c / 4);
-        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 2, _Float16>), dim3(blocks_for(total)), dim3(256), 0, s, xi, n, h, w, c / 4, oh, ow, wt,
+        const long long total = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4) * (c / 4);
+        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 4, _Float16>), dim3(blocks_for(total)), dim3(256), 0, s, xi, n, h, w, c / 4, oh, ow, wt,
                            scale, bias, lo, hi, oo);
     } else {
         const long long total = (long long)n * oh * ((ow + 1) / 2) * (c / 4);
