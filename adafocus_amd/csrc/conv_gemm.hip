@@ -1705,6 +1705,9 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
             // 96, 160: MobileNetV2's project convs) and there are enough row tiles to fill the device
             const int pad64 = ((a.N + 63) / 64) * 64;
             if ((pad64 - a.N) * 5 >= a.N && (long long)((a.M + 127) / 128) >= cus) tile = 38;
+            // the same padding with fewer rows but a long reduction (MobileNetV2's 960 -> 160 project convs on 7x7 maps: 25 k rows):
+            // waves of 64 x 32 under 256-row tiles -- 65 instead of 83 us per 512 frames (tools/tail_gemm_tiles.py)
+            else if ((pad64 - a.N) * 5 >= a.N && a.K >= 512 && (long long)((a.M + 255) / 256) * ((a.N + 31) / 32) >= cus) tile = 39;
         }
     }
     const bool dense = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
