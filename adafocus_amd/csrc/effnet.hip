@@ -346,6 +346,93 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     }
 }
 
+// ---- depthwise k x k on TINY maps (H = W = HW <= 5: the last stages of the network; 5 x 5 at B3's 144^2 patches) -----------------
+// On a 5 x 5 map a 5 x 5 window mostly sees padding (14.4 of its 25 taps are inside on average, 6.8 of 9 for 3 x 3), and
+// dw_same_kernel multiplies all of them (zeros staged in LDS), reads every staged value through LDS once per filter row, converts it
+// on every read and reduces the squeeze sums across threads.  Here a thread owns ONE image x 4 channels: it loads the whole map
+// (25 pixels x 4 channels, straight from global memory, every load in flight at once), converts it once, keeps all HW^2 x 4
+// accumulators in registers and visits exactly the (output, tap) pairs that fall inside the map -- the loops are unrolled at
+// compile time, so "inside" costs nothing -- in the same (ky, kx) order per output as everywhere else (a skipped tap would have
+// added an exact zero): bit-identical to dw_same_kernel.  The squeeze sum of an (image, channel) is thread-local: no LDS, no
+// barrier, no partial tiles.  b19-b23 (5 x 5 window, 1392 channels): 110 -> ~45 us per 1024 patches.
+struct DsArgs {
+    const void* x;
+    void* out;
+    const float* wt;     // [K*K][C]
+    const float* scale;
+    const float* bias;
+    float* pool_part;    // [n][C] sums (tiles = 1) or nullptr
+    int n, C, act;
+};
+
+template <typename T> struct Quad;      // four consecutive channels of one pixel
+template <> struct Quad<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Quad<_Float16> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 ld(const _Float16* p) {
+        const h4 v = *reinterpret_cast<const h4*>(p);
+        return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+    }
+    static __device__ __forceinline__ void st(_Float16* p, f32x4 v) { *reinterpret_cast<h4*>(p) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+};
+
+template <int K, int HW, typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void dw_small_kernel(const DsArgs a) {
+    constexpr int P = (K - 1) / 2;           // SAME padding at stride 1: symmetric
+    const int c4 = a.C >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)a.n * c4) return;
+    const int cq = (int)(idx % c4), img = (int)(idx / c4);
+    const T* xb = static_cast<const T*>(a.x) + (size_t)img * HW * HW * a.C + 4 * cq;
+    f32x4 v[HW * HW];
+#pragma unroll
+    for (int p = 0; p < HW * HW; ++p) v[p] = Quad<T>::ld(xb + (size_t)p * a.C);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * cq), bi = *reinterpret_cast<const f32x4*>(a.bias + 4 * cq);
+    T* ob = static_cast<T*>(a.out) + (size_t)img * HW * HW * a.C + 4 * cq;
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    // the output rows in two passes when the map is 5 x 5 (or 4 x 4 under a 5 x 5 window): HW^2 accumulators next to the HW^2
+    // converted inputs are 200 + registers = one wave per SIMD; with 3 + 2 rows the kernel fits two or three
+    constexpr int RA = (HW == 5 || (HW == 4 && K == 5)) ? (HW + 1) / 2 : HW;
+#pragma unroll
+    for (int r0 = 0; r0 < HW; r0 += RA) {
+        f32x4 acc[RA * HW];
+#pragma unroll
+        for (int p = 0; p < RA * HW; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(a.wt + (size_t)(ky * K + kx) * a.C + 4 * cq);
+#pragma unroll
+                for (int oy = r0; oy < r0 + RA; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < HW; ++ox) {
+                        const int iy = oy + ky - P, ix = ox + kx - P;
+                        if (oy >= HW || iy < 0 || iy >= HW || ix < 0 || ix >= HW) continue;       // resolved at compile time
+                        f32x4& s = acc[(oy - r0) * HW + ox];
+                        const f32x4 xin = v[iy * HW + ix];
+                        s.x = fmaf(xin.x, w.x, s.x); s.y = fmaf(xin.y, w.y, s.y); s.z = fmaf(xin.z, w.z, s.z); s.w = fmaf(xin.w, w.w, s.w);
+                    }
+            }
+#pragma unroll
+        for (int q = 0; q < RA * HW; ++q) {
+            const int p = r0 * HW + q;
+            if (p >= HW * HW) continue;
+            f32x4 o;
+            o.x = act_apply(fmaf(acc[q].x, sc.x, bi.x), a.act);
+            o.y = act_apply(fmaf(acc[q].y, sc.y, bi.y), a.act);
+            o.z = act_apply(fmaf(acc[q].z, sc.z, bi.z), a.act);
+            o.w = act_apply(fmaf(acc[q].w, sc.w, bi.w), a.act);
+            psum += o;
+            Quad<T>::st(ob + (size_t)p * a.C, o);
+        }
+    }
+    if (a.pool_part) *reinterpret_cast<f32x4*>(a.pool_part + (size_t)img * a.C + 4 * cq) = psum;
+}
+
 // ---- the same work as dw_same_kernel, software-pipelined ----------------------------------------------------------------
 // Measured on the first version (one tile per block: load -> barrier -> taps -> store): every layer ran at 2-3 TB/s whatever the
 // tile size or the number of resident blocks, because a block spends its load phase, its tap phase and its store phase one after
@@ -1308,6 +1395,21 @@ bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, bool pipe, size_t lds, 
     return true;
 }
 
+// tiny maps (H = W <= 5, stride 1): one thread per (image, 4 channels); false = not that shape
+template <typename T>
+static bool launch_dw_small_t(const DsArgs& a, int K, int HW, hipStream_t s) {
+    const unsigned grid = (unsigned)(((long long)a.n * (a.C / 4) + 255) / 256);
+#define ADAF_DS(K_, HW_) hipLaunchKernelGGL((dw_small_kernel<K_, HW_, T>), dim3(grid), dim3(256), 0, s, a); return true;
+    if (K == 3 && HW == 3) { ADAF_DS(3, 3) }
+    if (K == 3 && HW == 4) { ADAF_DS(3, 4) }
+    if (K == 3 && HW == 5) { ADAF_DS(3, 5) }
+    if (K == 5 && HW == 3) { ADAF_DS(5, 3) }
+    if (K == 5 && HW == 4) { ADAF_DS(5, 4) }
+    if (K == 5 && HW == 5) { ADAF_DS(5, 5) }
+#undef ADAF_DS
+    return false;
+}
+
 }  // namespace
 
 // Depthwise k x k (k = 3 | 5, stride 1 | 2), padding pad_t / pad_l before the first row / column and whatever the output
@@ -1322,6 +1424,12 @@ int adaf_effnet_dw_tiles(int c, int oh, int ow, int k, int stride, int dtype) {
 int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, int pad_t, int pad_l, int oh,
                         int ow, const float* wt, const float* scale, const float* bias, int act, void* out, float* pool_part,
                         const float* zeros, int cus, hipStream_t s) {
+    static const int small_on = [] { const char* e = getenv("ADAF_DW_SMALL"); return e ? atoi(e) : 1; }();     // 0 = dw_same_kernel everywhere (A/B)
+    if (small_on && stride == 1 && hh == ww && hh >= 3 && hh <= 5 && oh == hh && ow == ww && pad_t == (k - 1) / 2 && pad_l == pad_t && c % 4 == 0) {
+        DsArgs b;
+        b.x = x; b.out = out; b.wt = wt; b.scale = scale; b.bias = bias; b.pool_part = pool_part; b.n = n; b.C = c; b.act = act;
+        if (dtype == ADAF_DTYPE_F16 ? launch_dw_small_t<_Float16>(b, k, hh, s) : launch_dw_small_t<float>(b, k, hh, s)) return 1;
+    }
     DwPlan p;
     if (!plan_dw(c, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
     DwArgs a;

@@ -60,7 +60,7 @@ def _swish(x):
 @pytest.mark.parametrize("k,stride,size,c", [(3, 1, 72, 40), (3, 1, 72, 24), (3, 2, 72, 144), (3, 1, 36, 192), (5, 2, 36, 192),
                                              (5, 1, 18, 288), (3, 2, 18, 288), (3, 1, 9, 576), (5, 1, 9, 816), (5, 2, 9, 816),
                                              (5, 1, 5, 1392), (3, 1, 5, 2304), (5, 2, 11, 48), (3, 2, 7, 16), (5, 1, 10, 8),
-                                             (3, 1, 13, 200)])
+                                             (3, 1, 13, 200), (5, 1, 4, 64), (3, 1, 4, 96), (5, 1, 3, 64), (3, 1, 3, 2304)])
 def test_dwconv_same_vs_torch(dev, ops, R, k, stride, size, c):
     """Depthwise k x k with SAME padding + BN affine + swish + squeeze mean, fp32 and fp16 storage, against F.conv2d on the
     explicitly padded input (Conv2dStaticSamePadding)."""
@@ -90,6 +90,26 @@ def test_dwconv_same_vs_torch(dev, ops, R, k, stride, size, c):
         # products and sums are fp32 on fp16 inputs: only the final store rounds (half an ulp of fp16 = 2^-11 relative)
         assert (o16.float().cpu().permute(0, 3, 1, 2) - ref16).abs().max().item() < 1e-3 * max(1.0, float(ref16.abs().max()))
         assert (p16.cpu() - ref16.mean([2, 3])).abs().max().item() < 2e-5      # the squeeze sums the fp32 values
+
+
+def test_tiny_map_depthwise_kernel_bit_identical_to_the_staged_one():
+    """dw_small_kernel (H = W <= 5: one thread per image x 4 channels, padding taps skipped, thread-local squeeze sums) against
+    dw_same_kernel on the same inputs: same sha256 of every output map, fp32 and fp16 storage, 3x3 and 5x5 windows, 3^2 .. 5^2 maps.
+    The switch is read once per process, so both arms run as subprocesses (tools/dw_small_ab.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dw_small_ab.py")], capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, ADAF_DW_SMALL=mode))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln.split() for ln in r.stdout.splitlines() if len(ln.split()) == 3])
+    assert len(outs[0]) == 24 and len(outs[1]) == 24
+    for a, b in zip(*outs):
+        assert a[:2] == b[:2], (a, b)                                  # the maps: bit for bit
+        assert abs(float(a[2]) - float(b[2])) <= 1e-3 * max(1.0, abs(float(b[2])))      # the squeeze sums: another summation order
 
 
 def test_dwconv_same_rejects_bad_arguments(dev, ops):
