@@ -134,10 +134,12 @@ def gather_resize_row(dev, frames, patch=96, iters=20):
     return out
 
 
-def evaluate_loop_row(dev, model, args, b, t, batches=8):
+def evaluate_loop_row(dev, model, args, b, t, batches=24):
     """Row f3 end to end: evaluate.validate on an in-memory synthetic set of uint8 clips (host tensors -> pinned staging ->
     H2D -> ingest + glancer + policy + hot path -> loss / accuracy / mAP on the host).  One untimed pass first (pinned
-    buffers, scratch), then the timed pass."""
+    buffers, scratch), then the timed pass.  A call carries ~50 ms that do not overlap with anything (the first batch's staging +
+    copy, the last batch's drain, cal_map on the host): 8 batches measure 1.9-2.0 k clips/s, 24 batches 2.4 k, the steady state
+    is ~25.5 ms per 64-clip batch (tools/eval_loop_probe.py with EVAL_N=2048)."""
     from adafocus_amd import evaluate as E
     n = b * batches
     labels = torch.randint(0, args.num_classes, (n, 1))
@@ -158,7 +160,8 @@ def evaluate_loop_row(dev, model, args, b, t, batches=8):
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 1), "unit": "clips/s", "clips": n, "seconds": round(dt, 3), "ms_per_batch": round(dt / batches * 1e3, 2),
             "note": "evaluate.validate (ACT/main_dist.py:307-422 stage-3 branch) from the loader's uint8 (H,W,T*3) clips in host memory: "
-                    "pinned staging + H2D of batch i+1 under batch i's kernels, two-stream forward, metrics (accuracy, cal_map) on the host"}
+                    "pinned staging + H2D of batch i+1 under batch i's kernels, two-stream forward, metrics (accuracy, cal_map) on the host; "
+                    "%d batches per call (a call carries ~50 ms of un-overlapped first-batch staging, drain and cal_map)" % batches}
 
 
 def validate_sth_row(dev, b, t=8, p=128, batches=4):

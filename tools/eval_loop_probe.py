@@ -13,7 +13,7 @@ from adafocus_amd import evaluate as E  # noqa: E402
 from adafocus_amd.gfv_net import GFV  # noqa: E402
 
 dev = torch.device("cuda:0")
-t, b, n = 16, 64, 1024
+t, b, n = 16, 64, int(os.environ.get("EVAL_N", "1024"))
 args = act_args(t, 96, b)
 args.gpu = 0
 model = GFV(args).eval()
