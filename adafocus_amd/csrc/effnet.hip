@@ -380,7 +380,7 @@ template <> struct Quad<_Float16> {
 };
 
 template <int K, int HW, typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void dw_small_kernel(const DsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void dw_small_kernel(const DsArgs a) {
     constexpr int P = (K - 1) / 2;           // SAME padding at stride 1: symmetric
     const int c4 = a.C >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
