@@ -52,6 +52,11 @@ struct ConvArgs {
     int pm_images, pm_groups;   // set by the launcher: images in the batch, image groups of BM per pixel position
     int tiles_n;         // ceil(N / BN) for the chosen tile
     int nblocks;
+    // global average pool in the epilogue (adaf_launch_conv_pool: the trunk's last conv3): a tile's rows are whole images of pool_hw
+    // pixels (pool_rows = floor(128 / pool_hw) * pool_hw of them), the activated outputs are averaged per image in pixel order and
+    // pool_out[image * pool_ld + n] is written instead of `out`
+    int pool_hw, pool_rows, pool_ld;
+    float* pool_out;
 };
 
 // mbconv.hip: fused expand 1x1 -> depthwise 3x3 of an inverted-residual block
@@ -110,6 +115,7 @@ hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, co
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0
 int adaf_pick_conv_tile(int M, int N, int K, int cus);
 int adaf_launch_conv_lat(const ConvArgs& a, hipStream_t s);   // conv_lat.hip: small-batch form (tile id 95), 1 = launched, 0 = not eligible
+int adaf_launch_conv_pool(ConvArgs a, int hw, float* pool_out, int pool_ld, hipStream_t s);   // 1 = launched (tile id 96), 0 = not eligible
 bool adaf_conv_tile_exists(int tile);   // is `tile` an id adaf_launch_conv_gemm has a kernel for
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
 // conv2 3x3 (64 -> 64) -> conv3 1x1 (+ identity, ReLU) [-> the next block's conv1 1x1] in one launch (stage 1 of the trunk);

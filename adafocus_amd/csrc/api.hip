@@ -489,6 +489,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         }
     };
     int li = 0;
+    bool pooled = false;           // the last conv3 averaged its map itself
     auto conv = [&](const float* in, int hh, int ww, int act, const float* res, float* out, int tsm, int* oh, int* ow,
                     int ldo) -> int {
         const ConvLayer& L = net->convs[li];
@@ -608,15 +609,35 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
                 if (Ln) { float* t = t1; t1 = t2; t2 = t; c1_done = true; }
             } else {
                 if ((rc = conv(t1, h1, w1, ADAF_ACT_RELU, nullptr, t2, 0, &h2, &w2, 0))) return rc;
-                if ((rc = conv(t2, h2, w2, ADAF_ACT_RELU, identity, nxt, 0, &h3, &w3, 0))) return rc;
+                const bool last = s == 3 && b == kStageBlocks[3] - 1;
+                if (last && fuse && !rec && net->math == ADAF_MATH_F32 && !net->tiles[li] && !(lat_ok && n * h2 * w2 <= lat_rows)) {
+                    // the trunk's last conv3: the global average pool rides in its epilogue (conv_epilogue_pool) -- no 2048-channel map,
+                    // no pooling launch -- when whole images fill its row tiles (3x3 / 4x4 / 5x5 maps); bit-identical to conv + pool
+                    const ConvLayer& L3 = net->convs[li];
+                    adaf_conv_params p;
+                    memset(&p, 0, sizeof(p));
+                    p.n = n; p.h = h2; p.w = w2; p.cin = L3.cin_pad; p.cout = L3.cout; p.kh = p.kw = 1; p.stride = 1; p.pad = 0;
+                    p.act = ADAF_ACT_RELU;
+                    ConvArgs a3;
+                    if ((rc = make_conv_args(h, &p, t2, L3.w, L3.scale, L3.bias, identity, nxt, &a3))) return rc;
+                    // (the profiled pass -- one event in front of every launch -- keeps conv + pool: its per-launch table stays comparable)
+                    if (adaf_launch_conv_pool(a3, h2 * w2, feat, ldfeat, st)) {
+                        pooled = true;
+                        h3 = h2; w3 = w2;
+                        ++li;
+                    }
+                }
+                if (!pooled && (rc = conv(t2, h2, w2, ADAF_ACT_RELU, identity, nxt, 0, &h3, &w3, 0))) return rc;
             }
             li = i_next;
             hh = h3; ww = w3;
             float* t = cur; cur = nxt; nxt = t;
         }
     }
-    mark(0.0, 4.0 * ((double)n * hh * ww * 2048 + (double)n * 2048), 0);
-    adaf_launch_avgpool(cur, n, hh * ww, 2048, feat, ldfeat, st);
+    if (!pooled) {
+        mark(0.0, 4.0 * ((double)n * hh * ww * 2048 + (double)n * 2048), 0);
+        adaf_launch_avgpool(cur, n, hh * ww, 2048, feat, ldfeat, st);
+    }
     if (rec) (void)hipEventRecord((*rec)[info->size()], st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : hip_fail(h, e, "resnet50 forward");

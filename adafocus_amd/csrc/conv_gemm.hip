@@ -279,6 +279,69 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a0, float* smem, f
     }
 }
 
+// ---- epilogue with the global average pool folded in (ACT/models/resnet.py:222-223 avgpool + flatten) ----------
+// The trunk's last conv3 (+ BN + identity + ReLU) does not write its map: a tile's rows are whole images (pool_rows = images x
+// pool_hw pixels), every wave transposes its bands through its slab exactly as conv_epilogue does, applies the same arithmetic and
+// parks the activated values in an LDS tile; after one barrier a thread per (image, channel) adds the pool_hw pixels IN PIXEL
+// ORDER and divides by pool_hw -- the order and the operations of avgpool_kernel (misc_ops.hip), so the features are
+// bit-identical to conv + separate pool (tests/test_hip_parity_r3.py).  Saves the 75 MB map's round trip and a launch.
+template <int TM, int TN, int BM, int BN, int NW>
+__device__ __forceinline__ void conv_epilogue_pool(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                   int lane, int wave, int tile_m) {
+    constexpr int WM = TM * 32, WN = TN * 32, SP = WN + 4, PP = BN + 4;
+    float* st = smem + wave * 32 * SP;
+    float* P = smem + NW * 32 * SP;                    // [BM][PP]
+    constexpr int C4 = WN / 4, RPI = 64 / C4;
+    const int c4 = lane % C4, rsub = lane / C4;
+    const int crow = 4 * (lane >> 5);
+    const int n = n0 + wn * WN + 4 * c4;
+    const bool n_ok = n < a.N;
+    const int nn = n_ok ? n : 0;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nn) : one4;
+    const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nn) : zero4;
+    const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[(crow + (r & 3) + 8 * (r >> 2)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 32 / RPI; ++u) {
+            const int row = u * RPI + rsub;
+            const int lrow = wm * WM + i * 32 + row;                 // row inside the tile
+            const int ml = m0 + lrow;
+            const bool ok = n_ok && lrow < a.pool_rows && ml < a.M;
+            const f32x4 rv = (ok && a.res) ? *reinterpret_cast<const f32x4*>(a.res + (size_t)ml * a.ldr + n) : zero4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * SP + 4 * c4);
+            f32x4 o;
+            o.x = fminf(fmaxf(fmaf(v.x, sc.x, bi.x) + rv.x, act_lo), act_hi);
+            o.y = fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv.y, act_lo), act_hi);
+            o.z = fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv.z, act_lo), act_hi);
+            o.w = fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv.w, act_lo), act_hi);
+            *reinterpret_cast<f32x4*>(P + lrow * PP + wn * WN + 4 * c4) = o;
+        }
+    }
+    __syncthreads();
+    const int ipt = a.pool_rows / a.pool_hw;           // images per tile
+    const int images = a.M / a.pool_hw;
+    const float inv = (float)a.pool_hw;
+    for (int idx = threadIdx.x; idx < ipt * (BN / 4); idx += 64 * NW) {
+        const int im = idx / (BN / 4), cq = idx - im * (BN / 4);
+        const int img = tile_m * ipt + im, nc = n0 + 4 * cq;
+        if (img >= images || nc >= a.N) continue;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const float* p = P + (im * a.pool_hw) * PP + 4 * cq;
+        for (int r = 0; r < a.pool_hw; ++r) s += *reinterpret_cast<const f32x4*>(p + r * PP);
+        const f32x4 q = {s.x / inv, s.y / inv, s.z / inv, s.w / inv};
+        *reinterpret_cast<f32x4*>(a.pool_out + (size_t)img * a.pool_ld + nc) = q;
+    }
+}
+
 // FLAGS bit 0: raise wave priority around the MFMA cluster (s_setprio)
 template <int BM, int BN, int WGM, int WGN, int BK, bool DENSE, int FLAGS, int ET = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArgs a) {
@@ -495,9 +558,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(const ConvArg
 // builtin only emits the 64-bit-VGPR-address form: one v_lshl_add_u64 per instruction per slice).  Rows past the end of the
 // problem read a valid row instead of the zero block (their outputs are discarded by the epilogue), so no select either.
 template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, int EMU, bool BSP = false, int DT = 0, bool PM = false,
-          bool LEAN = false>
+          bool LEAN = false, bool POOL = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (BM == 128 && BN == 128 && WGM * WGN == 4) ? 2 : 1)   // 128x128: two blocks per CU
 void conv_gemm_glds_kernel(const ConvArgs a) {
+    static_assert(!POOL || (LEAN && DENSE && DT == 0), "pooled epilogue: the lean dense fp32 kernel");
     static_assert(!PM || (!DENSE && EMU == 0 && !BSP && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe");
     static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && EMU == 0 && !BSP && PIPE == 1), "lean K loop: plain fp32-pipe launches");
     constexpr int NW = WGM * WGN;
@@ -507,7 +571,8 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int STAGE = BM * 32 + BN * (BSP ? 48 : 32);
     static_assert(!BSP || (EMU != 0 && (3 * BN / 16) % NW == 0), "pre-split weights: split tiles only");
     constexpr int SLAB = NW * 32 * (TN * 32 + 4);
-    constexpr int SMEM = 2 * STAGE > SLAB ? 2 * STAGE : SLAB;
+    constexpr int POOLF = POOL ? BM * (BN + 4) : 0;                        // pooled epilogue: the activated tile, next to the slabs
+    constexpr int SMEM = 2 * STAGE > SLAB + POOLF ? 2 * STAGE : SLAB + POOLF;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "staging shape");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -524,7 +589,7 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
     }
     const int tile_m = bid / a.tiles_n;
     const int tile_n = bid - tile_m * a.tiles_n;
-    int m0 = tile_m * BM;
+    int m0 = tile_m * (POOL ? a.pool_rows : BM);      // (pooled epilogue: a tile holds whole images; its last BM - pool_rows rows repeat the next tile's)
     const int n0 = tile_n * BN;
     // position-major: this tile's pixel, its first image, and the taps inside the image (uniform over the tile)
     int pm_p = 0, pm_iy0 = 0, pm_ix0 = 0;
@@ -1017,6 +1082,10 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         }
     }
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
+    if constexpr (POOL) {
+        conv_epilogue_pool<TM, TN, BM, BN, NW>(a, smem, acc, m0, n0, wm, wn, lane, wave, tile_m);
+        return;
+    }
     if (PM) conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave, a.OH * a.OW, pm_p, a.pm_images);
     else conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave);
 }
@@ -1763,6 +1832,24 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         default: return -1;
     }
     return tile;
+}
+
+// The trunk's last conv3 with the global average pool in its epilogue (conv_epilogue_pool): 1x1 / stride 1 fp32, images of `hw`
+// pixels that fill a 128-row tile to >= 90 % (hw = 9 at 96^2 patches: 14 images = 126 rows; 16 at 128^2; 25 at 144^2).
+int adaf_launch_conv_pool(ConvArgs a, int hw, float* pool_out, int pool_ld, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("ADAF_CONV_POOL"); return e ? atoi(e) : 1; }();      // 0 = conv + separate avgpool_kernel (A/B)
+    if (!on || !conv_lean_enabled() || conv_lean_enabled() != 1) return 0;
+    if (a.in16 || a.out16 || a.res16 || a.split_n || a.tsm_T > 0 || a.wsp) return 0;
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || (a.K & 31) || (a.N & 3) || !a.vec_epi) return 0;
+    if (hw <= 0 || hw > 128 || a.M % hw || (128 / hw) * hw * 10 < 128 * 9 || (pool_ld & 3) || (reinterpret_cast<size_t>(pool_out) & 15)) return 0;
+    if (a.act != ADAF_ACT_NONE && a.act != ADAF_ACT_RELU && a.act != ADAF_ACT_RELU6) return 0;
+    if ((size_t)a.M * a.ldx * 4 >= 0xffffff00ull || (size_t)a.N * a.K * 4 >= 0xffffff00ull) return 0;
+    a.pool_hw = hw; a.pool_rows = (128 / hw) * hw; a.pool_out = pool_out; a.pool_ld = pool_ld;
+    a.vec_epi = 2;
+    a.tiles_n = (a.N + 63) / 64;
+    a.nblocks = ((a.M + a.pool_rows - 1) / a.pool_rows) * a.tiles_n;
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<128, 64, 2, 2, true, 1, false, 0, false, 0, false, true, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return 1;
 }
 
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s) {
