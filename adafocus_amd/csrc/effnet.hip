@@ -862,6 +862,138 @@ __global__ __launch_bounds__(1024) void ef_expand_kernel(const ExpArgs a) {
     }
 }
 
+// ---- gated project 1x1 for narrow blocks (K <= 64 hidden channels, N <= 32 outputs: blocks 0-1 of B3, 5.3 M rows each) ----------
+// gated_project_kernel walks these as 41 k tiles of 128 rows with a barrier pair per 64-wide k slice -- one slice, i.e. a block
+// that loads, synchronises, issues a handful of MFMAs and stores: 250-290 us for 0.7 GB.  The strip form of ef_expand_kernel: the
+// filter + BN in LDS for the life of a persistent block, a wave per 32-row strip with no block barrier, the next strip's rows in
+// flight while this one is multiplied; the SE gate (per image, per hidden channel) multiplies the A fragments in registers exactly
+// as gated_project_kernel's staging does (fp32 product, rounded to the storage type: the operand the MFMA sees is the same), same
+// MFMA instruction and k order, same epilogue arithmetic (BN affine, + identity in fp32, activation, one rounding): bit-identical.
+struct NprojArgs {
+    const void* x;        // [M][K]
+    const float* gate;    // [M / HW][K]
+    const void* w;        // [N][K] (storage type)
+    const float* scale;   // [N]
+    const float* bias;
+    const void* res;      // [M][N] or nullptr
+    void* out;            // [M][N]
+    int M, K, N, HW, act;
+    int KP, strips;
+};
+
+template <typename T, int KS>
+__global__ __launch_bounds__(512) void ef_nproj_kernel(const NprojArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int KSTEP = 2 * V;
+    constexpr int SP = 36;                                // slab row pitch in floats (32 columns + skew)
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int wpitch = a.KP * (int)sizeof(T) + 16;
+    char* wl = dsm;                                                   // [32][wpitch]
+    float* sb = reinterpret_cast<float*>(wl + 32 * wpitch);           // [2][32]
+    float* slab = sb + 64 + wave * 32 * SP;
+    {
+        const int CPP = wpitch / 16 - 1, kchunks = a.K / V;
+        const T* wb = static_cast<const T*>(a.w);
+        for (int i = tid; i < 32 * CPP; i += blockDim.x) {
+            const int h = i / CPP, c = i - h * CPP;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (h < a.N && c < kchunks) v = *reinterpret_cast<const u32x4*>(wb + (size_t)h * a.K + c * V);
+            *reinterpret_cast<u32x4*>(wl + (size_t)h * wpitch + c * 16) = v;
+        }
+        for (int i = tid; i < 64; i += blockDim.x) {
+            const int which = i >> 5, h = i & 31;
+            sb[i] = h < a.N ? (which ? (a.bias ? a.bias[h] : 0.f) : (a.scale ? a.scale[h] : 1.f)) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nl = lane & 31, half = lane >> 5;
+    const T* xb = static_cast<const T*>(a.x);
+    const int stride = gridDim.x * nwaves;
+    int strip = blockIdx.x * nwaves + wave;
+    auto load = [&](int st, u32x4 (&f)[KS]) {                    // the gated rows of strip st as A fragments
+        const long long row = (long long)st * 32 + nl;
+        const bool ok = st < a.strips && row < a.M;
+        const long long rr = ok ? row : 0;
+        const T* src = xb + (size_t)rr * a.K + half * V;
+        const float* g = a.gate + (size_t)(rr / a.HW) * a.K + half * V;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok && kk * KSTEP + half * V < a.K) {
+                v = *reinterpret_cast<const u32x4*>(src + kk * KSTEP);
+                float f32[V];
+                Chunk<T>::unpack(v, f32);
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + kk * KSTEP + e);
+                    f32[e] *= gv.x; f32[e + 1] *= gv.y; f32[e + 2] *= gv.z; f32[e + 3] *= gv.w;
+                }
+                v = Chunk<T>::pack(f32);
+            }
+            f[kk] = v;
+        }
+    };
+    u32x4 af[KS], an[KS];
+    load(strip, af);
+    const int PPR = a.N / V;                               // 16-byte pieces per output row
+    const T* rs = static_cast<const T*>(a.res);
+    T* ob = static_cast<T*>(a.out);
+    for (; strip < a.strips; strip += stride) {
+        load(strip + stride, an);
+        const long long m0 = (long long)strip * 32;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const char* brow = wl + (size_t)nl * wpitch + half * 16;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + kk * 32);
+            if constexpr (sizeof(T) == 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kk]), __builtin_bit_cast(f16x8, bf), acc, 0, 0, 0);
+            } else {
+                const f32x4 a4 = __builtin_bit_cast(f32x4, af[kk]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bf.w, acc, 0, 0, 0);
+            }
+        }
+        const float sc = sb[nl], bi = sb[32 + nl];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) slab[((i & 3) + 8 * (i >> 2) + 4 * half) * SP + nl] = fmaf(acc[i], sc, bi);
+        __builtin_amdgcn_wave_barrier();
+        // the strip's outputs are one contiguous range: piece q = (row q / PPR, chunk q % PPR)
+        const int rows = (int)min((long long)32, a.M - m0);
+        const int total = rows * PPR;
+        for (int q = lane; q < total; q += 64) {
+            const int r = q / PPR, c = q - r * PPR;
+            float v[V];
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(slab + r * SP + c * V + e);
+                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+            }
+            const size_t g = (size_t)(m0 + r) * a.N + c * V;
+            if (rs) {
+                float rr[V];
+                Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rs + g), rr);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] += rr[e];
+            }
+            if (a.act != ADAF_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] = act_apply(v[e], a.act);
+            }
+            *reinterpret_cast<u32x4*>(ob + g) = Chunk<T>::pack(v);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) af[kk] = an[kk];
+    }
+}
+
 // mean[n][c] = sum_t part[n][t][c] / hw  (the stand-alone op's squeeze output)
 __global__ void pool_finish_kernel(const float* __restrict__ part, int n, int tiles, int c, float inv_hw, float* __restrict__ mean) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1611,10 +1743,42 @@ void adaf_launch_se_gate(const float* part, int tiles, int hw, int n, int c, con
                            1.f / (float)hw, n, c, wr, br, sq, we, we_ldc, we_ldj, be, gate);
 }
 
+// narrow gated project (K <= 64, N <= 32) on the persistent strip kernel; false = not eligible
+template <typename T>
+static bool launch_nproj_t(const NprojArgs& a, int blocks, size_t lds, hipStream_t s) {
+    const int ks = a.KP / (2 * Chunk<T>::V);
+#define ADAF_NP(KS_) case KS_: hipLaunchKernelGGL((ef_nproj_kernel<T, KS_>), dim3((unsigned)blocks), dim3(512), lds, s, a); return true;
+    switch (ks) {
+        ADAF_NP(1) ADAF_NP(2) ADAF_NP(3) ADAF_NP(4) ADAF_NP(5) ADAF_NP(6) ADAF_NP(7) ADAF_NP(8)
+        default: return false;
+    }
+#undef ADAF_NP
+}
+
+static bool launch_narrow_project(const void* x, int dtype, long long m, int hw, int k, const float* gate, const void* w, int n, const float* scale,
+                                  const float* bias, const void* res, void* out, int act, int cus, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("ADAF_EF_NPROJ"); return e ? atoi(e) : 1; }();          // 0 = gated_project_kernel (A/B)
+    const bool f16 = dtype == ADAF_DTYPE_F16;
+    const int v = f16 ? 8 : 4, es = f16 ? 2 : 4;
+    if (!on || !gate || k > 64 || n > 32 || k % v || n % v || m < 32ll * 8 * cus || m > (1ll << 31) - 64) return false;
+    NprojArgs a;
+    a.x = x; a.gate = gate; a.w = w; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+    a.M = (int)m; a.K = k; a.N = n; a.HW = hw; a.act = act;
+    a.KP = (k + 2 * v - 1) / (2 * v) * (2 * v);
+    a.strips = (int)((m + 31) / 32);
+    const size_t lds = (size_t)32 * (a.KP * es + 16) + 64 * 4 + (size_t)8 * 32 * 36 * 4;
+    const int blocks = cus * 3;
+    return f16 ? launch_nproj_t<_Float16>(a, blocks, lds, s) : launch_nproj_t<float>(a, blocks, lds, s);
+}
+
 int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, const float* gate, const void* w, int n,
                               const float* scale, const float* bias, const void* res, void* out, hipStream_t s, int act = ADAF_ACT_NONE) {
     const int v = dtype == ADAF_DTYPE_F16 ? 8 : 4;
     if (k % v || m <= 0 || n <= 0 || hw <= 0) return -1;
+    {
+        static const int cus = [] { int d = 0, c = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) c = p.multiProcessorCount; return c; }();
+        if (launch_narrow_project(x, dtype, m, hw, k, gate, w, n, scale, bias, res, out, act, cus, s)) return 1;
+    }
     ProjArgs a;
     a.x = x; a.gate = gate; a.w = w; a.scale = scale; a.bias = bias; a.res = res; a.out = out; a.M = m; a.N = n; a.K = k; a.HW = hw;
     a.act = act;

@@ -112,6 +112,22 @@ def test_tiny_map_depthwise_kernel_bit_identical_to_the_staged_one():
         assert abs(float(a[2]) - float(b[2])) <= 1e-3 * max(1.0, abs(float(b[2])))      # the squeeze sums: another summation order
 
 
+def test_narrow_project_strip_kernel_bit_identical_to_the_tiled_one():
+    """ef_nproj_kernel (blocks 0-1: K <= 64, N <= 32, millions of rows) against gated_project_kernel: same sha256 of the block
+    outputs in fp32 and fp16 storage, with and without the identity skip, on even and odd maps (tools/nproj_ab.py, two processes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "nproj_ab.py")], capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, ADAF_EF_NPROJ=mode))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 5])
+    assert len(outs[0]) == 8 and outs[0] == outs[1]
+
+
 def test_dwconv_same_rejects_bad_arguments(dev, ops):
     from adafocus_amd._lib import AdafError
     x = torch.zeros((1, 8, 8, 8), device=dev)
