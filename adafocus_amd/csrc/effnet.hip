@@ -1782,17 +1782,35 @@ int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, co
     ProjArgs a;
     a.x = x; a.gate = gate; a.w = w; a.scale = scale; a.bias = bias; a.res = res; a.out = out; a.M = m; a.N = n; a.K = k; a.HW = hw;
     a.act = act;
-    // column tile: the fewest padded columns, then the fewest column tiles (the A panel is re-read per column tile)
+    // column tile: the fewest padded columns, then the fewest column tiles (the A panel is re-read per column tile).  fp16 storage
+    // with enough row tiles to fill the device twice over: ONE column tile if 160 / 192 / 256 columns hold the layer -- every column
+    // tile re-reads AND re-gates the A panel (8 conversions + 8 multiplies + the repack per 16 bytes), the products are nearly free
+    // (blocks 14-17 of B3: N = 136 as five 32-wide tiles 120 us, as one 160-wide tile 100 us; with 200 row tiles, blocks 19-23, the
+    // single tile loses as much again, so they keep two).
+    static const int cus = [] { int d = 0, c = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) c = p.multiProcessorCount; return c; }();
+    static const int wide_on = [] { const char* e = getenv("ADAF_GP_WIDE"); return e ? atoi(e) : 1; }();       // 0 = the padding rule only (A/B)
     int best = 1, best_pad = 1 << 30;
     for (int tn = 1; tn <= 4; ++tn) {
         const int bn = 32 * tn, pad = (n + bn - 1) / bn * bn;
         if (pad < best_pad || (pad == best_pad && tn > best)) { best_pad = pad; best = tn; }
     }
+    if (wide_on && dtype == ADAF_DTYPE_F16 && (m + 127) / 128 >= 2 * cus && n > 32 * best) {
+        for (int tn : {5, 6, 8})
+            if (32 * tn >= n) { best = tn; break; }
+    }
     const dim3 block(256);
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 32 * best - 1) / (32 * best)));
 #define ADAF_GP(T, TN) hipLaunchKernelGGL((gated_project_kernel<T, TN>), grid, block, 0, s, a)
     if (dtype == ADAF_DTYPE_F16) {
-        if (best == 1) ADAF_GP(_Float16, 1); else if (best == 2) ADAF_GP(_Float16, 2); else if (best == 3) ADAF_GP(_Float16, 3); else ADAF_GP(_Float16, 4);
+        switch (best) {
+            case 1: ADAF_GP(_Float16, 1); break;
+            case 2: ADAF_GP(_Float16, 2); break;
+            case 3: ADAF_GP(_Float16, 3); break;
+            case 4: ADAF_GP(_Float16, 4); break;
+            case 5: ADAF_GP(_Float16, 5); break;
+            case 6: ADAF_GP(_Float16, 6); break;
+            default: ADAF_GP(_Float16, 8); break;
+        }
     } else {
         if (best == 1) ADAF_GP(float, 1); else if (best == 2) ADAF_GP(float, 2); else if (best == 3) ADAF_GP(float, 3); else ADAF_GP(float, 4);
     }
