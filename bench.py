@@ -370,7 +370,7 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the CPU baseline leg")
     ap.add_argument("--cpu-clips", type=int, default=None, help="(deprecated) 0 = skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--profile-steps", type=int, default=3, help="per-launch HIP-event passes for the roofline (median per launch)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="per-launch HIP-event passes for the roofline (median per launch)")
     ap.add_argument("--sustained-steps", type=int, default=240, help="extra soak after the timed region (>= 3 s); 0 = skip")
     ap.add_argument("--full", action="store_true", help="also time the full forward (glancer + policy + hot path)")
     ap.add_argument("--math", choices=["f32", "split_bf16"], default="f32",
