@@ -371,7 +371,7 @@ void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int strid
     const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
     const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
     // thread tile at stride 1: 4 x 4 outputs share 6 x 6 input chunks (2.25 loads per output; measured on the glancer's maps at
-    // 512 frames, ADAF_DW3_VARIANT: 4x2 (3 loads per output, round 2's shape) 3.7-4.4 TB/s, 2x2 3.2-4.2, 4x1 3.0-3.6, 7x2 3.8-4.5,
+    // 512 frames: 4x2 (3 loads per output, round 2's shape, still selectable with ADAF_DW3_VARIANT=0) 3.7-4.4 TB/s, 2x2 3.2-4.2, 4x1 3.0-3.6, 7x2 3.8-4.5,
     // 4x4 4.3-4.9 -- fewer, fatter threads with 36 independent loads in flight each win although 14 = 3.5 x 4 wastes an eighth of them)
     static const int var = [] { const char* e = getenv("ADAF_DW3_VARIANT"); return e ? atoi(e) : 4; }();
     if (stride == 1 && var == 4) {
