@@ -26,6 +26,23 @@ struct adaf_handle {
     std::string err;
 };
 
+// Process-wide tuning / A-B switches of the library (adaf_set_option / adaf_get_option in include/adafocus.h; defaults = the plan
+// every number in DESIGN.md is measured with).  They replace the environment variables of earlier rounds: tests flip them in-process.
+struct AdafOptions {
+    int conv_lean = 1;            // "conv_lean": scalar-base DMA / VALU-free K loops of the conv engine (conv_gemm.hip LEAN kernels)
+    double pm_fill = 0.96;        // "pm_fill": position-major tiles when the tap fill is below this fraction
+    int conv_pool = 1;            // "conv_pool": global average pool in the last conv3's epilogue
+    int resize_lds_kb = 20;       // "resize_lds_kb": staged rows per block of the resampling gather
+    int mb_wave = 1;              // "mb_wave": wave-private MBConv kernels of the MobileNetV2 glancer
+    int dw3_variant = 4;          // "dw3_variant": thread tile of the stand-alone depthwise 3x3 (0: 4x2, 1: 2x2, 2: 4x1, 3: 7x2, 4: 4x4)
+    int mbv2_chunk = 512;         // "mbv2_chunk": frames per chunk of the MobileNetV2 forward
+    int latency_rows = 1536;      // "latency_rows": GEMM rows up to which a new trunk sends convs to the small-batch form
+    int latency_linear_rows = 128;  // "latency_linear_rows": the same for adaf_linear / GRU projections
+    unsigned effnet_plan = 31u;   // "effnet_plan": ADAF_EF_PLAN_* bits
+    int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
+};
+AdafOptions& adaf_options();
+
 // Flattened description of one implicit-GEMM convolution launch.
 struct ConvArgs {
     const float* x;
@@ -102,6 +119,15 @@ bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
 bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw);
 void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s);
+
+// mbconv_whole.hip: whole-image MBConv blocks (EfficientNet, fp16 storage)
+size_t adaf_mbw_bfrag_halfs(int n, int k, bool even_tiles);
+void adaf_launch_pack_bfrag_f16(const float* w, int n, int k, bool even_tiles, void* o, hipStream_t s);
+bool adaf_mbw_eligible(int hw, int k, int stride, int cin, int hid, int cout, int sq);
+bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
+                              const float* be, const float* wd, const float* sd, const float* bd, const float* se_wr, const float* se_br,
+                              const float* se_wet, const float* se_be, const void* wpf, const float* sp, const float* bp, bool skip, void* out,
+                              hipStream_t s);
 
 // gru_scan.hip
 int adaf_gru_scan_blocks_per_cu();

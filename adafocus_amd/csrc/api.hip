@@ -70,6 +70,24 @@ int make_conv_args(adaf_handle* h, const adaf_conv_params* p, const float* x, co
 
 }  // namespace
 
+AdafOptions& adaf_options() {
+    static AdafOptions o;
+    return o;
+}
+
+namespace {
+struct OptKey { const char* name; int kind; double lo, hi; };      // kind: index into the switch of opt_ref
+const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
+                           {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
+                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 31}, {"effnet_chunk", 10, 1, 1 << 20}};
+const OptKey* find_opt(const char* key) {
+    if (!key) return nullptr;
+    for (const OptKey& k : kOptKeys)
+        if (!strcmp(k.name, key)) return &k;
+    return nullptr;
+}
+}  // namespace
+
 // ======================================================================================
 extern "C" {
 
@@ -126,6 +144,46 @@ int adaf_set_conv_pos_major(adaf_handle* h, int on) {
     h->conv_pos_major = on < 0 || on > 2 ? 1 : on;    // 2: position-major rows WITHOUT tap skipping (experiments)
     return ADAF_OK;
 }
+int adaf_set_option(adaf_handle* h, const char* key, double value) {
+    const OptKey* k = find_opt(key);
+    if (!k) return fail(h, ADAF_E_BADARG, "set_option: unknown key '%s'", key ? key : "(null)");
+    if (!(value >= k->lo && value <= k->hi)) return fail(h, ADAF_E_BADARG, "set_option: %s = %g is outside [%g, %g]", key, value, k->lo, k->hi);
+    AdafOptions& o = adaf_options();
+    switch (k->kind) {
+        case 0: o.conv_lean = (int)value; break;
+        case 1: o.pm_fill = value; break;
+        case 2: o.conv_pool = (int)value; break;
+        case 3: o.resize_lds_kb = (int)value; break;
+        case 4: o.mb_wave = (int)value; break;
+        case 5: o.dw3_variant = (int)value; break;
+        case 6: o.mbv2_chunk = (int)value; break;
+        case 7: o.latency_rows = (int)value; break;
+        case 8: o.latency_linear_rows = (int)value; break;
+        case 9: o.effnet_plan = (unsigned)value; break;
+        default: o.effnet_chunk = (int)value; break;
+    }
+    return ADAF_OK;
+}
+
+double adaf_get_option(const char* key) {
+    const OptKey* k = find_opt(key);
+    if (!k) return __builtin_nan("");
+    const AdafOptions& o = adaf_options();
+    switch (k->kind) {
+        case 0: return o.conv_lean;
+        case 1: return o.pm_fill;
+        case 2: return o.conv_pool;
+        case 3: return o.resize_lds_kb;
+        case 4: return o.mb_wave;
+        case 5: return o.dw3_variant;
+        case 6: return o.mbv2_chunk;
+        case 7: return o.latency_rows;
+        case 8: return o.latency_linear_rows;
+        case 9: return o.effnet_plan;
+        default: return o.effnet_chunk;
+    }
+}
+
 int adaf_set_gru_persistent(adaf_handle* h, int on) {
     if (!h) return ADAF_E_BADARG;
     if (on < 0 || on > 2) return fail(h, ADAF_E_BADARG, "set_gru_persistent: mode %d (0 off, 1 on, 2 on + cooperative launch)", on);
@@ -421,7 +479,7 @@ struct adaf_resnet50 {
     int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
     bool fuse = true;              // stage 1: conv2 -> conv3 (-> next conv1) in one launch; stem + max-pool in one launch
     bool fuse_stem_always = false; // (tests) take the fused stem launch at every patch size, not only where it is faster
-    int lat_rows = -1;             // convs with at most this many GEMM rows take the small-batch form (-1 = ADAF_LATENCY_ROWS / 1536)
+    int lat_rows = -1;             // convs with at most this many GEMM rows take the small-batch form (-1 = the "latency_rows" option, 1536)
     float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
     bool finalized = false;
 };
@@ -474,8 +532,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     // Small problems (BASELINE config 1: B*T = 16 patches -> 576 / 144 output pixels in stages 3 / 4): a conv whose GEMM has at most
     // `lat_rows` rows is as long as ONE accumulator chain on the engine, and runs on the latency form instead (conv_lat.hip:
     // v_mfma_f32_16x16x4_f32 chains, 3.2x shorter and bit-identical).  ADAF_LATENCY_ROWS: the row limit (0 = never).
-    static const int lat_rows_env = [] { const char* e = getenv("ADAF_LATENCY_ROWS"); return e ? atoi(e) : 1536; }();
-    const int lat_rows = net->lat_rows >= 0 ? net->lat_rows : lat_rows_env;
+    const int lat_rows = net->lat_rows >= 0 ? net->lat_rows : adaf_options().latency_rows;
     const bool lat_ok = lat_rows > 0 && tsm_T == 0 && net->math == ADAF_MATH_F32;
     const bool fuse = net->fuse;
     const size_t slab = adaf_resnet50_workspace_bytes(net, n, P) / (5 * sizeof(float));  // largest activation, floats
@@ -851,7 +908,7 @@ static int linear_launch(adaf_handle* h, const float* x, int rows, int ldx, int 
     if (rc) return rc;
     // a few rows (config 1's GRU projection: 16 x 3328 -> 3072) are one accumulator chain per block on the engine: the
     // small-batch form's chain is 3.2x shorter and bit-identical (conv_lat.hip; ADAF_LATENCY_LINEAR_ROWS, 0 = never)
-    static const int lat_rows = [] { const char* e = getenv("ADAF_LATENCY_LINEAR_ROWS"); return e ? atoi(e) : 128; }();
+    const int lat_rows = adaf_options().latency_linear_rows;
     if (rows <= lat_rows && in >= 512 && adaf_launch_conv_gemm(a, 95, h->cus, st) > 0) return ADAF_OK;
     if (adaf_launch_conv_gemm(a, 0, h->cus, st) < 0) return fail(h, ADAF_E_LAUNCH, "linear: no kernel for this shape");
     return ADAF_OK;

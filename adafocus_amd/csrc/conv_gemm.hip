@@ -1573,11 +1573,8 @@ struct TileShape { int bm, bn; float eff; };
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
     {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.02f}, {64, 64, 0.98f}, {64, 128, 0.99f}};
 
-// ADAF_CONV_LEAN=0 keeps the builtin-DMA K loop and the general epilogue (A/B measurements); 2 = lean forms for position-major tiles only
-static int conv_lean_enabled() {
-    static const int on = [] { const char* e = getenv("ADAF_CONV_LEAN"); return e ? atoi(e) : 1; }();
-    return on;
-}
+// option "conv_lean": 0 keeps the builtin-DMA K loop and the general epilogue (A/B measurements); 2 = lean forms for position-major tiles only
+static int conv_lean_enabled() { return adaf_options().conv_lean; }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
@@ -1624,11 +1621,8 @@ static double conv_tap_fill(const ConvArgs& a) {
     return (double)(axis(a.OH, a.H, a.KH) * axis(a.OW, a.W, a.KW)) / ((double)a.OH * a.OW * a.KH * a.KW);
 }
 
-// position-major tiles are used when less than this share of the filter taps touches the image (ADAF_PM_FILL overrides, experiments)
-static double conv_pm_fill_threshold() {
-    static const double t = [] { const char* e = getenv("ADAF_PM_FILL"); return e ? atof(e) : 0.96; }();
-    return t;
-}
+// position-major tiles are used when less than this share of the filter taps touches the image (option "pm_fill", experiments)
+static double conv_pm_fill_threshold() { return adaf_options().pm_fill; }
 
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
@@ -1837,7 +1831,7 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
 // The trunk's last conv3 with the global average pool in its epilogue (conv_epilogue_pool): 1x1 / stride 1 fp32, images of `hw`
 // pixels that fill a 128-row tile to >= 90 % (hw = 9 at 96^2 patches: 14 images = 126 rows; 16 at 128^2; 25 at 144^2).
 int adaf_launch_conv_pool(ConvArgs a, int hw, float* pool_out, int pool_ld, hipStream_t s) {
-    static const int on = [] { const char* e = getenv("ADAF_CONV_POOL"); return e ? atoi(e) : 1; }();      // 0 = conv + separate avgpool_kernel (A/B)
+    const int on = adaf_options().conv_pool;      // 0 = conv + separate avgpool_kernel (A/B)
     if (!on || !conv_lean_enabled() || conv_lean_enabled() != 1) return 0;
     if (a.in16 || a.out16 || a.res16 || a.split_n || a.tsm_T > 0 || a.wsp) return 0;
     if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || (a.K & 31) || (a.N & 3) || !a.vec_epi) return 0;

@@ -74,79 +74,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-// ---- the tap loop and the output epilogue of a thread item, as functions -----------------------------------------------------
-// (used by the two opt-in kernels -- the pipelined and the fused form; the default dw_same_kernel keeps the same code written out
-// in place: routed through these functions it measured 2.5 % slower on the fp16 network, 11.5 vs 11.2 ms, from different
-// register allocation around the inlined bodies)
-// One thread item = OXT horizontally adjacent outputs x V channels.  `rowp` points at the item's first staged input pixel (its
-// 16-byte chunk), rows are `rowstride` bytes apart, pixels `pitchB`; `wl` holds the slice's taps [K*K][CS] in LDS, `wofs` = the
-// thread's first channel inside the slice.  Per filter row the K taps sit in registers and every staged column is read and
-// converted ONCE: column ci feeds output o through tap kx = ci - o S, resolved at compile time.
-template <int K, int S, int OXT, typename T>
-__device__ __forceinline__ void dw_taps(const char* rowp, int rowstride, int pitchB, const float* wl, int CS, int wofs,
-                                        float (&acc)[OXT][Chunk<T>::V]) {
-    constexpr int V = Chunk<T>::V;
-    constexpr int NC = (OXT - 1) * S + K;
-#pragma unroll
-    for (int o = 0; o < OXT; ++o)
-#pragma unroll
-        for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
-#pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {
-        float w[K][V];
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const float* wp = wl + (ky * K + kx) * CS + wofs;
-#pragma unroll
-            for (int e = 0; e < V; e += 4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + e);
-                w[kx][e] = w4.x; w[kx][e + 1] = w4.y; w[kx][e + 2] = w4.z; w[kx][e + 3] = w4.w;
-            }
-        }
-#pragma unroll
-        for (int ci = 0; ci < NC; ++ci) {
-            float xf[V];
-            Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(rowp + ci * pitchB), xf);
-#pragma unroll
-            for (int o = 0; o < OXT; ++o) {
-                const int kx = ci - o * S;
-                if (kx >= 0 && kx < K) {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) acc[o][e] = fmaf(xf[e], w[kx][e], acc[o][e]);
-                }
-            }
-        }
-        rowp += rowstride;
-    }
-}
-
-// BN affine (scale at sbl[wofs..], bias at sbl[CS + wofs..]) + activation, the squeeze partial sums, 16-byte stores of the
-// item's outputs that exist (`nvalid` of OXT), `ostep` elements apart.
-template <int OXT, typename T>
-__device__ __forceinline__ void dw_emit(float (&acc)[OXT][Chunk<T>::V], const float* sbl, int CS, int wofs, int act, int nvalid, T* op,
-                                        int ostep, float (&psum)[Chunk<T>::V]) {
-    constexpr int V = Chunk<T>::V;
-    float sc[V], bi[V];
-#pragma unroll
-    for (int e = 0; e < V; e += 4) {
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sbl + wofs + e), b4 = *reinterpret_cast<const f32x4*>(sbl + CS + wofs + e);
-        sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
-        bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
-    }
-#pragma unroll
-    for (int o = 0; o < OXT; ++o) {
-        if (o < nvalid) {
-            float v[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), act);
-                psum[e] += v[e];
-            }
-            *reinterpret_cast<u32x4*>(op + o * ostep) = Chunk<T>::pack(v);
-        }
-    }
-}
-
 // ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
 // A block owns IMB images x one channel slice (CS = LPP 16-byte chunks) x TH output rows.  Its input rows (with the padding
 // columns, zero-filled) are staged once in LDS; then thread (image, channel chunk cg, pixel-group lane pg) walks the
@@ -172,10 +99,7 @@ struct DwArgs {
     int WP;              // staged columns: (TWG * OXT - 1) * S + K
     int IMB, PG;         // images per block, pixel-group lanes per (image, channel chunk): IMB * PG * LPP <= 256
     int igroups;         // ceil(n / IMB)
-    // pipelined (persistent, double-buffered) form
-    const float* zeros;  // >= 16 bytes of zeros: source of the staged chunks that fall outside the image
-    int tile_bytes;      // bytes of one staged buffer: IMB * ihmax * WP * LPP chunks rounded up to 256 chunks
-    int total;           // work items: igroups * tiles * slices
+    int total;           // work items (= blocks): igroups * tiles * slices
 };
 
 template <int K, int S, int OXT, typename T>
@@ -431,298 +355,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         }
     }
     if (a.pool_part) *reinterpret_cast<f32x4*>(a.pool_part + (size_t)img * a.C + 4 * cq) = psum;
-}
-
-// ---- the same work as dw_same_kernel, software-pipelined ----------------------------------------------------------------
-// Measured on the first version (one tile per block: load -> barrier -> taps -> store): every layer ran at 2-3 TB/s whatever the
-// tile size or the number of resident blocks, because a block spends its load phase, its tap phase and its store phase one after
-// the other and three or four such blocks per CU do not cover each other.  Here a PERSISTENT block walks its work items with two
-// staged buffers: while the taps of item i run out of one buffer, the chunks of item i+1 travel straight from global memory into
-// the other one by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass; chunks outside the image come from a block
-// of zeros, so there is no select either), one barrier per item.  The DMA writes 64 consecutive 16-byte chunks per wave
-// instruction, so the staged image is dense (pixel pitch = LPP chunks) in the order (image, row, column, chunk).
-template <int K, int S, int OXT, typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void dw_same_pipe_kernel(const DwArgs a) {
-    constexpr int V = Chunk<T>::V;
-    constexpr int WFL = (K * K + 2);         // weight rows per slice: taps + BN scale + BN bias
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pitchB = a.LPP * 16;
-    const int ihmax = (a.TH - 1) * S + K;
-    const int img_lds = ihmax * a.WP * pitchB;
-    char* bufs[2] = {dsm, dsm + a.tile_bytes};
-    float* wls[2] = {reinterpret_cast<float*>(dsm + 2 * (size_t)a.tile_bytes), reinterpret_cast<float*>(dsm + 2 * (size_t)a.tile_bytes) + WFL * a.CS};
-    float* red = wls[1] + WFL * a.CS;        // [256][V]
-    const int nk = a.tile_bytes >> 12;       // DMA instructions per wave per item (256 chunks = 4 KB per block-wide pass)
-    // per-lane walk over the chunk index q = tid, tid + 256, ...: (chunk in pixel, pixel) -> (column, row, image)
-    const int cg0 = tid % a.LPP, p0 = tid / a.LPP;
-    const int dcg = 256 % a.LPP, dp = 256 / a.LPP;
-    const int col0 = p0 % a.WP, t0 = p0 / a.WP;
-    const int row0 = t0 % ihmax, im0 = t0 / ihmax;
-    const int dcol = dp % a.WP, dt = dp / a.WP;
-    const int drow = dt % ihmax, dim = dt / ihmax;
-    const T* xall = static_cast<const T*>(a.x);
-
-    auto decode = [&](int w, int& slice, int& tile, int& img0) {
-        slice = w % a.slices;
-        const int r = w / a.slices;
-        tile = r % a.tiles;
-        img0 = (r / a.tiles) * a.IMB;
-    };
-    auto issue = [&](int w, int b) {
-        int slice, tile, img0;
-        decode(w, slice, tile, img0);
-        const int nimg = min(a.IMB, a.n - img0);
-        const int c0 = slice * a.CS;
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int iy0 = ty * a.TH * S - a.pad_t, ix0 = tx * a.TWG * OXT * S - a.pad_l;
-        int cg = cg0, col = col0, row = row0, im = im0;
-        char* dst = bufs[b] + wave * 1024;
-        for (int k = 0; k < nk; ++k) {
-            const int iy = iy0 + row, ix = ix0 + col;
-            const bool ok = im < nimg && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const T* src = ok ? xall + (((size_t)(img0 + im) * a.H + iy) * a.W + ix) * a.C + c0 + cg * V : reinterpret_cast<const T*>(a.zeros);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + k * 4096), 16, 0, 0);
-            // next chunk of this lane: q += 256
-            cg += dcg; col += dcol; row += drow; im += dim;
-            if (cg >= a.LPP) { cg -= a.LPP; ++col; }
-            if (col >= a.WP) { col -= a.WP; ++row; }
-            if (row >= ihmax) { row -= ihmax; ++im; }
-        }
-        float* wl = wls[b];
-        for (int i = tid; i < K * K * a.CS; i += 256) {
-            const int tap = i / a.CS;
-            wl[i] = a.wt[(size_t)tap * a.C + c0 + (i - tap * a.CS)];
-        }
-        for (int i = tid; i < 2 * a.CS; i += 256) wl[K * K * a.CS + i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
-    };
-
-    const int TPI = a.LPP * a.PG;
-    const int im = tid / TPI, rem = tid - im * TPI;
-    const int cg = rem % a.LPP, pg = rem / a.LPP;
-    int w = blockIdx.x;
-    if (w < a.total) issue(w, 0);
-    for (int it = 0; w < a.total; ++it, w += gridDim.x) {
-        const int b = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA for item w has landed (and its earlier stores have left)
-        __syncthreads();                                       // ... everyone's has; everyone is done with the other buffer
-        if (w + (int)gridDim.x < a.total) issue(w + gridDim.x, b ^ 1);
-        int slice, tile, img0;
-        decode(w, slice, tile, img0);
-        const int nimg = min(a.IMB, a.n - img0);
-        const int c0 = slice * a.CS;
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int oy0 = ty * a.TH;
-        const int th = min(a.TH, a.OH - oy0);
-        const int xg0 = tx * a.TWG;
-        const float* wl = wls[b];
-        const float* sbl = wl + K * K * a.CS;
-        float psum[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) psum[e] = 0.f;
-        if (im < nimg) {
-            const int nxg = min(a.TWG, (a.OW + OXT - 1) / OXT - xg0);
-            const int dxg = a.PG % nxg, dr = a.PG / nxg;
-            int xg = pg % nxg, r = pg / nxg;
-            T* ob = static_cast<T*>(a.out) + ((size_t)(img0 + im) * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
-            const char* xim = bufs[b] + (size_t)im * img_lds + cg * 16;
-            while (r < th) {
-                const int ox0 = (xg0 + xg) * OXT;
-                float acc[OXT][V];
-                dw_taps<K, S, OXT, T>(xim + (r * S * a.WP + xg * OXT * S) * pitchB, a.WP * pitchB, pitchB, wl, a.CS, cg * V, acc);
-                dw_emit<OXT, T>(acc, sbl, a.CS, cg * V, a.act, a.OW - ox0, ob + (r * a.OW + ox0) * a.C, a.C, psum);
-                xg += dxg; r += dr;
-                if (xg >= nxg) { xg -= nxg; ++r; }
-            }
-        }
-        if (a.pool_part) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) red[tid * V + e] = psum[e];
-            __syncthreads();
-            for (int t = tid; t < nimg * a.CS; t += 256) {
-                const int ri = t / a.CS, c = t - ri * a.CS;
-                const int g = c / V, e = c % V;
-                float s = 0.f;
-                for (int q = 0; q < a.PG; ++q) s += red[(ri * TPI + q * a.LPP + g) * V + e];
-                a.pool_part[((size_t)(img0 + ri) * a.tiles + tile) * a.C + c0 + c] = s;
-            }
-            // (the next iteration's barrier separates these reads of `red` from its next writes)
-        }
-    }
-}
-
-// ---- fused expand 1x1 (+BN+swish) -> depthwise k x k (+BN+swish) + squeeze partial sums ---------------------------------
-// For the blocks whose input is narrow (cin <= 64: blocks 2..7 of B3), so that the 6x-expanded map never exists in HBM -- it is
-// the largest tensor of the network (1.5 GB per 1024 patches in block 2 alone) and would be written by one launch only to be
-// read back by the next.  A block owns one image x one output tile x one slice of HS = 32 TN hidden channels:
-//   phase 0  the input pixels the tile's depthwise windows touch (halo included) go to LDS once, k padded to a whole MFMA step
-//            (zeros), together with the slice's rows of the expand filter and a per-pixel "inside the image" flag;
-//   phase 1  expand on the matrix cores: bands of 32 staged pixels x the slice's channels, the SAME instruction and k order as
-//            the stand-alone expand launch (v_mfma_f32_32x32x2_f32 over k, or v_mfma_f32_32x32x16_f16), BN affine + swish in the
-//            epilogue, rounded to the storage type, pixels outside the image forced to 0 (the depthwise conv pads the EXPANDED
-//            map), into the LDS image E[pixel][HS];
-//   phase 2  the depthwise taps out of E exactly as dw_same_kernel does them, the squeeze partial sums, the stores.
-// Every value is produced by the same arithmetic in the same order as by the two-launch plan: the results are bit-identical
-// (tests/test_effnet.py::test_b3_fused_expand_dw_bit_identical).  Halo pixels are expanded more than once (1.13x at 8x8
-// stride-2 tiles, 1.4-1.6x at stride 1); the expand is a few per cent of the block's work on the fp16 pipe.
-struct EfFuseArgs {
-    const void* x;        // [n][H][W][cin]
-    const void* we;       // [hid][cin] expand filter (storage type)
-    const float* se;      // [hid] expand BN
-    const float* be;
-    const float* wd;      // [K*K][hid] depthwise taps
-    const float* sd;      // [hid] depthwise BN
-    const float* bd;
-    void* out;            // [n][OH][OW][hid]
-    float* pool_part;     // [n][tiles][hid]
-    int n, H, W, cin, hid, OH, OW, pad_t, pad_l, act;
-    int TH, TWG, tiles_x, tiles, slices;
-    int NPW, NPH;         // staged pixels per row / rows
-    int KP;               // cin padded to a whole MFMA k step (elements)
-};
-
-template <int K, int S, int OXT, typename T, int TN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 : 4, 8))) void ef_expand_dw_kernel(const EfFuseArgs a) {
-    constexpr int V = Chunk<T>::V;
-    constexpr int HS = 32 * TN, LPP = HS / V;
-    constexpr int KSTEP = sizeof(T) == 2 ? 16 : 8;        // k elements per 16-byte-per-lane step
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int slice = bid % a.slices; bid /= a.slices;
-    const int tile = bid % a.tiles;
-    const int img = bid / a.tiles;
-    const int c0 = slice * HS;
-    const int cvalid = min(LPP, (a.hid - c0) / V);        // 16-byte chunks of this slice that exist
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * a.TH, xg0 = tx * a.TWG;
-    const int th = min(a.TH, a.OH - oy0);
-    const int iy0 = oy0 * S - a.pad_t, ix0 = xg0 * OXT * S - a.pad_l;
-    const int NP = a.NPW * a.NPH;
-    const int NB = (NP + 31) >> 5;                        // 32-pixel bands
-    const int xpitch = a.KP * (int)sizeof(T) + 16;        // bytes per staged pixel / filter row (+16: the 32 rows a fragment read
-    const int epitch = HS * (int)sizeof(T) + 16;          //  touches start in different banks)
-    char* xl = dsm;                                                   // [NB*32][xpitch]
-    char* wel = xl + (size_t)NB * 32 * xpitch;                        // [HS][xpitch]
-    char* el = wel + (size_t)HS * xpitch;                             // [NB*32][epitch]
-    float* wl = reinterpret_cast<float*>(el + (size_t)NB * 32 * epitch);   // [K*K][HS] taps
-    float* sbl = wl + K * K * HS;                                     // [4][HS]: dw scale, dw bias, expand scale, expand bias
-    unsigned char* inside = reinterpret_cast<unsigned char*>(sbl + 4 * HS);   // [NB*32]
-
-    // ---- phase 0 ----
-    const int CPP = xpitch / 16 - 1;                       // 16-byte chunks per padded pixel row
-    const int cin_chunks = a.cin / V;
-    {
-        const T* xb = static_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.cin;
-        for (int i = tid; i < NB * 32 * CPP; i += 256) {
-            const int p = i / CPP, c = i - p * CPP;
-            const int py = p / a.NPW, px = p - py * a.NPW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool in = p < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (in && c < cin_chunks) v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + ix) * a.cin + c * V);
-            *reinterpret_cast<u32x4*>(xl + (size_t)p * xpitch + c * 16) = v;
-            if (c == 0) inside[p] = in ? 1 : 0;
-        }
-        const T* wb = static_cast<const T*>(a.we);
-        for (int i = tid; i < HS * CPP; i += 256) {
-            const int h = i / CPP, c = i - h * CPP;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (c0 + h < a.hid && c < cin_chunks) v = *reinterpret_cast<const u32x4*>(wb + (size_t)(c0 + h) * a.cin + c * V);
-            *reinterpret_cast<u32x4*>(wel + (size_t)h * xpitch + c * 16) = v;
-        }
-        for (int i = tid; i < K * K * HS; i += 256) {
-            const int tap = i / HS, h = i - tap * HS;
-            wl[i] = c0 + h < a.hid ? a.wd[(size_t)tap * a.hid + c0 + h] : 0.f;
-        }
-        for (int i = tid; i < 4 * HS; i += 256) {
-            const int which = i / HS, h = i - which * HS;
-            const float* src = which == 0 ? a.sd : which == 1 ? a.bd : which == 2 ? a.se : a.be;
-            sbl[i] = c0 + h < a.hid ? src[c0 + h] : 0.f;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 1: E = act(BN(X We^T)) for every staged pixel ----
-    {
-        const int nl = lane & 31, half = lane >> 5;
-        const int ksteps = a.KP / KSTEP;
-        for (int band = wave; band < NB; band += 4) {
-            f32x16 acc[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-            const char* arow = xl + (size_t)(band * 32 + nl) * xpitch + half * 16;
-            for (int kk = 0; kk < ksteps; ++kk) {
-                const f32x4 af = *reinterpret_cast<const f32x4*>(arow + kk * 32);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x4 bf = *reinterpret_cast<const f32x4*>(wel + (size_t)(j * 32 + nl) * xpitch + half * 16 + kk * 32);
-                    if constexpr (sizeof(T) == 2) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf), acc[j], 0, 0, 0);
-                    } else {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[j], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int h = j * 32 + nl;
-                const float sc = sbl[2 * HS + h], bi = sbl[3 * HS + h];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int p = band * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    const float v = inside[p] ? act_apply(fmaf(acc[j][i], sc, bi), a.act) : 0.f;
-                    *reinterpret_cast<T*>(el + (size_t)p * epitch + h * sizeof(T)) = (T)v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: depthwise taps out of E ----
-    const int nxg = min(a.TWG, (a.OW + OXT - 1) / OXT - xg0);
-    const int groups = th * nxg;
-    const int PG = 256 / LPP;
-    const int cg = tid % LPP, pg = tid / LPP;
-    float psum[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) psum[e] = 0.f;
-    if (cg < cvalid && pg < PG) {
-        T* ob = static_cast<T*>(a.out) + ((size_t)img * a.OH + oy0) * a.OW * a.hid + c0 + cg * V;
-        const char* xim = el + cg * 16;
-        for (int g = pg; g < groups; g += PG) {
-            const int r = g / nxg, xg = g - r * nxg;
-            const int ox0 = (xg0 + xg) * OXT;
-            float acc[OXT][V];
-            dw_taps<K, S, OXT, T>(xim + (r * S * a.NPW + xg * OXT * S) * epitch, a.NPW * epitch, epitch, wl, HS, cg * V, acc);
-            dw_emit<OXT, T>(acc, sbl, HS, cg * V, a.act, a.OW - ox0, ob + (r * a.OW + ox0) * a.hid, a.hid, psum);
-        }
-    }
-    if (a.pool_part) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(dsm);      // [256][V] (the staged input is dead)
-#pragma unroll
-        for (int e = 0; e < V; ++e) red[tid * V + e] = psum[e];
-        __syncthreads();
-        if (tid < cvalid * V) {
-            const int g = tid / V, e = tid % V;
-            float s = 0.f;
-            for (int q = 0; q < PG; ++q) s += red[(q * LPP + g) * V + e];
-            a.pool_part[((size_t)img * a.tiles + tile) * a.hid + c0 + tid] = s;
-        }
-    }
 }
 
 // ---- expand 1x1 (+BN+activation) for narrow inputs (cin <= 64: blocks 2..8 of B3) ------------------------------------------
@@ -1419,33 +1051,17 @@ __global__ void avgpool_any_kernel(const T* __restrict__ x, int n, int hw, int c
 }
 
 // ---- launch planning ---------------------------------------------------------------------------------------------------
-struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, TWG, tiles_y, tiles_x, tiles, IMB, PG; size_t lds; int tile_bytes; bool pipe; };
+struct DwPlan { int V, LPP, CS, slices, OXT, WP, pitch16, TH, TWG, tiles_y, tiles_x, tiles, IMB, PG; size_t lds; };
 
-// ADAF_DW_PIPE=1 selects the persistent double-buffered kernel (measured SLOWER than the one-tile-per-block form: 16.3 vs 12.0 ms
-// for the fp16 network -- kept as the A/B arm that showed the layers are not bound by exposed load latency); default 0
-static int dw_pipe_enabled() {
-    static const int on = [] { const char* e = getenv("ADAF_DW_PIPE"); return e ? atoi(e) : 0; }();
-    return on;
-}
-static size_t dw_pipe_tile_budget() {
-    static const size_t b = [] { const char* e = getenv("ADAF_DW_PIPE_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 28) * 1024; }();
-    return b;
-}
-
-// LDS per block the tile planner may spend (ADAF_DW_LDS_KB overrides, for tuning): the tile size trades halo re-reads and
-// per-block overhead against the number of blocks a CU can hold, i.e. the loads in flight
-static size_t dw_lds_budget() {
-    static const size_t b = [] { const char* e = getenv("ADAF_DW_LDS_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 48) * 1024; }();
-    return b;
-}
-#define kDwLdsBudget dw_lds_budget()
+// LDS per block the tile planner may spend: the tile size trades halo re-reads and per-block overhead against the number of blocks
+// a CU can hold, i.e. the loads in flight (measured on the fp16 network, 12 / 20 / 32 / 48 / 64 KB: 16.0 / 12.6 / 12.0 / 12.0 / 12.4 ms)
+constexpr size_t kDwLdsBudget = 48 * 1024;
 
 // Tile = TH output rows x TWG groups of OXT outputs, of IMB images, for one channel slice.  Chosen by a small cost model:
 // per output, (staged input chunks x the cost of a load + LDS store) + (thread passes x the tap work of a pass), the passes
 // counted with their idle lanes -- a tile whose items do not fill the block's lanes pays for the empty ones.
 bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
-    p->pipe = dw_pipe_enabled() != 0;
-    const size_t budget = p->pipe ? dw_pipe_tile_budget() : kDwLdsBudget;
+    const size_t budget = kDwLdsBudget;
     p->V = 16 / esize;
     if (C % p->V) return false;
     const int chunks = C / p->V;
@@ -1456,8 +1072,8 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     p->slices = C / p->CS;
     p->OXT = OW % 4 == 0 ? 4 : OW % 3 == 0 ? 3 : OW % 5 == 0 ? 5 : 4;
     const int nxg = (OW + p->OXT - 1) / p->OXT;
-    p->pitch16 = p->pipe ? p->LPP : (p->LPP | 1);  // odd pitch: consecutive pixels start in different bank groups (the DMA form is dense)
-    const size_t fixed = p->pipe ? 0 : (size_t)(K * K + 2) * p->CS * 4;
+    p->pitch16 = p->LPP | 1;                       // odd pitch: consecutive pixels start in different bank groups
+    const size_t fixed = (size_t)(K * K + 2) * p->CS * 4;
     const int lanes = 256 / p->LPP;
     auto img_bytes = [&](int th, int twg) { return (size_t)((th - 1) * S + K) * ((twg * p->OXT - 1) * S + K) * p->pitch16 * 16; };
     double best = 1e300;
@@ -1486,43 +1102,28 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     p->WP = (p->TWG * p->OXT - 1) * S + K;
     p->lds = (size_t)p->IMB * img_bytes(p->TH, p->TWG) + fixed;
     const size_t red = (size_t)256 * p->V * 4;
-    if (p->pipe) {
-        p->tile_bytes = (int)(((size_t)p->IMB * img_bytes(p->TH, p->TWG) + 4095) / 4096 * 4096);
-        p->lds = 2 * (size_t)p->tile_bytes + 2 * (size_t)(K * K + 2) * p->CS * 4 + red;
-    } else if (p->lds < red) p->lds = red;
+    if (p->lds < red) p->lds = red;
     return true;
 }
 
 template <int K, int S, int OXT, typename T>
-void launch_dw_one(const DwArgs& a, bool pipe, size_t lds, int cus, hipStream_t s) {
-    if (pipe) {
-        static bool attr_set = false;
-        if (!attr_set) {      // dynamic LDS above 64 KB has to be asked for
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_same_pipe_kernel<K, S, OXT, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        int per_cu = (int)((160 * 1024) / lds);
-        per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-        const int grid = a.total < cus * per_cu ? a.total : cus * per_cu;
-        hipLaunchKernelGGL((dw_same_pipe_kernel<K, S, OXT, T>), dim3(grid), dim3(256), lds, s, a);
-    } else {
-        hipLaunchKernelGGL((dw_same_kernel<K, S, OXT, T>), dim3((unsigned)a.total), dim3(256), lds, s, a);
-    }
+void launch_dw_one(const DwArgs& a, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((dw_same_kernel<K, S, OXT, T>), dim3((unsigned)a.total), dim3(256), lds, s, a);
 }
 
 template <int K, int S, typename T>
-void launch_dw_oxt(const DwArgs& a, int oxt, bool pipe, size_t lds, int cus, hipStream_t s) {
-    if (oxt == 3) launch_dw_one<K, S, 3, T>(a, pipe, lds, cus, s);
-    else if (oxt == 5) launch_dw_one<K, S, 5, T>(a, pipe, lds, cus, s);
-    else launch_dw_one<K, S, 4, T>(a, pipe, lds, cus, s);
+void launch_dw_oxt(const DwArgs& a, int oxt, size_t lds, hipStream_t s) {
+    if (oxt == 3) launch_dw_one<K, S, 3, T>(a, lds, s);
+    else if (oxt == 5) launch_dw_one<K, S, 5, T>(a, lds, s);
+    else launch_dw_one<K, S, 4, T>(a, lds, s);
 }
 
 template <typename T>
-bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, bool pipe, size_t lds, int cus, hipStream_t s) {
-    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T>(a, oxt, pipe, lds, cus, s);
-    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T>(a, oxt, pipe, lds, cus, s);
-    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T>(a, oxt, pipe, lds, cus, s);
-    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T>(a, oxt, pipe, lds, cus, s);
+bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, size_t lds, hipStream_t s) {
+    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T>(a, oxt, lds, s);
+    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T>(a, oxt, lds, s);
+    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T>(a, oxt, lds, s);
+    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T>(a, oxt, lds, s);
     else return false;
     return true;
 }
@@ -1555,8 +1156,8 @@ int adaf_effnet_dw_tiles(int c, int oh, int ow, int k, int stride, int dtype) {
 
 int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, int pad_t, int pad_l, int oh,
                         int ow, const float* wt, const float* scale, const float* bias, int act, void* out, float* pool_part,
-                        const float* zeros, int cus, hipStream_t s) {
-    static const int small_on = [] { const char* e = getenv("ADAF_DW_SMALL"); return e ? atoi(e) : 1; }();     // 0 = dw_same_kernel everywhere (A/B)
+                        hipStream_t s) {
+    const bool small_on = (adaf_options().effnet_plan & ADAF_EF_PLAN_TINY_DW) != 0;       // off = dw_same_kernel everywhere (A/B)
     if (small_on && stride == 1 && hh == ww && hh >= 3 && hh <= 5 && oh == hh && ow == ww && pad_t == (k - 1) / 2 && pad_l == pad_t && c % 4 == 0) {
         DsArgs b;
         b.x = x; b.out = out; b.wt = wt; b.scale = scale; b.bias = bias; b.pool_part = pool_part; b.n = n; b.C = c; b.act = act;
@@ -1571,111 +1172,9 @@ int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, 
     a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
     a.pitch16 = p.pitch16; a.WP = p.WP;
     a.IMB = p.IMB; a.PG = p.PG; a.igroups = (n + p.IMB - 1) / p.IMB;
-    a.zeros = zeros; a.tile_bytes = p.tile_bytes; a.total = a.igroups * a.tiles * a.slices;
-    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.pipe, p.lds, cus, s)
-                                            : launch_dw_t<float>(a, k, stride, p.OXT, p.pipe, p.lds, cus, s);
-    return ok ? p.tiles : -1;
-}
-
-// ---- fused expand -> depthwise: planning and launch ---------------------------------------------------------------------
-namespace {
-struct EfPlan { int OXT, TN, HS, slices, KP, TH, TWG, tiles_x, tiles_y, tiles, NPW, NPH; size_t lds; };
-
-static size_t ef_lds_budget() {
-    static const size_t b = [] { const char* e = getenv("ADAF_EF_LDS_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 ? v : 52) * 1024; }();
-    return b;
-}
-
-bool plan_ef(int cin, int hid, int OH, int OW, int K, int S, int esize, EfPlan* p) {
-    const int V = 16 / esize;
-    if (cin % V || hid % V || cin > 64) return false;
-    const int kstep = esize == 2 ? 16 : 8;
-    p->KP = (cin + kstep - 1) / kstep * kstep;
-    p->TN = (esize == 2 && hid % 64 == 0) ? 2 : 1;
-    p->HS = 32 * p->TN;
-    p->slices = (hid + p->HS - 1) / p->HS;
-    // outputs per thread along x: the fused kernel's tiles are small (the expanded tile has to fit LDS), so a thread takes as
-    // few outputs as it needs for the block's 256 lanes to be busy in the depthwise phase (ADAF_EF_OXT overrides, tuning)
-    static const int oxt_env = [] { const char* e = getenv("ADAF_EF_OXT"); return e ? atoi(e) : 0; }();
-    p->OXT = oxt_env > 0 ? oxt_env : (S == 2 ? 1 : 2);
-    const int nxg = (OW + p->OXT - 1) / p->OXT;
-    const int LPP = p->HS / V;
-    const size_t xpitch = (size_t)p->KP * esize + 16, epitch = (size_t)p->HS * esize + 16;
-    auto lds = [&](int th, int twg) {
-        const int npw = (twg * p->OXT - 1) * S + K, nph = (th - 1) * S + K;
-        const size_t nb32 = (size_t)((npw * nph + 31) / 32) * 32;
-        return nb32 * (xpitch + epitch + 1) + p->HS * xpitch + (size_t)(K * K + 4) * p->HS * 4;
-    };
-    long best = -1;
-    p->TH = 0;
-    for (int th = 1; th <= OH; ++th) {
-        const int ty = (OH + th - 1) / th;
-        if ((OH + ty - 1) / ty != th) continue;
-        for (int twg = 1; twg <= nxg; ++twg) {
-            const int tx = (nxg + twg - 1) / twg;
-            if ((nxg + tx - 1) / tx != twg) continue;
-            if (lds(th, twg) > ef_lds_budget()) break;
-            // the more outputs per staged pixel the better (less halo to expand again); among equals, tiles whose depthwise
-            // phase fills the block's lanes
-            const int groups = th * twg, lanes = 256 / LPP;
-            const int passes = (groups + lanes - 1) / lanes;
-            const int npw = (twg * p->OXT - 1) * S + K, nph = (th - 1) * S + K;
-            const long score = (long)(1000.0 * (double)(groups * p->OXT) / (double)(npw * nph) * ((double)groups / (double)(passes * lanes) * 0.5 + 0.5));
-            if (score > best) { best = score; p->TH = th; p->TWG = twg; p->tiles_y = ty; p->tiles_x = tx; }
-        }
-    }
-    if (p->TH == 0) return false;
-    p->tiles = p->tiles_x * p->tiles_y;
-    p->NPW = (p->TWG * p->OXT - 1) * S + K;
-    p->NPH = (p->TH - 1) * S + K;
-    p->lds = lds(p->TH, p->TWG);
-    const size_t red = (size_t)256 * V * 4;
-    if (p->lds < red) p->lds = red;
-    return true;
-}
-
-template <int K, int S, int OXT, typename T>
-void launch_ef_tn(const EfFuseArgs& a, int tn, unsigned grid, size_t lds, hipStream_t s) {
-    if (tn == 2) hipLaunchKernelGGL((ef_expand_dw_kernel<K, S, OXT, T, 2>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((ef_expand_dw_kernel<K, S, OXT, T, 1>), dim3(grid), dim3(256), lds, s, a);
-}
-template <int K, int S, typename T>
-void launch_ef_oxt(const EfFuseArgs& a, int oxt, int tn, unsigned grid, size_t lds, hipStream_t s) {
-    if (oxt == 1) launch_ef_tn<K, S, 1, T>(a, tn, grid, lds, s);
-    else if (oxt == 2) launch_ef_tn<K, S, 2, T>(a, tn, grid, lds, s);
-    else launch_ef_tn<K, S, 4, T>(a, tn, grid, lds, s);
-}
-template <typename T>
-bool launch_ef_t(const EfFuseArgs& a, int K, int S, int oxt, int tn, unsigned grid, size_t lds, hipStream_t s) {
-    if (K == 3 && S == 1) launch_ef_oxt<3, 1, T>(a, oxt, tn, grid, lds, s);
-    else if (K == 3 && S == 2) launch_ef_oxt<3, 2, T>(a, oxt, tn, grid, lds, s);
-    else if (K == 5 && S == 1) launch_ef_oxt<5, 1, T>(a, oxt, tn, grid, lds, s);
-    else if (K == 5 && S == 2) launch_ef_oxt<5, 2, T>(a, oxt, tn, grid, lds, s);
-    else return false;
-    return true;
-}
-}  // namespace
-
-// tiles per image of the fused launch's squeeze partial sums (> 0), or < 0 when the shape is not eligible
-int adaf_effnet_ef_tiles(int cin, int hid, int oh, int ow, int k, int stride, int dtype) {
-    EfPlan p;
-    if (!plan_ef(cin, hid, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
-    return p.tiles;
-}
-
-int adaf_launch_ef_expand_dw(const void* x, int dtype, int n, int hh, int ww, int cin, const void* we, const float* se, const float* be,
-                             int hid, int k, int stride, int pad_t, int pad_l, int oh, int ow, const float* wd, const float* sd,
-                             const float* bd, int act, void* out, float* pool_part, hipStream_t s) {
-    EfPlan p;
-    if (!plan_ef(cin, hid, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
-    EfFuseArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.we = we; a.se = se; a.be = be; a.wd = wd; a.sd = sd; a.bd = bd; a.out = out; a.pool_part = pool_part;
-    a.n = n; a.H = hh; a.W = ww; a.cin = cin; a.hid = hid; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
-    a.TH = p.TH; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.tiles = p.tiles; a.slices = p.slices; a.NPW = p.NPW; a.NPH = p.NPH; a.KP = p.KP;
-    const unsigned grid = (unsigned)((size_t)n * p.tiles * p.slices);
-    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_ef_t<_Float16>(a, k, stride, p.OXT, p.TN, grid, p.lds, s)
-                                            : launch_ef_t<float>(a, k, stride, p.OXT, p.TN, grid, p.lds, s);
+    a.total = a.igroups * a.tiles * a.slices;
+    const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.lds, s)
+                                            : launch_dw_t<float>(a, k, stride, p.OXT, p.lds, s);
     return ok ? p.tiles : -1;
 }
 
@@ -1703,8 +1202,7 @@ bool adaf_launch_ef_expand(const void* x, int dtype, long long m, int k, const v
     a.KP = (k + 2 * v - 1) / (2 * v) * (2 * v);
     a.NP = (n + 31) / 32 * 32;
     a.strips = (int)((m + 31) / 32);
-    static const int whole_pol = [] { const char* e = getenv("ADAF_EF_EXPAND_WHOLE"); return e ? atoi(e) : -1; }();   // -1 auto, 0 never, 1 always (A/B)
-    const bool whole = whole_pol < 0 ? (f16 && ((size_t)n * es) % 128 != 0) : whole_pol != 0;   // (fp32 rows: measured no better)
+    const bool whole = f16 && ((size_t)n * es) % 128 != 0;     // (fp32 rows: measured no better)
     const size_t fixed = (size_t)a.NP * (a.KP * es + 16) + (size_t)2 * a.NP * 4;
     const size_t slab = (size_t)32 * ((whole ? a.NP : 64) * es + 16);
     // waves per block / blocks per CU: the most resident waves the LDS allows (each block carries its own copy of the filter)
@@ -1734,8 +1232,7 @@ void adaf_launch_se_gate(const float* part, int tiles, int hw, int n, int c, con
     // one block per G images is one block per CU at n = 1024: the squeeze FC is a chain of L2 round trips per wave (SQ / waves filter
     // rows of C floats each), so the wide layers (C >= 512: SQ = 24..96) run 16 waves per block instead of 4
     constexpr int G = 4;
-    static const int wide = [] { const char* e = getenv("ADAF_SE_WIDE"); return e ? atoi(e) : 512; }();
-    if (c >= wide)
+    if (c >= 512)
         hipLaunchKernelGGL((se_gate_kernel<G, 1024>), dim3((unsigned)((n + G - 1) / G)), dim3(1024), (size_t)G * (c + sq) * 4, s, part, tiles,
                            1.f / (float)hw, n, c, wr, br, sq, we, we_ldc, we_ldj, be, gate);
     else
@@ -1757,7 +1254,7 @@ static bool launch_nproj_t(const NprojArgs& a, int blocks, size_t lds, hipStream
 
 static bool launch_narrow_project(const void* x, int dtype, long long m, int hw, int k, const float* gate, const void* w, int n, const float* scale,
                                   const float* bias, const void* res, void* out, int act, int cus, hipStream_t s) {
-    static const int on = [] { const char* e = getenv("ADAF_EF_NPROJ"); return e ? atoi(e) : 1; }();          // 0 = gated_project_kernel (A/B)
+    const bool on = (adaf_options().effnet_plan & ADAF_EF_PLAN_STRIP_PROJECT) != 0;     // off = gated_project_kernel (A/B)
     const bool f16 = dtype == ADAF_DTYPE_F16;
     const int v = f16 ? 8 : 4, es = f16 ? 2 : 4;
     if (!on || !gate || k > 64 || n > 32 || k % v || n % v || m < 32ll * 8 * cus || m > (1ll << 31) - 64) return false;
@@ -1788,13 +1285,12 @@ int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, co
     // (blocks 14-17 of B3: N = 136 as five 32-wide tiles 120 us, as one 160-wide tile 100 us; with 200 row tiles, blocks 19-23, the
     // single tile loses as much again, so they keep two).
     static const int cus = [] { int d = 0, c = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) c = p.multiProcessorCount; return c; }();
-    static const int wide_on = [] { const char* e = getenv("ADAF_GP_WIDE"); return e ? atoi(e) : 1; }();       // 0 = the padding rule only (A/B)
     int best = 1, best_pad = 1 << 30;
     for (int tn = 1; tn <= 4; ++tn) {
         const int bn = 32 * tn, pad = (n + bn - 1) / bn * bn;
         if (pad < best_pad || (pad == best_pad && tn > best)) { best_pad = pad; best = tn; }
     }
-    if (wide_on && dtype == ADAF_DTYPE_F16 && (m + 127) / 128 >= 2 * cus && n > 32 * best) {
+    if (dtype == ADAF_DTYPE_F16 && (m + 127) / 128 >= 2 * cus && n > 32 * best) {
         for (int tn : {5, 6, 8})
             if (32 * tn >= n) { best = tn; break; }
     }
@@ -1856,6 +1352,8 @@ struct EfBlock {
     float* se_br = nullptr;         // [sq]
     float* se_wet = nullptr;        // [sq][hid] (transposed _se_expand.weight)
     float* se_be = nullptr;         // [hid]
+    void* wef = nullptr;            // fp16 storage: expand / project filters in MFMA B-fragment order for the whole-block kernel
+    void* wpf = nullptr;            //  (mbconv_whole.hip)
 };
 
 struct adaf_effnet {
@@ -1866,11 +1364,9 @@ struct adaf_effnet {
     std::vector<EfBlock> blocks;
     int stem = 0, head = 0, feat = 1280;
     int dtype = ADAF_DTYPE_F32;
-    // expand -> depthwise in one kernel for the blocks with a narrow input (ef_expand_dw_kernel).  OFF by default: measured on
-    // 1024 patches of 144^2 it is SLOWER than the two launches it replaces (fp16: block 2 1.96 ms vs 0.88 + 0.95, blocks 3-4
-    // 0.82 vs 0.61, block 5 1.05 vs 0.51; network 13.7 vs 11.9 ms) -- these layers are bound by their instruction streams
-    // (swish on every expanded value incl. the re-expanded halo, the depthwise taps), not by the HBM round trip fusion removes.
-    bool fuse = false;
+    // MBConv blocks whose map is small enough for a workgroup to own whole images run as ONE launch (mbconv_whole.hip; fp16 storage,
+    // stride 1, maps up to 9 x 9).  On by default; adaf_effnet_set_fusion(net, 0) restores the four-launch plan (tests, A/B).
+    bool fuse = true;
     bool finalized = false;
 };
 
@@ -1962,11 +1458,7 @@ void slab_sizes(const adaf_effnet* net, int size, int pad_size, int dtype, size_
         if (b.expand >= 0 && (size_t)hw * hw * b.hid > *ex) *ex = (size_t)hw * hw * b.hid;
         if ((size_t)ohw * ohw * b.hid > *dw) *dw = (size_t)ohw * ohw * b.hid;
         if ((size_t)ohw * ohw * b.cout > *io) *io = (size_t)ohw * ohw * b.cout;
-        int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
-        if (b.expand >= 0) {
-            const int ft = adaf_effnet_ef_tiles(b.cin, b.hid, ohw, ohw, b.k, b.stride, dtype);
-            if (ft > tiles) tiles = ft;
-        }
+        const int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
         if ((size_t)(tiles > 0 ? tiles : 1) * b.hid > *pc) *pc = (size_t)(tiles > 0 ? tiles : 1) * b.hid;
         if ((size_t)b.hid > *gc) *gc = b.hid;
         hw = ohw;
@@ -1978,7 +1470,7 @@ void slab_sizes(const adaf_effnet* net, int size, int pad_size, int dtype, size_
 }
 
 int chunk_frames(int n) {
-    static int c = [] { const char* e = getenv("ADAF_EFFNET_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    const int c = adaf_options().effnet_chunk > 0 ? adaf_options().effnet_chunk : 1024;
     return n < c ? n : c;
 }
 
@@ -2027,6 +1519,8 @@ int adaf_effnet_destroy(adaf_effnet* net) {
         if (b.se_br) (void)hipFree(b.se_br);
         if (b.se_wet) (void)hipFree(b.se_wet);
         if (b.se_be) (void)hipFree(b.se_be);
+        if (b.wef) (void)hipFree(b.wef);
+        if (b.wpf) (void)hipFree(b.wpf);
     }
     delete net;
     return ADAF_OK;
@@ -2047,6 +1541,23 @@ int adaf_effnet_set_fusion(adaf_effnet* net, int on) {
     if (!net) return ADAF_E_BADARG;
     net->fuse = on != 0;
     return ADAF_OK;
+}
+
+int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size) {
+    if (!net || size < 32) return 0;
+    if (pad_size <= 0) pad_size = size;
+    if (net->dtype != ADAF_DTYPE_F16 || !net->fuse || !(adaf_options().effnet_plan & ADAF_EF_PLAN_WHOLE_BLOCK)) return 0;
+    int tot, count = 0;
+    (void)same_pad(pad_size, 3, 2, &tot);
+    int hw = conv_out_len(size, 3, 2, tot), ps = ceil_div(pad_size, 2);
+    for (auto& b : net->blocks) {
+        const int pbd = same_pad(ps, b.k, b.stride, &tot);
+        const int ohw = conv_out_len(hw, b.k, b.stride, tot);
+        if (b.expand >= 0 && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1 && adaf_mbw_eligible(hw, b.k, 1, b.cin, b.hid, b.cout, b.sq)) ++count;
+        hw = ohw;
+        ps = ceil_div(ps, b.stride);
+    }
+    return count;
 }
 
 int adaf_effnet_set_dtype(adaf_effnet* net, int dtype) {
@@ -2115,6 +1626,17 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
         (void)hipMemcpyAsync(b.se_br, br, (size_t)b.sq * 4, hipMemcpyDeviceToDevice, st);
         (void)hipMemcpyAsync(b.se_be, be, (size_t)b.hid * 4, hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((b.sq * b.hid + 255) / 256)), dim3(256), 0, st, we, b.hid, b.sq, b.se_wet);
+        if (net->dtype == ADAF_DTYPE_F16 && b.expand >= 0 && b.stride == 1 && b.cin % 8 == 0 && b.hid % 16 == 0) {
+            // the whole-block kernel streams its filters as ready-made B fragments (one coalesced 1 KB load per wave instruction)
+            const float *wexp, *wproj;
+            if ((rc = get(net->convs[b.expand].name + ".weight", (size_t)b.hid * b.cin, &wexp)) ||
+                (rc = get(net->convs[b.project].name + ".weight", (size_t)b.cout * b.hid, &wproj)))
+                return rc;
+            if (!b.wef && hipMalloc(&b.wef, adaf_mbw_bfrag_halfs(b.hid, b.cin, true) * 2) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            if (!b.wpf && hipMalloc(&b.wpf, adaf_mbw_bfrag_halfs(b.cout, b.hid, false) * 2) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            adaf_launch_pack_bfrag_f16(wexp, b.hid, b.cin, true, b.wef, st);
+            adaf_launch_pack_bfrag_f16(wproj, b.cout, b.hid, false, b.wpf, st);
+        }
     }
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return efail(h, ADAF_E_LAUNCH, "effnet finalize: %s", hipGetErrorString(e));
@@ -2167,7 +1689,8 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
         char* cur = bufA;
         char* nxt = bufB;
         const EfConv& S = net->convs[net->stem];
-        static const int own_stem = [] { const char* e = getenv("ADAF_EF_STEM"); return e ? atoi(e) : 1; }();   // 0 = the generic engine (A/B)
+        const unsigned plan = adaf_options().effnet_plan;
+        const bool own_stem = (plan & ADAF_EF_PLAN_OWN_STEM) != 0;       // off = the generic engine (A/B)
         if (!(own_stem && adaf_launch_ef_stem(frames_nhwc4 + (size_t)f0 * size * size * 4, net->dtype, nc, size, hw, hw, pb0, S.w, S.scale, S.bias,
                                               S.cout, ADAF_ACT_SWISH, cur, st)) &&
             (rc = run_dense(net, S, frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size, hw, hw, pb0, ADAF_ACT_SWISH, cur, f16, st)))
@@ -2180,20 +1703,25 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             const int pbd = same_pad(ps, b.k, b.stride, &tot);
             const int ohw = conv_out_len(hw, b.k, b.stride, tot);
             const EfConv& D = net->convs[b.dwc];
-            int tiles = -1;
-            static const unsigned fuse_mask = [] { const char* e = getenv("ADAF_EF_FUSE_MASK"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();   // per-block A/B
-            if (b.expand >= 0 && (net->fuse || ((fuse_mask >> bi) & 1u)) && hw >= 16) {
-                // narrow input, wide hidden map: expand -> depthwise in one launch, the expanded map stays in LDS
+            const EfConv& P = net->convs[b.project];
+            const bool skip = b.stride == 1 && b.cin == b.cout;
+            if (f16 && net->fuse && (plan & ADAF_EF_PLAN_WHOLE_BLOCK) && b.expand >= 0 && b.wef && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1) {
+                // maps small enough for a workgroup to own whole images: the block as ONE launch (mbconv_whole.hip)
                 const EfConv& E = net->convs[b.expand];
-                tiles = adaf_launch_ef_expand_dw(cur, net->dtype, nc, hw, hw, b.cin, f16 ? E.w16 : static_cast<const void*>(E.w), E.scale, E.bias,
-                                                 b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale, D.bias, ADAF_ACT_SWISH, bufD, part, st);
+                if (adaf_launch_mbconv_whole(cur, nc, hw, b.cin, b.hid, b.cout, b.sq, b.k, b.wef, E.scale, E.bias, D.w, D.scale, D.bias, b.se_wr,
+                                             b.se_br, b.se_wet, b.se_be, b.wpf, P.scale, P.bias, skip, nxt, st)) {
+                    char* t = cur; cur = nxt; nxt = t;
+                    out_elems = (size_t)hw * hw * b.cout;
+                    continue;
+                }
             }
+            int tiles = -1;
             if (tiles <= 0) {
                 if (b.expand >= 0) {
                     // (the expand GEMM stays on the conv engine: routed through gated_project_kernel -- 128 x 128 tiles, swish in its
                     // 16-byte epilogue -- the fp16 network measured 12.6 instead of 11.5 ms)
                     const EfConv& E = net->convs[b.expand];
-                    static const int own_expand = [] { const char* e = getenv("ADAF_EF_EXPAND"); return e ? atoi(e) : 1; }();   // 0 = the conv engine for every expand (A/B)
+                    const bool own_expand = (plan & ADAF_EF_PLAN_STRIP_EXPAND) != 0;   // off = the conv engine for every expand (A/B)
                     if (!(own_expand && adaf_launch_ef_expand(cur, net->dtype, (long long)nc * hw * hw, b.cin, f16 ? E.w16 : static_cast<const void*>(E.w),
                                                               E.scale, E.bias, b.hid, ADAF_ACT_SWISH, bufE, net->h->cus, st)) &&
                         (rc = run_dense(net, E, cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, bufE, f16, st)))
@@ -2201,12 +1729,10 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
                     dw_in = bufE;
                 }
                 tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
-                                            D.bias, ADAF_ACT_SWISH, bufD, part, net->h->zeros, net->h->cus, st);
+                                            D.bias, ADAF_ACT_SWISH, bufD, part, st);
             }
             if (tiles <= 0) return efail(h, ADAF_E_LAUNCH, "effnet: depthwise launch (block %zu)", bi);
             adaf_launch_se_gate(part, tiles, ohw * ohw, nc, b.hid, b.se_wr, b.se_br, b.sq, b.se_wet, 1, b.hid, b.se_be, gate, st);
-            const EfConv& P = net->convs[b.project];
-            const bool skip = b.stride == 1 && b.cin == b.cout;
             if (adaf_launch_gated_project(bufD, net->dtype, nc * ohw * ohw, ohw * ohw, b.hid, gate, f16 ? P.w16 : static_cast<const void*>(P.w),
                                           b.cout, P.scale, P.bias, skip ? cur : nullptr, nxt, st) < 0)
                 return efail(h, ADAF_E_LAUNCH, "effnet: project launch (block %zu)", bi);
@@ -2263,8 +1789,7 @@ int adaf_dwconv_same_bn_act(adaf_handle* h, const void* x, int dtype, int n, int
         if (!ws || ws_bytes < adaf_dwconv_same_workspace_bytes(n, hh, ww, c, k, stride, dtype)) return efail(h, ADAF_E_NOMEM, "dwconv_same: workspace");
         part = static_cast<float*>(ws);
     }
-    const int tiles = adaf_launch_dw_same(x, dtype, n, hh, ww, c, k, stride, pt, pl, oh, ow, w_kkc, scale, bias, act, out, part, h->zeros, h->cus,
-                                          (hipStream_t)stream);
+    const int tiles = adaf_launch_dw_same(x, dtype, n, hh, ww, c, k, stride, pt, pl, oh, ow, w_kkc, scale, bias, act, out, part, (hipStream_t)stream);
     if (tiles <= 0) return efail(h, ADAF_E_LAYOUT, "dwconv_same: shape not supported");
     if (pool_mean) adaf_launch_pool_finish(part, n, tiles, c, oh * ow, pool_mean, (hipStream_t)stream);
     hipError_t e = hipGetLastError();

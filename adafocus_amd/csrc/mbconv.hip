@@ -852,7 +852,7 @@ static void launch_expand_dw_w(MbFuseArgs a, hipStream_t s) {
 
 // ADAF_MB_WAVE=0 keeps the block-cooperative kernel (A/B measurements)
 static bool mb_wave_enabled() {
-    static const bool on = [] { const char* e = getenv("ADAF_MB_WAVE"); return !e || atoi(e) != 0; }();
+    const bool on = adaf_options().mb_wave != 0;
     return on;
 }
 

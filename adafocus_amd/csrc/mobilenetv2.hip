@@ -114,7 +114,7 @@ void slab_sizes(const adaf_mobilenetv2* net, int size, size_t* io, size_t* ex, s
 }
 
 int chunk_size() {   // frames per pass through the network (ADAF_MBV2_CHUNK overrides, for tuning)
-    static int c = [] { const char* e = getenv("ADAF_MBV2_CHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    const int c = adaf_options().mbv2_chunk;
     return c;
 }
 

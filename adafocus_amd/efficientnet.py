@@ -72,13 +72,16 @@ class MBConvBlock(nn.Module):
 
 
 class EfficientNet(nn.Module):
-    def __init__(self, model_name="efficientnet-b3", num_classes=1000, image_size=None, dtype="f32"):
+    def __init__(self, model_name="efficientnet-b3", num_classes=1000, image_size="native", dtype="f32"):
         super().__init__()
         width, depth, native, dropout = _PARAMS[model_name]
         self.model_name, self.width, self.depth = model_name, width, depth
-        # the resolution the static SAME padding is computed for (EfficientNet.from_name(..., image_size=)); None = whatever
-        # the input's size is, i.e. exact TensorFlow-SAME behaviour
-        self.image_size = image_size
+        # the resolution the SAME padding is computed for.  "native" (default) = the model's own resolution, 300 for B3: what
+        # the package's EfficientNet.from_name(name) bakes into its Conv2dStaticSamePadding layers (utils.py get_model_params ->
+        # global_params.image_size = res), so a checkpoint produced with the package sees the same sampling grid here; an int =
+        # from_name(name, image_size=int); None = the package's dynamic form (image_size=None -> Conv2dDynamicSamePadding):
+        # padding for the input at hand, i.e. exact TensorFlow-SAME behaviour
+        self.image_size = native if image_size == "native" else image_size
         c0 = _round_filters(32, width)
         self._conv_stem = nn.Conv2d(3, c0, 3, 2, bias=False)
         self._bn0 = _bn(c0)
@@ -97,7 +100,7 @@ class EfficientNet(nn.Module):
         self.last_layer_name = "_fc"            # STH/ops/models_ada.py:73
         self.feature_dim = ch
         self.storage = dtype                    # "f32" | "f16": HBM storage of activations and 1x1 filters
-        self.fusion = False                     # expand -> depthwise in one kernel for the narrow-input blocks (adaf_effnet_set_fusion): measured slower, opt-in
+        self.fusion = True                      # fp16 storage: whole-image MBConv kernels for maps up to 9 x 9 (adaf_effnet_set_fusion; csrc/mbconv_whole.hip)
         self._net, self._sig = None, None
 
     @classmethod
@@ -140,6 +143,7 @@ class EfficientNet(nn.Module):
             self._net.load(self._neutral(sd))
             self._sig = sig
         self._net.set_fusion(self.fusion)
+        self._net.pad_size = int(self.image_size or 0)
         return self._net
 
     def _check_eval(self):

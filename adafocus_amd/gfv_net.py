@@ -54,11 +54,13 @@ class GFV(nn.Module):
                              action_dim=args.action_dim, hidden_state_dim=args.hidden_state_dim,
                              policy_conv=args.policy_conv, gpu=args.gpu, continuous=getattr(args, "continuous", False),
                              gamma=getattr(args, "gamma", 0.7), policy_lr=getattr(args, "policy_lr", 0.0003))
-        # build-specific: local_arch = "efficientnet-b3" (+ local_dtype "f16" | "f32") selects BASELINE config 5's local CNN,
-        # "mbconv_f16" / "mbconv_f32" its round-2 stand-in (no reference implementation, parity unpinned --
-        # adafocus_amd/mbconv_local.py); default = the reference's ResNet-50
+        # build-specific: local_arch = "efficientnet-b3" (+ local_dtype "f16" | "f32", local_image_size = the resolution the
+        # package's static SAME padding is computed for: "native" like EfficientNet.from_name, an int, or None = the input's own
+        # size) selects BASELINE config 5's local CNN (no reference implementation, parity unpinned -- adafocus_amd/mbconv_local.py);
+        # default = the reference's ResNet-50
         self.focuser = Focuser(args.patch_size, args.random_patch, policy_params, self.num_class,
-                               local_arch=getattr(args, "local_arch", "resnet50"), local_dtype=getattr(args, "local_dtype", "f16"))
+                               local_arch=getattr(args, "local_arch", "resnet50"), local_dtype=getattr(args, "local_dtype", "f16"),
+                               local_image_size=getattr(args, "local_image_size", "native"))
         self.dropout = nn.Dropout(p=args.dropout)
         feat_dim = self.focuser.feature_dim + (self.glancer.feature_dim if self.with_glancer else 0)
         if args.consensus == "gru":
@@ -287,19 +289,17 @@ class Glancer(nn.Module):
 
 
 class Focuser(nn.Module):
-    def __init__(self, size=96, random=True, policy_params=None, num_classes=200, local_arch="resnet50", local_dtype="f16"):
+    def __init__(self, size=96, random=True, policy_params=None, num_classes=200, local_arch="resnet50", local_dtype="f16",
+                 local_image_size="native"):
         super().__init__()
         if local_arch == "resnet50":
             self.net = resnet50(pretrained=False)
             self.net.fc = nn.Linear(self.net.fc.in_features, num_classes)
-        elif local_arch in ("mbconv_f16", "mbconv_f32"):
-            from .mbconv_local import MBConvLocalCNN
-            self.net = MBConvLocalCNN(num_classes=num_classes, dtype=local_arch[-3:])
         elif local_arch.startswith("efficientnet-b"):
             from .mbconv_local import EfficientNetLocalCNN
-            self.net = EfficientNetLocalCNN(local_arch, num_classes=num_classes, dtype=local_dtype)
+            self.net = EfficientNetLocalCNN(local_arch, num_classes=num_classes, dtype=local_dtype, image_size=local_image_size)
         else:
-            raise ValueError("local_arch must be 'resnet50', 'efficientnet-b<N>', 'mbconv_f16' or 'mbconv_f32'")
+            raise ValueError("local_arch must be 'resnet50' or 'efficientnet-b<N>'")
         self.patch_size = size
         self.random = random
         self.patch_sampler = PatchSampler(self.patch_size, self.random)

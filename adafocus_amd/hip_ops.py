@@ -720,6 +720,7 @@ class EffNetNet:
         self._scratch = _StreamScratch(self.device)
         self.feature_dim = self._lib.adaf_effnet_feature_dim(net)
         self.dtype = DTYPE_F32
+        self.pad_size = 0          # default image size the SAME padding is computed for (0 = the input's own); the owner sets it
 
     def __del__(self):
         try:
@@ -743,8 +744,12 @@ class EffNetNet:
         self.dtype = int(code)
 
     def set_fusion(self, on):
-        """Expand -> depthwise in one kernel for the narrow-input blocks; default off = the two-launch plan (the fused form measured slower)."""
+        """fp16 storage: whole-image MBConv kernels for the stride-1 blocks on maps up to 9 x 9 (default on); off = the four-launch plan."""
         L.check(self._lib.adaf_effnet_set_fusion(self._net, int(bool(on))), self._h)
+
+    def whole_blocks(self, size, pad_size=None):
+        """MBConv blocks of a forward at this input size that run as one launch each (csrc/mbconv_whole.hip)."""
+        return int(self._lib.adaf_effnet_whole_blocks(self._net, int(size), int(self.pad_size if pad_size is None else pad_size)))
 
     def load(self, params):
         keep = []
@@ -788,11 +793,13 @@ class EffNetNet:
                                               L.ptr(ws), need, L.stream_ptr()), self._h)
         return fmap, fvec
 
-    def forward_blocks(self, frames_nhwc4, upto, pad_size=0):
-        """Output of the first `upto` MBConv blocks (0 = the stem) as (N,h,w,c) in the storage dtype (tests)."""
+    def forward_blocks(self, frames_nhwc4, upto, pad_size=None):
+        """Output of the first `upto` MBConv blocks (0 = the stem) as (N,h,w,c) in the storage dtype (tests).  pad_size: the image
+        size the SAME padding is computed for; None = this engine's default (set by its owner), 0 = the input's own size."""
         L.need_gpu_f32(frames_nhwc4)
         x = frames_nhwc4.contiguous()
         n, s = x.shape[0], x.shape[1]
+        pad_size = self.pad_size if pad_size is None else pad_size
         ps = pad_size or s
 
         def step(hw, ps, k, st):

@@ -72,6 +72,22 @@ int adaf_gru_scan_timeouts(adaf_handle* h, unsigned* count_out);
  * multiply zero padding are skipped for the whole tile (40 % of the products of a 3x3 conv on a 3x3 map, 21 % on 6x6).
  * Bit-identical to the row-major tiles (a skipped slice contributes exact zeros).  Default on; off for A/B and tests. */
 int adaf_set_conv_pos_major(adaf_handle* h, int on);
+/* Process-wide tuning / A-B switches (they replace the ADAF_* environment variables of earlier rounds; the defaults are the plan
+ * every reported number is measured with, INTEGRATION.md lists them).  Keys:
+ *   "conv_lean" 0|1, "pm_fill" 0..1, "conv_pool" 0|1, "resize_lds_kb", "mb_wave" 0|1, "dw3_variant" 0..4, "mbv2_chunk",
+ *   "latency_rows", "latency_linear_rows", "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk".
+ * adaf_set_option returns ADAF_E_BADARG for an unknown key or a value out of range; adaf_get_option returns the current value
+ * (NaN for an unknown key).  Not thread-safe against concurrent launches: set options between forwards. */
+enum {
+    ADAF_EF_PLAN_WHOLE_BLOCK = 1,    /* whole-image MBConv kernels where a block is eligible (see adaf_effnet_set_fusion) */
+    ADAF_EF_PLAN_TINY_DW = 2,        /* register-resident depthwise kernel for maps up to 5 x 5 */
+    ADAF_EF_PLAN_STRIP_PROJECT = 4,  /* strip kernel for the narrow gated project convs (K <= 64, N <= 32) */
+    ADAF_EF_PLAN_STRIP_EXPAND = 8,   /* strip kernel for the narrow-input expand convs (K <= 64) */
+    ADAF_EF_PLAN_OWN_STEM = 16       /* EfficientNet's own 3x3 / stride-2 stem kernel instead of the generic engine */
+};
+int adaf_set_option(adaf_handle* h, const char* key, double value);
+double adaf_get_option(const char* key);
+
 
 /* ---- a1: patch gather -------------------------------------------------------------------
  * Replaces get_patch(images, action_sequence, patch_size) -- ACT/models/utils.py:37-51
@@ -349,11 +365,15 @@ int adaf_effnet_feature_dim(const adaf_effnet* net);
 int adaf_effnet_block_count(const adaf_effnet* net);
 int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8);
 int adaf_effnet_set_dtype(adaf_effnet* net, int dtype);
-/* on: the blocks with a narrow input (cin <= 64 on maps >= 16^2: blocks 2..8 of B3 at 144^2) run expand 1x1 -> depthwise k x k
- * in ONE kernel, the 6x-expanded map stays in LDS; off (DEFAULT -- the fused form measured slower) = the
- * two-launch plan.  Same arithmetic in the same order for every stored value; the squeeze sums its tiles in a different
- * order (fp32 rounding level). */
+/* on (DEFAULT): fp16 storage only -- the stride-1 MBConv blocks whose map is at most 9 x 9 (blocks 9-17 and 19-25 of B3 at 144^2
+ * patches) run as ONE launch per block: a workgroup owns whole images, the 6x-expanded map goes from the MFMA accumulators
+ * straight into the depthwise taps, the depthwise output and the squeeze-and-excite live in LDS, the block reads its input and
+ * writes its output (csrc/mbconv_whole.hip).  off = the four-launch plan (expand, depthwise, SE gate, gated project).  Same
+ * arithmetic and the same fp16 roundings for every stored value; the squeeze adds its pixels in a different order (fp32
+ * rounding level, which can move a gated value across an fp16 rounding boundary). */
 int adaf_effnet_set_fusion(adaf_effnet* net, int on);
+/* how many MBConv blocks of a forward at this input size take the one-launch form (0 in fp32 storage or with fusion off) */
+int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size);
 int adaf_effnet_set_param(adaf_effnet* net, const char* name, const float* dev_ptr, size_t numel);
 int adaf_effnet_finalize(adaf_effnet* net, void* stream);
 size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int pad_size);

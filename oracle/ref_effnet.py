@@ -151,11 +151,15 @@ def mbconv(sd, p, x, b, pad_size):
     return x
 
 
-def extract_features(sd, x, name="efficientnet-b3", image_size=None, upto=None):
+def extract_features(sd, x, name="efficientnet-b3", image_size="native", upto=None):
     """model.py EfficientNet.extract_features: (N,3,S,S) -> (N, head, s, s).  image_size: the resolution the static SAME
-    padding is computed for (EfficientNet.from_name(name, image_size=...)); None = the input's own size, i.e. exact
+    padding is computed for -- "native" (default) = the model's own resolution, what EfficientNet.from_name(name) bakes into its
+    Conv2dStaticSamePadding layers (utils.py get_model_params: global_params.image_size = res); an int =
+    from_name(name, image_size=int); None = the package's Conv2dDynamicSamePadding: the input's own size, i.e. exact
     TensorFlow-SAME behaviour.  upto: stop after that many blocks and return the block output (tests)."""
     width, depth = PARAMS[name][:2]
+    if image_size == "native":
+        image_size = PARAMS[name][2]
     size = int(image_size or x.shape[-1])
     x = swish(_bn(sd, "_bn0", _conv_same(x, sd["_conv_stem.weight"], 2, size)))
     size = out_size(size, 2)
@@ -169,7 +173,20 @@ def extract_features(sd, x, name="efficientnet-b3", image_size=None, upto=None):
     return swish(_bn(sd, "_bn1", F.conv2d(x, sd["_conv_head.weight"])))
 
 
-def features_pooled(sd, x, name="efficientnet-b3", image_size=None):
+def mbconv_block(sd, x, name, bi, image_size="native"):
+    """Block bi of the network applied to ITS OWN input x (N, cin, h, w) -- tests compare one block's arithmetic in isolation."""
+    width, depth, native = PARAMS[name][:3]
+    if image_size == "native":
+        image_size = native
+    size = out_size(int(image_size or 0), 2) if image_size else None
+    blocks = block_list(width, depth)
+    for b in blocks[:bi]:
+        if size is not None:
+            size = out_size(size, b["stride"])
+    return mbconv(sd, "_blocks.%d." % bi, x, blocks[bi], size if size is not None else x.shape[-1])
+
+
+def features_pooled(sd, x, name="efficientnet-b3", image_size="native"):
     """extract_features + _avg_pooling + flatten (model.py EfficientNet.forward up to the dropout): (N, head)."""
     return F.adaptive_avg_pool2d(extract_features(sd, x, name, image_size), 1).flatten(1)
 

@@ -19,6 +19,16 @@ def rnd(shape, seed, scale=1.0):
     return torch.from_numpy(g.standard_normal(shape, dtype=np.float32) * np.float32(scale))
 
 
+def load_tool(name):
+    """Import tools/<name>.py as a module (the A/B tools double as test fixtures: tests call their digests())."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", name + ".py")
+    spec = importlib.util.spec_from_file_location("adaf_tool_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 _MANIFEST = None
 
 

@@ -92,40 +92,36 @@ def test_dwconv_same_vs_torch(dev, ops, R, k, stride, size, c):
         assert (p16.cpu() - ref16.mean([2, 3])).abs().max().item() < 2e-5      # the squeeze sums the fp32 values
 
 
-def test_tiny_map_depthwise_kernel_bit_identical_to_the_staged_one():
+def test_tiny_map_depthwise_kernel_bit_identical_to_the_staged_one(dev):
     """dw_small_kernel (H = W <= 5: one thread per image x 4 channels, padding taps skipped, thread-local squeeze sums) against
-    dw_same_kernel on the same inputs: same sha256 of every output map, fp32 and fp16 storage, 3x3 and 5x5 windows, 3^2 .. 5^2 maps.
-    The switch is read once per process, so both arms run as subprocesses (tools/dw_small_ab.py)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for mode in ("1", "0"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dw_small_ab.py")], capture_output=True, text=True, timeout=600, cwd=root,
-                           env=dict(os.environ, ADAF_DW_SMALL=mode))
-        assert r.returncode == 0, r.stderr[-1500:]
-        outs.append([ln.split() for ln in r.stdout.splitlines() if len(ln.split()) == 3])
-    assert len(outs[0]) == 24 and len(outs[1]) == 24
-    for a, b in zip(*outs):
+    dw_same_kernel on the same inputs: same sha256 of every output map, fp32 and fp16 storage, 3x3 and 5x5 windows, 3^2 .. 5^2 maps
+    (tools/dw_small_ab.py; the two arms differ in one bit of the library option "effnet_plan")."""
+    from adafocus_amd import _lib
+    from tests.helpers import load_tool
+    tool = load_tool("dw_small_ab")
+    plan = int(_lib.get_option("effnet_plan"))
+    with _lib.option("effnet_plan", plan | _lib.EF_PLAN_TINY_DW):
+        small = tool.digests()
+    with _lib.option("effnet_plan", plan & ~_lib.EF_PLAN_TINY_DW):
+        staged = tool.digests()
+    assert len(small) == 24 and len(staged) == 24
+    for a, b in zip(small, staged):
         assert a[:2] == b[:2], (a, b)                                  # the maps: bit for bit
         assert abs(float(a[2]) - float(b[2])) <= 1e-3 * max(1.0, abs(float(b[2])))      # the squeeze sums: another summation order
 
 
-def test_narrow_project_strip_kernel_bit_identical_to_the_tiled_one():
+def test_narrow_project_strip_kernel_bit_identical_to_the_tiled_one(dev):
     """ef_nproj_kernel (blocks 0-1: K <= 64, N <= 32, millions of rows) against gated_project_kernel: same sha256 of the block
-    outputs in fp32 and fp16 storage, with and without the identity skip, on even and odd maps (tools/nproj_ab.py, two processes)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for mode in ("1", "0"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "nproj_ab.py")], capture_output=True, text=True, timeout=600, cwd=root,
-                           env=dict(os.environ, ADAF_EF_NPROJ=mode))
-        assert r.returncode == 0, r.stderr[-1500:]
-        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 5])
-    assert len(outs[0]) == 8 and outs[0] == outs[1]
+    outputs in fp32 and fp16 storage, with and without the identity skip, on even and odd maps (tools/nproj_ab.py)."""
+    from adafocus_amd import _lib
+    from tests.helpers import load_tool
+    tool = load_tool("nproj_ab")
+    plan = int(_lib.get_option("effnet_plan"))
+    with _lib.option("effnet_plan", plan | _lib.EF_PLAN_STRIP_PROJECT):
+        strip = tool.digests()
+    with _lib.option("effnet_plan", plan & ~_lib.EF_PLAN_STRIP_PROJECT):
+        tiled = tool.digests()
+    assert len(strip) == 8 and strip == tiled
 
 
 def test_dwconv_same_rejects_bad_arguments(dev, ops):
@@ -201,7 +197,7 @@ def test_conv_engine_swish_epilogue(dev, ops):
 
 
 # ------------------------------------------------------------------------------------ the network
-def _net(dev, name, classes, dtype="f32", seed=1007, image_size=None):
+def _net(dev, name, classes, dtype="f32", seed=1007, image_size="native"):
     from adafocus_amd.efficientnet import EfficientNet
     m = EfficientNet.from_name(name, num_classes=classes, image_size=image_size, dtype=dtype).eval()
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -210,24 +206,25 @@ def _net(dev, name, classes, dtype="f32", seed=1007, image_size=None):
     return m.to(dev), sd
 
 
-@pytest.mark.parametrize("size", [144, 96, 100, 75])
-def test_b3_fp32_storage_vs_oracle(dev, R, size):
+@pytest.mark.parametrize("size,image_size", [(144, "native"), (96, "native"), (100, "native"), (100, None), (75, None)])
+def test_b3_fp32_storage_vs_oracle(dev, R, size, image_size):
     """EfficientNet-B3, fp32 storage: every block boundary and the final features against the CPU restatement, at BASELINE
-    config 5's 144^2 patches, at 96^2, and at sizes whose maps go odd (100: 50/25/13/7/4; 75: 38/19/10/5/3) where the
-    SAME padding turns asymmetric in different places."""
-    m, sd = _net(dev, "efficientnet-b3", 200)
+    config 5's 144^2 patches and at 96^2 / 100^2 with the package's default padding (static, computed for the native 300^2:
+    100^2 then runs on 50/25/13/6/3 maps), and with the package's dynamic padding at sizes whose maps go odd (100: 50/25/13/7/4;
+    75: 38/19/10/5/3) where the SAME padding turns asymmetric in different places."""
+    m, sd = _net(dev, "efficientnet-b3", 200, image_size=image_size)
     x = _smooth((2, 3, size, size), 740 + size)
     from adafocus_amd.utils import nchw_to_nhwc4
     x4 = nchw_to_nhwc4(x.to(dev))
     eng = m.engine()
     with torch.no_grad():
         for upto in (0, 1, 2, 3, 5, 6, 8, 9, 13, 14, 18, 19, 24, 26):
-            ref = R.extract_features(sd, x, "efficientnet-b3", upto=upto)
+            ref = R.extract_features(sd, x, "efficientnet-b3", image_size=image_size, upto=upto)
             got = eng.forward_blocks(x4, upto).cpu().permute(0, 3, 1, 2)
             assert got.shape == ref.shape, (upto, got.shape, ref.shape)
             assert _close(got, ref)[0], (size, upto, _close(got, ref)[1])
-        ref_map = R.extract_features(sd, x, "efficientnet-b3")
-        ref_vec = R.features_pooled(sd, x, "efficientnet-b3")
+        ref_map = R.extract_features(sd, x, "efficientnet-b3", image_size=image_size)
+        ref_vec = R.features_pooled(sd, x, "efficientnet-b3", image_size=image_size)
         fmap = m.extract_features(x.to(dev)).cpu()
         fvec = m.features_nhwc4(x4).cpu()
         pooled = m.get_featmap(x.to(dev), pooled=True).cpu()
@@ -247,13 +244,17 @@ def test_b3_logits_and_static_padding_for_another_resolution(dev, R):
         ref = R.features_pooled(sd, x, "efficientnet-b3") @ sd["_fc.weight"].t() + sd["_fc.bias"]
         got = m(x.to(dev)).cpu()
     assert _close(got, ref)[0]
-    m300, sd300 = _net(dev, "efficientnet-b3", 200, image_size=300)
+    # the default IS the package's: static padding for the native 300^2; image_size=None = the package's dynamic padding
+    mdyn, sddyn = _net(dev, "efficientnet-b3", 200, image_size=None)
+    assert m.image_size == 300 and mdyn.image_size is None
     with torch.no_grad():
-        ref300 = R.extract_features(sd300, x, "efficientnet-b3", image_size=300)
-        got300 = m300.extract_features(x.to(dev)).cpu()
-        plain = R.extract_features(sd300, x, "efficientnet-b3")
+        ref300 = R.extract_features(sddyn, x, "efficientnet-b3", image_size=300)
+        refdyn = R.extract_features(sddyn, x, "efficientnet-b3", image_size=None)
+        gotdyn = mdyn.extract_features(x.to(dev)).cpu()
+        got300 = m.extract_features(x.to(dev)).cpu()
     assert got300.shape == ref300.shape and _close(got300, ref300)[0]
-    assert (ref300 - plain).abs().max().item() > 10 * TOL
+    assert gotdyn.shape == refdyn.shape and _close(gotdyn, refdyn)[0]
+    assert (ref300 - refdyn).abs().max().item() > 10 * TOL
 
 
 def test_b0_fp32_storage_vs_oracle(dev, R):
@@ -292,25 +293,51 @@ def test_b3_fp16_storage_vs_oracle(dev, R):
     assert (v16 - ref).abs().max().item() < 5e-2 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("size", [144, 100, 75, 64])
-def test_b3_fused_expand_dw_equals_two_launch_plan(dev, size):
-    """The expand -> depthwise kernel (blocks 2..7: the 6x-expanded map stays in LDS) against the two-launch plan, both
-    storage modes.  Every stored value comes from the same instructions in the same order; only the squeeze adds its tiles in
-    a different order, so the networks agree to fp32 rounding (fp16 storage: to a few fp16 ulps where a gate moved a value
-    across a rounding boundary)."""
+@pytest.mark.parametrize("size,image_size,whole", [(144, "native", 16), (100, "native", 16), (75, "native", 11), (100, None, 16), (75, None, 16),
+                                                   (128, None, 16)])
+def test_b3_whole_block_kernels_equal_the_four_launch_plan(dev, size, image_size, whole):
+    """fp16 storage: the stride-1 MBConv blocks on maps up to 9 x 9 as ONE launch each (csrc/mbconv_whole.hip: expand ->
+    depthwise out of the accumulators -> in-block squeeze-and-excite -> gated project) against the four-launch plan, at every
+    block boundary behind a fused block and at the pooled features.  Every stored value comes from the same arithmetic with the
+    same fp16 roundings; the squeeze adds its pixels in another order, which can move a gated value across an fp16 rounding
+    boundary: agreement to a few fp16 ulps.  144^2 (config 5): blocks 9-17 on 9 x 9 and 19-25 on 5 x 5 maps; the other sizes /
+    padding rules put 3 x 3 ... 8 x 8 maps under the kernel (native padding at 100^2: 6 x 6 and 3 x 3; at 75^2: 9 x 9 for blocks
+    6-7 and 4 x 4; dynamic padding at 100^2: 7 x 7 and 4 x 4; at 75^2: 5 x 5 and 3 x 3; at 128^2: 8 x 8 and 4 x 4); n = 5 leaves a
+    ragged last image pair where a workgroup owns two images."""
     from adafocus_amd.utils import nchw_to_nhwc4
-    x4 = nchw_to_nhwc4(_smooth((3, 3, size, size), 800 + size).to(dev))
-    for dtype, tol in (("f32", 2e-5), ("f16", 4e-3)):
-        m, _ = _net(dev, "efficientnet-b3", 200, dtype=dtype)
-        with torch.no_grad():
-            m.fusion = True
-            fused = [m.engine().forward_blocks(x4, k).float().clone() for k in (3, 5, 8)] + [m.features_nhwc4(x4).clone()]
-            m.fusion = False
-            plain = [m.engine().forward_blocks(x4, k).float().clone() for k in (3, 5, 8)] + [m.features_nhwc4(x4).clone()]
-        for f, p in zip(fused, plain):
-            assert f.shape == p.shape
-            assert (f - p).abs().max().item() <= tol * max(1.0, float(p.abs().max())), (size, dtype, (f - p).abs().max().item())
-        assert not torch.equal(fused[0], plain[0]) or True
+    x4 = nchw_to_nhwc4(_smooth((5, 3, size, size), 800 + size).to(dev))
+    m, _ = _net(dev, "efficientnet-b3", 200, dtype="f16", image_size=image_size)
+    cuts = (7, 8, 9, 10, 13, 14, 15, 18, 19, 20, 24, 25, 26)
+    with torch.no_grad():
+        m.fusion = True
+        assert m.engine().whole_blocks(size) == whole
+        fused = [m.engine().forward_blocks(x4, k).float().clone() for k in cuts] + [m.features_nhwc4(x4).clone()]
+        m.fusion = False
+        assert m.engine().whole_blocks(size) == 0
+        plain = [m.engine().forward_blocks(x4, k).float().clone() for k in cuts] + [m.features_nhwc4(x4).clone()]
+    for k, f, p in zip(cuts + ("features",), fused, plain):
+        assert f.shape == p.shape
+        if True:
+            assert (f - p).abs().max().item() <= 4e-3 * max(1.0, float(p.abs().max())), (size, k, (f - p).abs().max().item())
+    m32, _ = _net(dev, "efficientnet-b3", 200, dtype="f32")
+    assert m32.engine().whole_blocks(size) == 0          # fp32 storage keeps the four-launch plan
+
+
+def test_b3_whole_block_kernel_single_block_vs_torch(dev, R):
+    """One fused block against the oracle's mbconv on the block's own fp16 input (so only this block's arithmetic is compared):
+    block 14 (5x5 window, 9 x 9 map, identity skip) and block 24 (3x3 window, 5 x 5 map, 232 -> 384, no skip), 3 images."""
+    from adafocus_amd.utils import nchw_to_nhwc4
+    x4 = nchw_to_nhwc4(_smooth((3, 3, 144, 144), 860).to(dev))
+    m, sd = _net(dev, "efficientnet-b3", 200, dtype="f16")
+    with torch.no_grad():
+        eng = m.engine()
+        for bi in (14, 24):
+            xin = eng.forward_blocks(x4, bi)                       # fp16 NHWC input of block bi
+            got = eng.forward_blocks(x4, bi + 1).float().cpu().permute(0, 3, 1, 2)
+            ref = R.mbconv_block(sd, xin.float().cpu().permute(0, 3, 1, 2), "efficientnet-b3", bi)
+            assert got.shape == ref.shape
+            rel = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            assert rel < 2e-3, (bi, rel)                          # fp16 storage of E, D and the output: ~2^-11 each
 
 
 def test_b3_batch_invariance_and_chunking(dev, monkeypatch):

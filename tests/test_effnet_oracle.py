@@ -54,8 +54,9 @@ def test_oracle_runs_and_static_padding_differs_only_where_it_should():
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 3).items()}
     x = torch.randn(1, 3, 64, 64)
     with torch.no_grad():
-        f = R.extract_features(sd, x, "efficientnet-b0")
+        f = R.extract_features(sd, x, "efficientnet-b0", image_size=None)
         assert f.shape == (1, 1280, 2, 2)
+        assert torch.equal(R.extract_features(sd, x, "efficientnet-b0"), R.extract_features(sd, x, "efficientnet-b0", image_size=224))
         assert torch.equal(R.extract_features(sd, x, "efficientnet-b0", image_size=64), f)
         # padding computed for another resolution: 100 -> 50 -> 50 -> 25 -> 13: the 5x5 / stride-2 conv pads (2, 2) there but
         # (1, 2) on the actual 16-pixel map; 224's chain happens to give the same pads as 64's everywhere
@@ -78,9 +79,9 @@ def test_python_mirror_has_the_package_state_dict_layout():
 
 
 def test_local_cnn_wrapper_registers_the_classifier_once():
-    from adafocus_amd.mbconv_local import EfficientNetLocalCNN, MBConvLocalCNN
+    from adafocus_amd.mbconv_local import EfficientNetLocalCNN
     e = EfficientNetLocalCNN("efficientnet-b0", num_classes=7)
     assert e.fc is e._fc and sum(k.endswith("fc.weight") for k in e.state_dict()) == 1
-    m = MBConvLocalCNN(num_classes=7)            # fc used to be registered twice (duplicate state-dict keys)
-    keys = list(m.state_dict())
-    assert m.fc is m.net.classifier[-1] and not any(k.startswith("fc.") for k in keys)
+    assert e.image_size == 224                    # the package's default is static padding for the native resolution
+    assert EfficientNetLocalCNN("efficientnet-b3", image_size=None).image_size is None
+    assert EfficientNetLocalCNN("efficientnet-b3", image_size=144).image_size == 144

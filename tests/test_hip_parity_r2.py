@@ -530,29 +530,6 @@ def test_mobilenetv2_f16_storage_vs_g5_golden(dev, ops):
         assert (got - ref).abs().max().item() < 2e-2 * max(1.0, float(ref.abs().max())), name
 
 
-def test_config5_mbconv_f16_local_cnn_end_to_end(dev, O):
-    """BASELINE config 5's shape (T = 16, P = 144, MBConv local CNN, fp16 storage) through GFV.hot_path.  No reference
-    implementation exists (parity unpinned): checked against the oracle's MobileNetV2 + GRU in fp32 at fp16 tolerance."""
-    m, sd = _act_model(dev, num_segments=16, patch_size=144, local_arch="mbconv_f16")
-    assert m.focuser.feature_dim == 1280 and m.classifier.gru.weight_ih_l0.shape[1] == 2560
-    b, t = 4, 16
-    fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=51))
-    _, act = synth.synth_actions(b * t, 7, seed=52)
-    gvec = rnd((b, t, 1280), 53, 0.5)
-    with torch.no_grad():
-        lg, last, feat = m.hot_path(fr.view(b * t, 3, 224, 224).to(dev), gvec.to(dev), torch.from_numpy(act).to(dev), b, t)
-        patches = O.get_patch(fr.view(b * t, 3, 224, 224), torch.from_numpy(act), 144)
-        local = O.mobilenetv2_features(sd, "focuser.net.net.", patches, "act").mean([2, 3]).view(b, t, -1)
-        rl, rlast = O.recurrent_classifier(sd, "classifier.", torch.cat([gvec, local], dim=2))
-    lf = feat[:, :, 1280:].cpu()
-    assert ((lf - local).pow(2).mean().sqrt() / local.pow(2).mean().sqrt()).item() < 4e-2      # measured 1.5e-2 (see the G5 test)
-    assert ((lg.cpu() - rl).pow(2).mean().sqrt() / rl.pow(2).mean().sqrt()).item() < 5e-2
-    m32, _ = _act_model(dev, num_segments=16, patch_size=144, local_arch="mbconv_f32")
-    with torch.no_grad():
-        lg32, _, _ = m32.hot_path(fr.view(b * t, 3, 224, 224).to(dev), gvec.to(dev), torch.from_numpy(act).to(dev), b, t)
-    assert (lg32.cpu() - rl).abs().max().item() < TOL            # the same network in fp32 storage meets the fp32 bar
-
-
 @pytest.mark.parametrize("vd", [1, 2])
 def test_validate_sth_loop_against_golden(dev, vd):
     """evaluate.validate_sth = the loop of STH/evaluate.py:165-226 (two frame streams, video_div focusing steps, baseline
@@ -824,16 +801,13 @@ def test_device_mismatch_is_refused(dev, ops):
 @pytest.mark.gpu
 def test_conv_lean_forms_bit_identical_to_builtin_forms():
     """The VALU-free K loop (scalar-base LDS-DMA, clamped rows) and the lean epilogue (saddr accesses, packed fma/add, med3)
-    against the builtin-DMA K loop and the general epilogue they replace (ADAF_CONV_LEAN=0): same digests on interior,
-    ragged, position-major and sub-tile launches, default tile and forced 128x128 / 128x64 / 64x64."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for mode in ("1", "0"):
-        env = dict(os.environ, ADAF_CONV_LEAN=mode)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "lean_ab.py")], capture_output=True, text=True, timeout=600,
-                           cwd=root, env=env)
-        assert r.returncode == 0, r.stderr[-1500:]
-        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 3])
-    assert len(outs[0]) == 9 * 4 and outs[0] == outs[1]
+    against the builtin-DMA K loop and the general epilogue they replace (library option "conv_lean" = 0): same digests on
+    interior, ragged, position-major and sub-tile launches, default tile and forced 128x128 / 128x64 / 64x64."""
+    from adafocus_amd import _lib
+    from tests.helpers import load_tool
+    tool = load_tool("lean_ab")
+    with _lib.option("conv_lean", 1):
+        lean = tool.digests()
+    with _lib.option("conv_lean", 0):
+        builtin = tool.digests()
+    assert len(lean) == 9 * 4 and lean == builtin

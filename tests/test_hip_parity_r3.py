@@ -99,18 +99,15 @@ def test_config1_step_equals_the_same_clips_in_a_large_batch(dev):
     assert torch.equal(lg.view(2, t, -1), lg_big.view(b, t, -1)[:2])
 
 
-def test_average_pool_in_the_last_conv_epilogue_bit_identical():
+def test_average_pool_in_the_last_conv_epilogue_bit_identical(dev):
     """the trunk's last conv3 averages its map in its epilogue (whole images per row tile, pixel-order sum,
     division by hw: avgpool_kernel's arithmetic) -- same features bit for bit as conv3 + pooling launch, at 3x3 / 4x4 / 5x5 final
-    maps, ragged image counts and with the temporal shift.  The switch is read once per process: two subprocesses."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for mode in ("1", "0"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pool_ab.py")], capture_output=True, text=True, timeout=600, cwd=root,
-                           env=dict(os.environ, ADAF_CONV_POOL=mode))
-        assert r.returncode == 0, r.stderr[-1500:]
-        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 4])
-    assert len(outs[0]) == 5 and outs[0] == outs[1]
+    maps, ragged image counts and with the temporal shift (tools/pool_ab.py under the library option "conv_pool" = 1 and 0)."""
+    from adafocus_amd import _lib
+    from tests.helpers import load_tool
+    tool = load_tool("pool_ab")
+    with _lib.option("conv_pool", 1):
+        fused = tool.digests()
+    with _lib.option("conv_pool", 0):
+        plain = tool.digests()
+    assert len(fused) == 5 and fused == plain

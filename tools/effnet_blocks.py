@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """EfficientNet-B3 per-block cost: forward truncated after k blocks (k = 0 is the stem), differences of consecutive times.
-usage: python tools/effnet_blocks.py [N=1024] [P=144] [dtype=f16]      (ADAF_EF_FUSE_MASK=<bits> fuses expand -> depthwise per block)"""
+usage: python tools/effnet_blocks.py [N=1024] [P=144] [dtype=f16] [fusion=1]      (fusion=0: the four-launch plan for every block)"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ from adafocus_amd.efficientnet import EfficientNet  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 144
 dt = sys.argv[3] if len(sys.argv) > 3 else "f16"
+fusion = (int(sys.argv[4]) if len(sys.argv) > 4 else 1) != 0
 dev = torch.device("cuda:0")
 x4 = torch.randn((n, p, p, 4), device=dev)
 x4[..., 3] = 0
@@ -20,7 +21,9 @@ m = EfficientNet.from_name("efficientnet-b3", num_classes=200, dtype=dt).eval()
 shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
 m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 1007).items()})
 m = m.to(dev)
+m.fusion = fusion
 net = m.engine()
+print("whole-block launches per forward: %d" % net.whole_blocks(p))
 blocks = net.blocks()
 
 
