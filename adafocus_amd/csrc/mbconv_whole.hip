@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "adaf_internal.h"
 
@@ -30,15 +31,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int kMbwThreads = 512;
 constexpr int kMbwWaves = kMbwThreads / 64;
-constexpr int kMbwMaxRounds = 5;          // channel pairs per wave: hid <= 64 * 8 * 5
+constexpr int kMbwMaxRounds = 4;          // channel pairs per wave: hid <= 64 * 8 * 4 = 2048 (= 4 x 512 threads in the SE expand FC)
 
 __device__ __forceinline__ float w_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 __device__ __forceinline__ float w_swish(float v) { return v * w_sigmoid(v); }
+// two values at a time on the packed fp32 instructions (v_pk_mul / v_pk_add; a plain VALU instruction of a wave takes ~4 cycles on
+// gfx950 and the vector part of this kernel is what bounds it): the same operations in the same order as w_swish
+__device__ __forceinline__ f32x2 w_swish2(f32x2 t) {
+    f32x2 e = t * -1.4426950408889634f;
+    e.x = __builtin_amdgcn_exp2f(e.x); e.y = __builtin_amdgcn_exp2f(e.y);
+    e = 1.f + e;
+    e.x = __builtin_amdgcn_rcpf(e.x); e.y = __builtin_amdgcn_rcpf(e.y);
+    return t * e;
+}
+__device__ __forceinline__ f32x2 w_fma2(f32x2 a, float s, float b) { return __builtin_elementwise_fma(a, f32x2{s, s}, f32x2{b, b}); }
 
 struct MbwArgs {
     const _Float16* x;       // [n][HW*HW][cin] block input
@@ -81,15 +93,28 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     const int hid = a.hid;
 
     // ---- phase 0: X -> LDS ----
+    // (all global loads of this kernel are UNCONDITIONAL loads from clamped addresses, in straight-line batches: hipcc puts an
+    // s_waitcnt vmcnt(0) in front of a load that sits in its own branch, which serialises a batch into a chain of L2 round trips --
+    // measured: the residual loads of phase 4 and the filter rows of phase 2 ran 4-5x slower that way)
     {
         const int cpr = a.cin >> 3, cpp = a.KS * 2;
         const int rows = nimg * PX;
+        const int total = G * PX * cpp;
         const _Float16* xb = a.x + (size_t)img0 * PX * a.cin;
-        for (int i = tid; i < G * PX * cpp; i += kMbwThreads) {
-            const int r = i / cpp, c = i - r * cpp;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r < rows && c < cpr) v = *reinterpret_cast<const u32x4*>(xb + (size_t)r * a.cin + c * 8);
-            *reinterpret_cast<u32x4*>(xl + r * a.xpitch + c * 16) = v;
+        for (int i0 = tid; i0 < total; i0 += 4 * kMbwThreads) {
+            u32x4 v[4];
+            int r[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kMbwThreads;
+                r[u] = i / cpp; c[u] = i - r[u] * cpp;
+                const bool ok = i < total && r[u] < rows && c[u] < cpr;
+                v[u] = *reinterpret_cast<const u32x4*>(xb + (ok ? (size_t)r[u] * a.cin + c[u] * 8 : 0));
+                if (!ok) v[u] = u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * kMbwThreads < total) *reinterpret_cast<u32x4*>(xl + r[u] * a.xpitch + c[u] * 16) = v[u];
         }
     }
     __syncthreads();
@@ -116,13 +141,20 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             const u32x4* p0 = a.wef + ((size_t)(2 * jp) * KS + k0) * 64 + lane;
             const u32x4* p1 = p0 + (size_t)KS * 64;
 #pragma unroll
-            for (int u = 0; u < KC; ++u)
-                if (k0 + u < KS) { dst[0][u] = p0[u * 64]; dst[1][u] = p1[u * 64]; }
+            for (int u = 0; u < KC; ++u) {
+                const int uu = k0 + u < KS ? u : 0;          // (a partial last chunk repeats its first step; the products are skipped)
+                dst[0][u] = p0[uu * 64]; dst[1][u] = p1[uu * 64];
+            }
         };
+        // Every workgroup of the launch streams the same filters; they start together, so without a stagger all CUs would ask the L2
+        // for the same lines at the same time.  Workgroup b walks the channel pairs starting at pair `rot`.
+        const int rot = (int)((blockIdx.x * 5u) % (unsigned)a.NPAIR);
+        auto pair_of = [&](int li) { const int j = li + rot; return j >= a.NPAIR ? j - a.NPAIR : j; };
         u32x4 bc[2][KC], bn[2][KC];
-        if (wave < a.NPAIR) load_b(bc, wave, 0);
+        if (wave < a.NPAIR) load_b(bc, pair_of(wave), 0);
         int rd = 0;
-        for (int jp = wave; jp < a.NPAIR; jp += kMbwWaves, ++rd) {
+        for (int li = wave; li < a.NPAIR; li += kMbwWaves, ++rd) {
+            const int jp = pair_of(li);
             const int c = 64 * jp + lane;            // the channel this lane owns in the depthwise part
             const bool cok = c < hid;
             const int cc = cok ? c : 0;
@@ -142,34 +174,44 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[t][b][i] = 0.f;
-            for (int k0 = 0; k0 < KS; k0 += KC) {
-                if (k0 + KC < KS) load_b(bn, jp, k0 + KC);
+            // K loop in chunks of KC steps, branch-free inside a chunk: every A fragment of the chunk is requested from LDS before its
+            // first product (a read -> wait -> product sequence per step leaves the matrix pipe idle for an LDS round trip each time)
+            auto mma_chunk = [&](int k0, auto ns_tag) {
+                constexpr int NS = decltype(ns_tag)::value;
+                f16x8 af[NS][NB];
 #pragma unroll
-                for (int u = 0; u < KC; ++u) {
-                    if (k0 + u < KS) {
-                        f16x8 af[NB];
+                for (int u = 0; u < NS; ++u)
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) af[b] = *reinterpret_cast<const f16x8*>(xl + xoff[b] + (k0 + u) * 32);
+                    for (int b = 0; b < NB; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(xl + xoff[b] + (k0 + u) * 32);
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[b], __builtin_bit_cast(f16x8, bc[0][u]), acc[0][b], 0, 0, 0);
-                            acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[b], __builtin_bit_cast(f16x8, bc[1][u]), acc[1][b], 0, 0, 0);
-                        }
+                for (int u = 0; u < NS; ++u)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[0][u]), acc[0][b], 0, 0, 0);
+                        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[1][u]), acc[1][b], 0, 0, 0);
                     }
-                }
+            };
+            const int nfull = KS / KC, krem = KS - nfull * KC;
+            for (int c = 0; c < nfull; ++c) {
+                if ((c + 1) * KC < KS) load_b(bn, jp, (c + 1) * KC);
+                mma_chunk(c * KC, std::integral_constant<int, KC>());
 #pragma unroll
                 for (int u = 0; u < KC; ++u) { bc[0][u] = bn[0][u]; bc[1][u] = bn[1][u]; }
             }
+            if (krem == 1) mma_chunk(nfull * KC, std::integral_constant<int, 1>());
+            else if (krem == 2) mma_chunk(nfull * KC, std::integral_constant<int, 2>());
             // the next pair's first fragments travel under the vector part
-            if (jp + kMbwWaves < a.NPAIR) load_b(bc, jp + kMbwWaves, 0);
+            if (li + kMbwWaves < a.NPAIR) load_b(bc, pair_of(li + kMbwWaves), 0);
 
             // BN + swish on the accumulators, rounded to the storage type (what the expand launch would have written)
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    acc[0][b][i] = (float)(_Float16)w_swish(fmaf(acc[0][b][i], sce0, bie0));
-                    acc[1][b][i] = (float)(_Float16)w_swish(fmaf(acc[1][b][i], sce1, bie1));
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 t0 = w_swish2(w_fma2(f32x2{acc[0][b][i], acc[0][b][i + 1]}, sce0, bie0));
+                    const f32x2 t1 = w_swish2(w_fma2(f32x2{acc[1][b][i], acc[1][b][i + 1]}, sce1, bie1));
+                    acc[0][b][i] = (float)(_Float16)t0.x; acc[0][b][i + 1] = (float)(_Float16)t0.y;
+                    acc[1][b][i] = (float)(_Float16)t1.x; acc[1][b][i + 1] = (float)(_Float16)t1.y;
                 }
             // lanes 0-31 take tile 0's other half-rows, lanes 32-63 give them and take tile 1's: afterwards acc[h][b][i] of lane l is
             // row 32 b + (i & 3) + 8 (i >> 2) + 4 h of channel 64 jp + l
@@ -181,16 +223,18 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                     acc[0][b][i] = __uint_as_float(r[0]);
                     acc[1][b][i] = __uint_as_float(r[1]);
                 }
-            // depthwise k x k + BN + swish out of registers
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float ps = 0.f;
-                char* dp = dl + (size_t)g * PX * a.dpitch + cc * 2;
+            // depthwise k x k + BN + swish out of registers: the map value of pixel p of image g
+#define MBW_M(g_, p_) acc[(((p_) & 31) >> 2) & 1][(g_) * RB + ((p_) >> 5)][((p_) & 3) + 4 * (((p_) & 31) >> 3)]
+            if constexpr (G == 2) {
+                // two images per workgroup: the packed lanes are the two images (same channel, same taps)
+                f32x2 ps = {0.f, 0.f};
+                unsigned dofs = (unsigned)a.d_off + (unsigned)cc * 2u;
+                const unsigned gofs = (unsigned)(PX * a.dpitch);
 #pragma unroll
                 for (int oy = 0; oy < HW; ++oy) {
-                    float s[HW];
+                    f32x2 s[HW];
 #pragma unroll
-                    for (int ox = 0; ox < HW; ++ox) s[ox] = 0.f;
+                    for (int ox = 0; ox < HW; ++ox) s[ox] = f32x2{0.f, 0.f};
 #pragma unroll
                     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
@@ -199,85 +243,173 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                             for (int ox = 0; ox < HW; ++ox) {
                                 const int iy = oy + ky - P, ix = ox + kx - P;
                                 if (iy < 0 || iy >= HW || ix < 0 || ix >= HW) continue;      // resolved at compile time
-                                const int p = iy * HW + ix, r = p & 31;
-                                s[ox] = fmaf(acc[(r >> 2) & 1][g * RB + (p >> 5)][(r & 3) + 4 * (r >> 3)], w[ky * K + kx], s[ox]);
+                                const int p = iy * HW + ix;
+                                s[ox] = __builtin_elementwise_fma(f32x2{MBW_M(0, p), MBW_M(1, p)}, f32x2{w[ky * K + kx], w[ky * K + kx]}, s[ox]);
                             }
 #pragma unroll
                     for (int ox = 0; ox < HW; ++ox) {
-                        const float v = w_swish(fmaf(s[ox], sdl, bdl));
+                        const f32x2 v = w_swish2(w_fma2(s[ox], sdl, bdl));
                         ps += v;
-                        if (cok && g < nimg) *reinterpret_cast<_Float16*>(dp) = (_Float16)v;
-                        dp += a.dpitch;
+                        if (cok) {
+                            *reinterpret_cast<_Float16*>(dsm + dofs) = (_Float16)v.x;
+                            if (nimg > 1) *reinterpret_cast<_Float16*>(dsm + dofs + gofs) = (_Float16)v.y;
+                        }
+                        dofs += (unsigned)a.dpitch;
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < kMbwMaxRounds; ++q) psr[q][g] = q == rd ? ps : psr[q][g];
+                for (int q = 0; q < kMbwMaxRounds; ++q) { psr[q][0] = q == rd ? ps.x : psr[q][0]; psr[q][1] = q == rd ? ps.y : psr[q][1]; }
+            } else {
+                // one image per workgroup: one product per instruction, in (ky, kx) order like the four-launch plan.  (Measured on
+                // gfx950 with two waves per SIMD: v_fma_f32 issues every ~3 cycles, v_pk_fma_f32 every ~5.3 -- pairing two outputs per
+                // instruction through two partial sums per output bought nothing and gave up the summation order; tools/exp/valu_rate_bench.hip)
+                f32x2 ps = {0.f, 0.f};
+                unsigned dofs = (unsigned)a.d_off + (unsigned)cc * 2u;
+#pragma unroll
+                for (int oy = 0; oy < HW; ++oy) {
+                    float s[HW + 1];
+#pragma unroll
+                    for (int ox = 0; ox <= HW; ++ox) s[ox] = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                            for (int ox = 0; ox < HW; ++ox) {
+                                const int iy = oy + ky - P, ix = ox + kx - P;
+                                if (iy < 0 || iy >= HW || ix < 0 || ix >= HW) continue;      // resolved at compile time
+                                s[ox] = fmaf(MBW_M(0, iy * HW + ix), w[ky * K + kx], s[ox]);
+                            }
+                    // BN + swish two outputs at a time (the last pair of an odd row carries a dummy)
+#pragma unroll
+                    for (int ox = 0; ox < HW; ox += 2) {
+                        const f32x2 v = w_swish2(w_fma2(f32x2{s[ox], s[ox + 1]}, sdl, bdl));
+                        if (ox + 1 < HW) ps += v; else ps.x += v.x;
+                        if (cok) {
+                            *reinterpret_cast<_Float16*>(dsm + dofs) = (_Float16)v.x;
+                            if (ox + 1 < HW) *reinterpret_cast<_Float16*>(dsm + dofs + a.dpitch) = (_Float16)v.y;
+                        }
+                        dofs += (ox + 1 < HW ? 2u : 1u) * (unsigned)a.dpitch;
+                    }
+                }
+                const float pst = ps.x + ps.y;
+#pragma unroll
+                for (int q = 0; q < kMbwMaxRounds; ++q) psr[q][0] = q == rd ? pst : psr[q][0];
             }
+#undef MBW_M
         }
     }
-    __syncthreads();           // X is dead, D is complete
-
-    // ---- phase 2: squeeze-and-excite ----
+    // ---- phase 2: squeeze-and-excite (the arithmetic of se_gate_kernel) ----
+    // The filter rows come from L2 and do not depend on this block's data, and every workgroup of the launch streams all of them:
+    // the phase is bound by how many bytes a CU keeps in flight.  A batch is SEB rows per wave with every 16-byte piece requested
+    // before the first is used, the first batch is requested BEFORE the barrier that closes phase 1 (a wave that ran out of channel
+    // pairs waits there anyway), and the expand FC's first rows are requested before the barrier that closes the reduce FC.
+    constexpr int SEB = 4;                                          // rows per wave per batch of the reduce FC
+    constexpr int GJB = 32;                                         // rows per batch of the expand FC
+    const int C4 = hid >> 2;
+    const int SQ = a.sq;
     float* mean = reinterpret_cast<float*>(xl);            // [G][hid], later the gate
     float* sqv = mean + G * hid;                            // [G][sq]
-    {
-        const float inv_hw = 1.f / (float)PX;
+    // reduce FC for NP 16-byte pieces of a filter row per lane (NP = ceil(hid / 256): a compile-time count keeps the batch straight-line)
+    auto se_reduce = [&](auto np_tag) {
+        constexpr int NP = decltype(np_tag)::value;
+        f32x4 wv[SEB][NP];
+        auto se_load = [&](int j0) {
 #pragma unroll
-        for (int q = 0; q < kMbwMaxRounds; ++q) {
-            const int c = 64 * (wave + q * kMbwWaves) + lane;
-            if (c < hid) {
+            for (int r = 0; r < SEB; ++r) {
+                const int j = j0 + r * kMbwWaves < SQ ? j0 + r * kMbwWaves : SQ - 1;
+                const float* wrow = a.se_wr + (size_t)j * hid + 4 * lane;
 #pragma unroll
-                for (int g = 0; g < G; ++g) mean[g * hid + c] = psr[q][g] * inv_hw;
+                for (int q = 0; q < NP; ++q) wv[r][q] = *reinterpret_cast<const f32x4*>(wrow + (lane + 64 * q < C4 ? 256 * q : 0));
+            }
+        };
+        se_load(wave);
+        __syncthreads();           // X is dead, D is complete
+        {
+            const float inv_hw = 1.f / (float)PX;
+            const int rot = (int)((blockIdx.x * 5u) % (unsigned)a.NPAIR);
+#pragma unroll
+            for (int q = 0; q < kMbwMaxRounds; ++q) {
+                const int li = wave + q * kMbwWaves;
+                const int jp = li + rot >= a.NPAIR ? li + rot - a.NPAIR : li + rot;
+                const int c = 64 * jp + lane;
+                if (li < a.NPAIR && c < hid) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) mean[g * hid + c] = psr[q][g] * inv_hw;
+                }
             }
         }
-    }
-    __syncthreads();
-    {
-        const int C4 = hid >> 2;
-        for (int j = wave; j < a.sq; j += kMbwWaves) {
-            const float* wrow = a.se_wr + (size_t)j * hid;
-            float s[G];
+        __syncthreads();
+        for (int j0 = wave; j0 < SQ; j0 += SEB * kMbwWaves) {
+            if (j0 != wave) se_load(j0);
 #pragma unroll
-            for (int g = 0; g < G; ++g) s[g] = 0.f;
-#pragma unroll 4
-            for (int c4 = lane; c4 < C4; c4 += 64) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * c4);
+            for (int r = 0; r < SEB; ++r) {
+                const int j = j0 + r * kMbwWaves;
+                float sg[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) sg[g] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int c4 = lane + 64 * q;
+                    if (c4 < C4) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const f32x4 m = *reinterpret_cast<const f32x4*>(mean + g * hid + 4 * c4);
+                            sg[g] = fmaf(m.x, wv[r][q].x, fmaf(m.y, wv[r][q].y, fmaf(m.z, wv[r][q].z, fmaf(m.w, wv[r][q].w, sg[g]))));
+                        }
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const f32x4 m = *reinterpret_cast<const f32x4*>(mean + g * hid + 4 * c4);
-                    s[g] = fmaf(m.x, wv.x, fmaf(m.y, wv.y, fmaf(m.z, wv.z, fmaf(m.w, wv.w, s[g]))));
-                }
-            }
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) s[g] += __shfl_xor(s[g], off, 64);
-                if (lane == 0) {
-                    const float v = s[g] + a.se_br[j];
-                    sqv[g * a.sq + j] = v * w_sigmoid(v);
+                    for (int off = 32; off >= 1; off >>= 1) sg[g] += __shfl_xor(sg[g], off, 64);
+                    if (lane == 0 && j < SQ) {
+                        const float v = sg[g] + a.se_br[j];
+                        sqv[g * SQ + j] = v * w_sigmoid(v);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
+    };
     {
-        const int C4 = hid >> 2, SQ = a.sq;
-        for (int c4 = tid; c4 < C4; c4 += kMbwThreads) {
-            f32x4 s[G];
+        const int np = (C4 + 63) >> 6;
+        if (np <= 2) se_reduce(std::integral_constant<int, 2>());
+        else if (np == 3) se_reduce(std::integral_constant<int, 3>());
+        else if (np == 4) se_reduce(std::integral_constant<int, 4>());
+        else if (np <= 6) se_reduce(std::integral_constant<int, 6>());
+        else se_reduce(std::integral_constant<int, 8>());
+    }
+    {
+        // expand FC: a thread owns 4 consecutive channels; rows in batches of GJB with every load of a batch in flight at once
+        const int c4 = tid < C4 ? tid : 0;            // (C4 <= 512; threads past the end repeat piece 0 and store nothing)
+        const float* wp = a.se_wet + 4 * c4;
+        f32x4 wj[GJB];
+        auto gate_load = [&](int j0) {
+#pragma unroll
+            for (int u = 0; u < GJB; ++u) wj[u] = *reinterpret_cast<const f32x4*>(wp + (size_t)(j0 + u < SQ ? j0 + u : SQ - 1) * hid);
+        };
+        gate_load(0);
+        __syncthreads();
+        {
+            f32x4 sg[G];
             const f32x4 b = *reinterpret_cast<const f32x4*>(a.se_be + 4 * c4);
 #pragma unroll
-            for (int g = 0; g < G; ++g) s[g] = b;
-            const float* wp = a.se_wet + 4 * c4;
-#pragma unroll 8
-            for (int j = 0; j < SQ; ++j) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)j * hid);
+            for (int g = 0; g < G; ++g) sg[g] = b;
+            for (int j0 = 0; j0 < SQ; j0 += GJB) {
+                if (j0) gate_load(j0);
 #pragma unroll
-                for (int g = 0; g < G; ++g) s[g] += wv * sqv[g * SQ + j];
+                for (int u = 0; u < GJB; ++u)
+                    if (j0 + u < SQ) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) sg[g] += wj[u] * sqv[g * SQ + j0 + u];
+                    }
             }
+            if (tid < C4) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 o = {w_sigmoid(s[g].x), w_sigmoid(s[g].y), w_sigmoid(s[g].z), w_sigmoid(s[g].w)};
-                *reinterpret_cast<f32x4*>(mean + g * hid + 4 * c4) = o;          // (every thread is past its reads of `mean`: the barrier above)
+                for (int g = 0; g < G; ++g) {
+                    const f32x4 o = {w_sigmoid(sg[g].x), w_sigmoid(sg[g].y), w_sigmoid(sg[g].z), w_sigmoid(sg[g].w)};
+                    *reinterpret_cast<f32x4*>(mean + g * hid + 4 * c4) = o;      // (every thread is past its reads of `mean`: the barrier above)
+                }
             }
         }
     }
@@ -309,50 +441,79 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     // ---- phase 4: project 1x1 + BN (+ identity), one 32-column tile per wave iteration ----
     {
         const int KSP = a.KSP;
-        for (int nt = wave; nt < a.NTP; nt += kMbwWaves) {
+        const _Float16* __restrict__ resb = a.res ? a.res + (size_t)img0 * PX * a.cout : nullptr;
+        _Float16* __restrict__ outb = a.out + (size_t)img0 * PX * a.cout;
+        const int rotp = (int)((blockIdx.x * 3u) % (unsigned)a.NTP);
+        for (int lt = wave; lt < a.NTP; lt += kMbwWaves) {
+            const int nt = lt + rotp >= a.NTP ? lt + rotp - a.NTP : lt + rotp;
             const u32x4* bp0 = a.wpf + (size_t)nt * KSP * 64 + lane;
-            u32x4 bc[KCP], bn[KCP];
+            // B fragments three chunks of KCP steps deep (this phase is bound by the matrix pipe and by how many bytes a wave keeps in flight)
+            u32x4 bc[KCP], bn[KCP], bnn[KCP];
+            auto load_p = [&](u32x4 (&dst)[KCP], int k0) {
 #pragma unroll
-            for (int u = 0; u < KCP; ++u)
-                if (u < KSP) bc[u] = bp0[u * 64];
+                for (int u = 0; u < KCP; ++u) dst[u] = bp0[(k0 + u < KSP ? k0 + u : KSP - 1) * 64];
+            };
+            load_p(bc, 0);
+            load_p(bn, KCP);
+            // the identity rows of this tile travel under the products (one 2-byte load per output of the lane)
+            const int ncol = nt * 32 + nl;
+            const bool nok = ncol < a.cout;
+            const int obase = 4 * half * a.cout + (nok ? ncol : 0);
+            // (unconditional loads from clamped addresses -- a load inside a per-lane branch is followed by its own s_waitcnt, and 41 of
+            // those in a row were most of this phase's time; values of pixels that do not exist are never stored)
+            _Float16 rv[NB][16];
+            if (resb) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);          // pixel of the h = 0 lanes; h = 1: + 4
+                        const bool ok = b / RB < nimg && pr + 4 * half < PX;
+                        rv[b][i] = resb[ok ? obase + ((b / RB) * PX + pr) * a.cout : 0];
+                    }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rv[b][i] = (_Float16)0.f;
+            }
             f32x16 acc[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-            for (int k0 = 0; k0 < KSP; k0 += KCP) {
+            auto mma_chunk = [&](int k0, auto ns_tag) {
+                constexpr int NS = decltype(ns_tag)::value;
+                f16x8 af[NS][NB];
 #pragma unroll
-                for (int u = 0; u < KCP; ++u)
-                    if (k0 + KCP + u < KSP) bn[u] = bp0[(k0 + KCP + u) * 64];
+                for (int u = 0; u < NS; ++u)
 #pragma unroll
-                for (int u = 0; u < KCP; ++u) {
-                    if (k0 + u < KSP) {
+                    for (int b = 0; b < NB; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(dl + doff[b] + (k0 + u) * 32);
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const f16x8 af = *reinterpret_cast<const f16x8*>(dl + doff[b] + (k0 + u) * 32);
-                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, bc[u]), acc[b], 0, 0, 0);
-                        }
-                    }
-                }
+                for (int u = 0; u < NS; ++u)
 #pragma unroll
-                for (int u = 0; u < KCP; ++u) bc[u] = bn[u];
+                    for (int b = 0; b < NB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[u]), acc[b], 0, 0, 0);
+            };
+            const int nfull = KSP / KCP, krem = KSP - nfull * KCP;
+            for (int c = 0; c < nfull; ++c) {
+                load_p(bnn, (c + 2) * KCP);
+                mma_chunk(c * KCP, std::integral_constant<int, KCP>());
+#pragma unroll
+                for (int u = 0; u < KCP; ++u) { bc[u] = bn[u]; bn[u] = bnn[u]; }
             }
-            const int ncol = nt * 32 + nl;
-            if (ncol < a.cout) {
+            if (krem == 1) mma_chunk(nfull * KCP, std::integral_constant<int, 1>());
+            else if (krem == 2) mma_chunk(nfull * KCP, std::integral_constant<int, 2>());
+            else if (krem == 3) mma_chunk(nfull * KCP, std::integral_constant<int, 3>());
+            if (nok) {
                 const float sc = a.sp[ncol], bi = a.bp[ncol];
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const int g = b / RB;
-                    if (g >= nimg) continue;
+                    if (b / RB >= nimg) continue;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int p = (b % RB) * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                        if (p < PX) {
-                            const size_t o = ((size_t)(img0 + g) * PX + p) * a.cout + ncol;
-                            float v = fmaf(acc[b][i], sc, bi);
-                            if (a.res) v += (float)a.res[o];
-                            a.out[o] = (_Float16)v;
-                        }
+                        const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);
+                        if (pr + 4 * half < PX) outb[obase + ((b / RB) * PX + pr) * a.cout] = (_Float16)(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
                     }
                 }
             }

@@ -165,16 +165,53 @@ def effnet_macs_per_frame(name="efficientnet-b3", size=144):
     return macs + blocks[-1]["ohw"] ** 2 * blocks[-1]["cout"] * ch
 
 
-def effnet_bytes_per_frame(name="efficientnet-b3", size=144, elem=2):
-    """HBM bytes per frame of the launch plan of csrc/effnet.hip (activation inputs + outputs of every launch; the 12 M
-    parameters are shared by >= 1024 frames per launch and ignored): patch in (fp32 x 4 lanes), stem out; per block expand
-    (in, out), depthwise (in, out), project (in, out, + identity); head (in, fp32 out), pooled vector.  elem = bytes per
-    stored activation (2 = fp16 storage, 4 = fp32)."""
+def effnet_whole_block(b, elem=2):
+    """Does block `b` (a dict of effnet_blocks) run as ONE launch (csrc/mbconv_whole.hip)?  Mirror of plan_mbw / adaf_mbw_eligible:
+    fp16 storage, an expand conv, stride 1, a 3 x 3 ... 9 x 9 map, hidden <= 2048 channels, and LDS for the block input (k padded to
+    16) + the depthwise output of one image (two up to 5 x 5) within 160 KB."""
+    if elem != 2 or b["expand"] == 1 or b["stride"] != 1 or not (3 <= b["hw"] <= 9) or b["cin"] % 8 or b["hid"] % 16 or b["hid"] > 2048:
+        return False
+    px, ks = b["hw"] ** 2, -(-b["cin"] // 16)
+    for g in ((2, 1) if b["hw"] <= 5 else (1,)):
+        for pad in (16, 0):
+            first = max(g * px * (ks * 32 + pad), g * (b["hid"] + b["sq"]) * 4)
+            if (first + 15) // 16 * 16 + g * px * (b["hid"] * 2 + pad) <= 160 * 1024:
+                return True
+    return False
+
+
+def effnet_block_bytes_per_frame(name="efficientnet-b3", size=144, elem=2):
+    """BLOCK-LEVEL algorithmic bytes per frame: the patch (3 channels, fp32) read once, every tensor that crosses a block boundary
+    (stem -> block 0 -> ... -> block 25 -> head) written once and read once in the storage type, the identity skip re-read where a
+    block has one, the pooled feature vector written (fp32); nothing inside a block (expanded map, depthwise output, squeeze, gate)
+    and no parameters.  3.4 MB for B3 at 144^2 in fp16 storage: the floor a perfectly fused network would move."""
+    c0, blocks, ch = effnet_blocks(name, size)
+    hw = -(-size // 2)
+    b_ = size * size * 3 * 4 + hw * hw * c0 * elem                 # patch in, stem out
+    for b in blocks:
+        b_ += (b["hw"] ** 2 * b["cin"] + b["ohw"] ** 2 * b["cout"]) * elem
+        if b["stride"] == 1 and b["cin"] == b["cout"]:
+            b_ += b["ohw"] ** 2 * b["cout"] * elem                    # identity rows
+    b_ += blocks[-1]["ohw"] ** 2 * blocks[-1]["cout"] * elem + ch * 4    # head in, pooled vector out
+    return b_
+
+
+def effnet_bytes_per_frame(name="efficientnet-b3", size=144, elem=2, fused=True):
+    """HBM bytes per frame of the launch plan of csrc/effnet.hip + csrc/mbconv_whole.hip that RUNS (activation inputs + outputs of every
+    launch; the 12 M parameters are shared by >= 1024 frames per launch and ignored): patch in (fp32 x 4 lanes), stem out; per block
+    either ONE launch (block in, out, + identity: the whole-image kernel, fused=True and effnet_whole_block) or expand (in, out),
+    depthwise (in, out), project (in, out, + identity); head (in, fp32 out), pooled vector.  elem = bytes per stored activation
+    (2 = fp16 storage, 4 = fp32)."""
     c0, blocks, ch = effnet_blocks(name, size)
     hw = -(-size // 2)
     b_ = size * size * 16 + hw * hw * c0 * elem
     for b in blocks:
         hin, hout = b["hw"] ** 2, b["ohw"] ** 2
+        if fused and effnet_whole_block(b, elem):
+            b_ += (hin * b["cin"] + hout * b["cout"]) * elem
+            if b["cin"] == b["cout"]:
+                b_ += hout * b["cout"] * elem
+            continue
         if b["expand"] != 1:
             b_ += (hin * b["cin"] + hin * b["hid"]) * elem
         b_ += (hin * b["hid"] + hout * b["hid"]) * elem                       # depthwise

@@ -93,11 +93,17 @@ def config5_row(dev, b, streams, frames, steps=30):
                 e1.record()
                 torch.cuda.synchronize()
                 cnn_ms = min(cnn_ms, e0.elapsed_time(e1) / 5)
-        by = float(workload.effnet_bytes_per_frame("efficientnet-b3", p, 2 if dtype == "f16" else 4)) * b * t
+        elem = 2 if dtype == "f16" else 4
+        by = float(workload.effnet_block_bytes_per_frame("efficientnet-b3", p, elem)) * b * t      # block-level algorithmic bytes
+        plan = float(workload.effnet_bytes_per_frame("efficientnet-b3", p, elem)) * b * t            # in + out of every launch that runs
         out[dtype + "_storage"] = {
             "clips_per_s": round(steps * b / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
             "local_cnn": {"bound": "hbm", "ms": round(cnn_ms, 3), "achieved": round(by / cnn_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(by / cnn_ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_patch": int(by / (b * t)),
+                          "plan_bytes_per_patch": int(plan / (b * t)), "plan_gbs": round(plan / cnn_ms / 1e6, 1),
+                          "plan_frac": round(plan / cnn_ms / 1e6 / HBM_PEAK_GBS, 4),
+                          "traffic_bytes_per_patch": load_effnet_traffic(dtype, b * t, p),
+                          "whole_block_launches": int(net.engine().whole_blocks(p)),
                           "tflops": round(2.0 * workload.effnet_macs_per_frame("efficientnet-b3", p) * b * t / cnn_ms / 1e9, 1)}}
         if ref is None:
             ref = lg
@@ -109,9 +115,28 @@ def config5_row(dev, b, streams, frames, steps=30):
     out["gmac_per_patch"] = round(workload.effnet_macs_per_frame("efficientnet-b3", p) / 1e9, 4)
     out["note"] = ("gather (P=144) + EfficientNet-B3 (MBConv + squeeze-excite + swish, 3x3 / 5x5 depthwise, 26 blocks, 1536-d features) over "
                    "B*T = %d patches + GRU classifier, B=%d, T=16; fp16 = activations and 1x1 filters stored as fp16, fp32 accumulate; "
-                   "local_cnn = the network alone (HIP events), bytes = activation in + out of every launch (workload.effnet_bytes_per_frame); "
+                   "local_cnn = the network alone (HIP events): achieved / frac are priced on the BLOCK-LEVEL algorithmic bytes (every tensor that crosses a block "
+                   "boundary written once and read once + identity rows + patch in + feature out: workload.effnet_block_bytes_per_frame), plan_* on the activation "
+                   "in + out of every launch of the plan that runs (workload.effnet_bytes_per_frame; whole_block_launches of the 26 MBConv blocks are one launch "
+                   "each, csrc/mbconv_whole.hip), traffic_bytes_per_patch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes (null if none); "
                    "parity unpinned (no reference implementation of this config)" % (b * t, b))
     return out
+
+
+def load_effnet_traffic(dtype, patches, p):
+    """HBM bytes per patch of the EfficientNet forward from the committed rocprofv3 PMC passes (profiles/r<N>_effnet_traffic.json, written by
+    tools/publish_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/effnet_probe.py); null when not collected for this case."""
+    for tag in ("r4",):
+        path = os.path.join(ROOT, "profiles", "%s_effnet_traffic.json" % tag)
+        if os.path.exists(path):
+            try:
+                j = json.load(open(path))
+                e = j.get(dtype)
+                if e and e.get("patches") == patches and e.get("P") == p:
+                    return int(e["bytes_per_patch"])
+            except Exception:
+                pass
+    return None
 
 
 def load_traffic(t, p, b):

@@ -293,8 +293,8 @@ def test_b3_fp16_storage_vs_oracle(dev, R):
     assert (v16 - ref).abs().max().item() < 5e-2 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("size,image_size,whole", [(144, "native", 16), (100, "native", 16), (75, "native", 11), (100, None, 16), (75, None, 16),
-                                                   (128, None, 16)])
+@pytest.mark.parametrize("size,image_size,whole", [(144, "native", 15), (100, "native", 15), (75, "native", 11), (100, None, 15), (75, None, 15),
+                                                   (128, None, 15)])
 def test_b3_whole_block_kernels_equal_the_four_launch_plan(dev, size, image_size, whole):
     """fp16 storage: the stride-1 MBConv blocks on maps up to 9 x 9 as ONE launch each (csrc/mbconv_whole.hip: expand ->
     depthwise out of the accumulators -> in-block squeeze-and-excite -> gated project) against the four-launch plan, at every
