@@ -97,6 +97,26 @@ def cal_map(output, old_test_y):
     return ap.mean() * 100, ap * 100
 
 
+STAGE_THREADS = 4    # worker threads that copy a batch's clips into pinned memory
+HOST_THREADS = 4     # torch intra-op threads while a loop runs (restored afterwards)
+
+
+class _HostThreads:
+    """The evaluation loops keep the host busy with many small jobs (launches, per-clip copies into pinned memory, three scalars per
+    batch); torch's default intra-op team is one thread per core (128 on the GPU boxes' hosts) and every Tensor.copy_ / small CPU op
+    wakes all of it.  Measured on validate_sth from uint8 clips (64-clip batches, 28.6 ms of GPU work each): 128 threads 34-38 ms per
+    batch, 1-4 threads 31 ms; without the baseline branch 24-29 -> 19.9 ms (17.7 ms of GPU work)."""
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        if self.old > HOST_THREADS:
+            torch.set_num_threads(HOST_THREADS)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.old:
+            torch.set_num_threads(self.old)
+        return False
 _PINNED = {}     # (slot, batch size, item shape, dtype) -> pinned staging buffer, reused across validate() calls
 
 
@@ -111,11 +131,10 @@ class _Prefetcher:
         self.stop = stop
         self.cuda = dev.type == "cuda"
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
-        self.pinned = [None, None]
         self.devbuf = [None, None]          # device-side landing buffers, reused (no allocator traffic per batch)
         self.consumed = [None, None]        # event: the forward that read a device slot has been enqueued ... and finishes
         self.copied = [None, None]          # event of the last H2D copy out of each pinned slot
-        self.pool = ThreadPoolExecutor(max_workers=8) if self.cuda else None   # large tensor copies release the GIL
+        self.pool = ThreadPoolExecutor(max_workers=STAGE_THREADS) if self.cuda else None
         self.slot = 0
         self.next = None
         self._issue(0)
@@ -127,68 +146,75 @@ class _Prefetcher:
         lo = self.los[i]
         items = [self.ds[j] for j in range(lo, min(lo + self.bs, self.stop))]
         tgt = torch.stack([it[1] for it in items])
+        multi = isinstance(items[0][0], (tuple, list))      # a sample made of several tensors (two frame streams): one buffer each
         if not self.cuda:
-            self.next = (torch.stack([torch.cat(list(it[0]), 0) if isinstance(it[0], (tuple, list)) else it[0] for it in items]).to(self.dev), tgt, None, 0)
+            if multi:
+                data = tuple(torch.stack([it[0][k] for it in items]).to(self.dev) for k in range(len(items[0][0])))
+            else:
+                data = torch.stack([it[0] for it in items]).to(self.dev)
+            self.next = (data, tgt, None, 0)
             return
-        first = items[0][0]
-        parts = isinstance(first, (tuple, list))        # a sample made of several tensors, concatenated along dim 0 in the batch
-        if parts:
-            rows = [int(q.shape[0]) for q in first]
-            first = first[0].new_empty((sum(rows),) + tuple(first[0].shape[1:]))     # (shape / dtype carrier only)
-        shape = (len(items),) + tuple(first.shape)
+        firsts = list(items[0][0]) if multi else [items[0][0]]
+        n = len(items)
         if self.copied[self.slot] is not None:
-            self.copied[self.slot].synchronize()        # the previous copy out of this slot has left the host buffer
-        buf = self.pinned[self.slot]
-        if buf is None or buf.shape[1:] != shape[1:] or buf.shape[0] < shape[0] or buf.dtype != first.dtype:
-            key = (self.slot, self.bs, tuple(first.shape), first.dtype)
+            self.copied[self.slot].synchronize()        # the previous copy out of this slot has left the host buffers
+        hosts, devs = [], []
+        for k, first in enumerate(firsts):
+            key = (self.slot, k, self.bs, tuple(first.shape), first.dtype)
             buf = _PINNED.get(key)
             if buf is None:       # page-locking ~150-600 MB costs tens of milliseconds: do it once per process
                 buf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype).pin_memory()
                 _PINNED[key] = buf
-            self.pinned[self.slot] = buf
-        host = buf[:shape[0]]
-        dbuf = self.devbuf[self.slot]
-        if dbuf is None or dbuf.shape[1:] != shape[1:] or dbuf.dtype != first.dtype:
-            dbuf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype, device=self.dev)
-            self.devbuf[self.slot] = dbuf
-        devt = dbuf[:shape[0]]
+            hosts.append(buf[:n])
+            dbuf = self.devbuf[self.slot].get(k) if self.devbuf[self.slot] else None
+            if dbuf is None or dbuf.shape[1:] != first.shape or dbuf.dtype != first.dtype:
+                # allocated UNDER THE COPY STREAM: the caching allocator hands a block freed on stream A only to allocations on stream A.
+                # Allocated on the compute stream (as this was until round 4), slot 1's landing buffer -- first needed while batch 0's
+                # forward is still queued -- could be a block that forward had just freed: the H2D copy then landed in memory that
+                # queued kernels of batch 0 were still going to write (seen as wrong logits for batch 1 only, video_div = 2, gone under
+                # AMD_SERIALIZE_KERNEL=3)
+                with torch.cuda.stream(self.stream):
+                    dbuf = torch.empty((self.bs,) + tuple(first.shape), dtype=first.dtype, device=self.dev)
+                if self.devbuf[self.slot] is None:
+                    self.devbuf[self.slot] = {}
+                self.devbuf[self.slot][k] = dbuf
+            devs.append(dbuf[:n])
         # the labels ride along: a pageable .to(device) inside the loop would block the host until the stream drains
         tkey = ("tgt", self.slot, self.bs, tuple(tgt.shape[1:]), tgt.dtype)
         tpin = _PINNED.get(tkey)
         if tpin is None:
             tpin = torch.empty((self.bs,) + tuple(tgt.shape[1:]), dtype=tgt.dtype).pin_memory()
             _PINNED[tkey] = tpin
-        tpin[:shape[0]].copy_(tgt)
+        tpin[:n].copy_(tgt)
 
-        def put(jt):
-            if parts:
-                lo = 0
-                for q in jt[1][0]:
-                    host[jt[0], lo:lo + q.shape[0]].copy_(q)
-                    lo += q.shape[0]
-            else:
-                host[jt[0]].copy_(jt[1][0])
-        # (staging and copying in chunks of 8 / 16 clips -- the DMA of chunk k under the host copies of chunk k + 1 -- measured no
-        # better than the whole batch at once on the shared hosts of the GPU boxes: 1.3-1.7 k clips/s either way for the fp32 loops)
-        list(self.pool.map(put, enumerate(items)))
+        def put(j):       # each part of a sample straight into its row of its pinned batch buffer (large copies release the GIL)
+            parts = items[j][0] if multi else (items[j][0],)
+            for k, q in enumerate(parts):
+                hosts[k][j].copy_(q)
+        # (measured on the GPU boxes' 256-thread hosts, 64 clips per batch: a pool of STAGE_THREADS workers beats both one copy_ after
+        # the other on this thread -- 2.4x slower for the uint8 loops -- and staging / copying in chunks of 8-16 clips)
+        list(self.pool.map(put, range(n)))
         with torch.cuda.stream(self.stream):
             if self.consumed[self.slot] is not None:
                 self.stream.wait_event(self.consumed[self.slot])   # the batch that last used this slot has been computed
-            devt.copy_(host, non_blocking=True)
-        with torch.cuda.stream(self.stream):
-            tgt_dev = tpin[:shape[0]].to(self.dev, non_blocking=True)
+            for h_, d_ in zip(hosts, devs):
+                d_.copy_(h_, non_blocking=True)
+            tgt_dev = tpin[:n].to(self.dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.copied[self.slot] = ev
-        self.next = (devt, tgt_dev, ev, self.slot)
+        self.next = (tuple(devs) if multi else devs[0], tgt_dev, ev, self.slot)
         self.slot ^= 1
 
     def __iter__(self):
         for i in range(len(self.los)):
             images, tgt, ev, slot = self.next
             if ev is not None:
-                torch.cuda.current_stream(self.dev).wait_event(ev)
-                tgt.record_stream(torch.cuda.current_stream(self.dev))
+                cur = torch.cuda.current_stream(self.dev)
+                cur.wait_event(ev)
+                tgt.record_stream(cur)
+                for d_ in (images if isinstance(images, tuple) else (images,)):
+                    d_.record_stream(cur)      # (the landing buffers belong to the copy stream's pool; the forward reads them on this one)
 
             def stage_next(n=i + 1, slot=slot):
                 if self.cuda:      # called right after this batch's forward was enqueued: marks the end of its reads
@@ -201,6 +227,13 @@ class _Prefetcher:
 
 @torch.no_grad()
 def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
+    """Stage-3 evaluation loop of ACT/main_dist.py:307-422 (arguments, behaviour and return value: `_validate` below), run with the
+    host's intra-op thread team capped (`_HostThreads`)."""
+    with _HostThreads():
+        return _validate(dataset, model, criterion, args, rank, world, batch_size, device, quiet)
+
+
+def _validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
     """Stage-3 evaluation (main_dist.py:307-422, branch :367-371) over this rank's shard of `dataset`
     (indexable -> (images, target (L,) int64) with images either the reference's normalised fp32 ``(T*3,H,W)`` clip or
     the loader's stacked uint8 ``(H,W,T*3)`` clip, which is normalised on the GPU -- row f1).  Every rank returns the
@@ -296,8 +329,8 @@ def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, 
 
 
 class _TwoStream:
-    """(glancer clip, focuser clip, target) items as ONE tensor per sample, so the prefetcher stages and copies them
-    together; the halves are views again on the device."""
+    """(glancer clip, focuser clip, target) items as a two-part sample: the prefetcher stages each clip straight into its own pinned
+    batch buffer and copies both with the batch (no per-sample torch.cat, no shared shape: the two streams may differ in length)."""
 
     def __init__(self, ds):
         self.ds = ds
@@ -307,16 +340,25 @@ class _TwoStream:
 
     def __getitem__(self, i):
         g, f, t = self.ds[i]
-        # the two clips as PARTS of one sample: the prefetcher's worker threads copy each straight into its rows of the pinned
-        # batch buffer (a torch.cat here is a 9.6 MB single-threaded copy per sample: it was most of a batch's 123 ms)
+        # (a torch.cat here is a 9.6 MB single-threaded copy per sample: it was most of a batch's 123 ms)
         return (g, f), torch.as_tensor(t).reshape(-1)[:1]
 
 
 @torch.no_grad()
 def validate_sth(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False, with_baseline=True,
                  return_logits=False):
+    """Something-Something evaluation loop of STH/evaluate.py:165-226 (arguments, behaviour and return value: `_validate_sth` below),
+    run with the host's intra-op thread team capped (`_HostThreads`)."""
+    with _HostThreads():
+        return _validate_sth(dataset, model, criterion, args, rank, world, batch_size, device, quiet, with_baseline, return_logits)
+
+
+def _validate_sth(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False, with_baseline=True,
+                  return_logits=False):
     """Something-Something evaluation (STH/evaluate.py:165-226) over this rank's shard of `dataset` (indexable ->
-    (glancer_images (Tg*3,H,W), focuser_images (Tf*3,H,W), target), normalised fp32 like the reference's loader emits).
+    (glancer_images, focuser_images, target): either normalised fp32 (Tg*3,H,W) / (Tf*3,H,W) clips like the reference's loader
+    emits, or the loader's stacked uint8 (H,W,Tg*3) / (H,W,Tf*3) clips, normalised on the GPU (row f1: 154 MB instead of 617 MB of
+    H2D per 64-clip batch at T = 8 + 8).
     Per batch: nearest resize of the glancer frames to glance_size (:188), `model.glance`, then for each of the
     `args.video_div` focusing steps `model.action_stage2(..., training=False)` with the previous steps' patches carried
     (:198-201), the loss, and -- when `with_baseline` (the reference always computes it; it only feeds the logged reward)
@@ -353,27 +395,52 @@ def validate_sth(dataset, model, criterion, args, rank=0, world=1, batch_size=No
 
     for bi, images, target, stage_next in _Prefetcher(_TwoStream(dataset), start, stop, bs, dev):
         target = target.to(dev)[:, 0]
-        b = images.shape[0]
-        hh, ww = images.shape[2], images.shape[3]
-        glancer_images = images[:, :tg3]
-        g = getattr(args, "glance_size", hh)
-        if g != hh:         # F.interpolate(glancer_images, (glance_size, glance_size)): nearest (evaluate.py:188)
-            from . import hip_ops
-            glancer_images = hip_ops.resize_nearest(glancer_images.reshape(-1, 1, hh, ww), g).view(b, tg3, g, g)
-        focuser_images = images[:, tg3:].reshape(b, args.num_segments_focuser, 3, hh, ww)
-        fm, glog = model.glance(glancer_images)
+        glancer_images, focuser_flat = images
+        b = glancer_images.shape[0]
+        g = getattr(args, "glance_size", None)
         local_patch, pred, loss, rews = None, None, None, []
-        for step in range(args.video_div):
-            pred, base, local_patch = model.action_stage2(focuser_images, fm, glog, step, args, prev_local_patch=local_patch,
-                                                          training=False, with_baseline=with_baseline)
-            loss = criterion(pred, target)
-            if with_baseline:
-                conf = torch.gather(F.softmax(pred, 1), 1, target.view(-1, 1)).view(-1)
-                bsl = torch.gather(F.softmax(base, 1), 1, target.view(-1, 1)).view(-1)
-                rews.append(conf - bsl)
-                rewards[step].append(rews[-1])
-            else:
-                rews.append(None)
+        if glancer_images.dtype == torch.uint8:
+            # the loader's stacked uint8 clips (H, W, T*3) -- what Stack() hands ToTorchFormatTensor (STH/ops/transforms.py:303-336):
+            # 4x fewer bytes over PCIe, normalised on the GPU in the reference's op order (GroupNormalize, :64-77: bit-exact, G8)
+            # straight into the pixel-major frames the glancer's stem and the patch gather read
+            from . import hip_ops
+            from ._lib import LAYOUT_NHWC4
+            from .transforms import ingest_uint8
+            hh = glancer_images.shape[1]
+            g4 = ingest_uint8(glancer_images, args.num_segments_glancer, model.input_mean, model.input_std)
+            f4 = ingest_uint8(focuser_flat, args.num_segments_focuser, model.input_mean, model.input_std)
+            if g is not None and g != hh:         # F.interpolate(glancer_images, (glance_size, glance_size)): nearest (evaluate.py:188)
+                g4 = hip_ops.resize_nearest(g4, g, LAYOUT_NHWC4)
+            fm4, glog = model.glance_nhwc4(g4, b)
+            for step in range(args.video_div):
+                pred, base, local_patch = model.action_stage2_nhwc4(f4, fm4, glog, step, args, prev_patch4=local_patch,
+                                                                    with_baseline=with_baseline)
+                loss = criterion(pred, target)
+                if with_baseline:
+                    conf = torch.gather(F.softmax(pred, 1), 1, target.view(-1, 1)).view(-1)
+                    bsl = torch.gather(F.softmax(base, 1), 1, target.view(-1, 1)).view(-1)
+                    rews.append(conf - bsl)
+                    rewards[step].append(rews[-1])
+                else:
+                    rews.append(None)
+        else:
+            hh, ww = glancer_images.shape[2], glancer_images.shape[3]
+            if g is not None and g != hh:         # F.interpolate(glancer_images, (glance_size, glance_size)): nearest (evaluate.py:188)
+                from . import hip_ops
+                glancer_images = hip_ops.resize_nearest(glancer_images.reshape(-1, 1, hh, ww), g).view(b, tg3, g, g)
+            focuser_images = focuser_flat.reshape(b, args.num_segments_focuser, 3, hh, ww)
+            fm, glog = model.glance(glancer_images)
+            for step in range(args.video_div):
+                pred, base, local_patch = model.action_stage2(focuser_images, fm, glog, step, args, prev_local_patch=local_patch,
+                                                              training=False, with_baseline=with_baseline)
+                loss = criterion(pred, target)
+                if with_baseline:
+                    conf = torch.gather(F.softmax(pred, 1), 1, target.view(-1, 1)).view(-1)
+                    bsl = torch.gather(F.softmax(base, 1), 1, target.view(-1, 1)).view(-1)
+                    rews.append(conf - bsl)
+                    rewards[step].append(rews[-1])
+                else:
+                    rews.append(None)
         stage_next()
         acc1, acc5 = accuracy(pred, target, topk=(1, 5))
         preds.append(pred)

@@ -156,6 +156,59 @@ class GFV(nn.Module):
         feat = self.focuser.net.features_nhwc4(torch.cat(groups, 0) if len(groups) > 1 else groups[0])
         return feat, local_patch, action, b, frames_total, len(groups)
 
+    # ---- the same two calls for frames that are already normalised pixel-major (uint8 ingest, evaluate.validate_sth) ----------
+    @torch.no_grad()
+    def glance_nhwc4(self, frames_nhwc4, b):
+        """`glance` for (B*Tg, g, g, 4) pixel-major frames (transforms.ingest_uint8): -> (featmap (B*Tg, h, w, 1280) pixel-major,
+        logits (B, Tg, C)) -- STH/models/gfv_net.py:101-107 without the layout round trip."""
+        net = self.glancer.net
+        fm4, fvec = net._engine.features(frames_nhwc4, net.tsm_segments, net.tsm_div)
+        logit = hip_ops.linear(fvec, net.classifier.weight.detach(), net.classifier.bias.detach())
+        return fm4, logit.view(b, -1, logit.shape[-1])
+
+    @torch.no_grad()
+    def action_stage2_nhwc4(self, focuser_frames4, featmap_nhwc, global_feat_logit, step, args, prev_patch4=None, with_baseline=True,
+                            forced_action=None, baseline_action=None):
+        """`action_stage2(training=False)` (STH/models/gfv_net.py:136-188) on pixel-major data end to end: focuser_frames4
+        (B*Tf, H, W, 4), featmap_nhwc (B*Tg, h, w, 1280) from glance_nhwc4; the patches stay pixel-major ((B, frames, P, P, 4),
+        carried from step to step as `prev_patch4`).  -> (total_logit, baseline_logit | None, patches4).  Same kernels and the
+        same values as action_stage2 on the corresponding planar tensors."""
+        if self.training:
+            raise RuntimeError("adafocus_amd: eval mode only")
+        nfg = args.num_segments_glancer // args.video_div
+        nff = args.num_segments_focuser // args.video_div
+        tf_ = args.num_segments_focuser
+        n, hh, ww, _ = focuser_frames4.shape
+        b = n // tf_
+        cur4 = focuser_frames4.view(b, tf_, hh, ww, 4)[:, step * nff:(step + 1) * nff].reshape(b * nff, hh, ww, 4)
+        _, fh, fw, fc_ = featmap_nhwc.shape
+        seg = featmap_nhwc.view(b, args.num_segments_glancer, fh, fw, fc_)[:, step * nfg:(step + 1) * nfg].reshape(b * nfg, fh, fw, fc_)
+        if self.focuser.ppo_continuous:
+            action = self.focuser.policy.policy_old.act_nhwc(seg, b, nfg, self.focuser.memory, restart_batch=(step == 0))
+        else:
+            state = seg.view(b, nfg, fh, fw, fc_).permute(0, 1, 4, 2, 3).reshape(b, nfg * fc_, fh, fw)
+            action = self.focuser.act(state, restart_batch=(step == 0))
+        if forced_action is not None:
+            action = forced_action.to(action.device)
+        p = args.patch_size
+        main4 = hip_ops.crop_gather_nhwc4(cur4, action.to(dtype=torch.float32), p, nff).view(b, nff, p, p, 4)
+        patches4 = main4 if prev_patch4 is None else torch.cat([prev_patch4, main4], dim=1)
+        frames_total = patches4.shape[1]
+        groups = [patches4.reshape(b * frames_total, p, p, 4)]
+        if with_baseline:
+            # Focuser.random_patching, gfv_net.py:424-427: the reference draws on the CPU generator
+            rand_action = baseline_action if baseline_action is not None else torch.rand(b, 2)
+            rand_action = rand_action.to(cur4.device, non_blocking=True)
+            base4 = hip_ops.crop_gather_nhwc4(cur4, rand_action, p, nff).view(b, nff, p, p, 4)
+            base_all = base4 if prev_patch4 is None else torch.cat([prev_patch4, base4], dim=1)
+            groups.append(base_all.reshape(b * frames_total, p, p, 4))
+        feat = self.focuser.net.features_nhwc4(torch.cat(groups, 0) if len(groups) > 1 else groups[0])
+        per = b * frames_total
+        glog = global_feat_logit if self.with_glancer else None
+        logits = [hip_ops.fc_meanpool_forward(feat[k * per:(k + 1) * per], b, self.classifier.weight.detach(),
+                                              self.classifier.bias.detach(), glog) for k in range(len(groups))]
+        return logits[0], (logits[1] if with_baseline else None), patches4
+
     def action_stage2(self, focuser_image, global_feat_map, global_feat_logit, focus_time_step, args,
                       prev_local_patch=None, training=True, with_baseline=True, forced_action=None, baseline_action=None):
         """STH/models/gfv_net.py:136-188 -> (total_logit, baseline_logit, local_patch)."""

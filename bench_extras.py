@@ -164,10 +164,11 @@ def evaluate_loop_row(dev, model, args, b, t, batches=24):
                     "%d batches per call (a call carries ~50 ms of un-overlapped first-batch staging, drain and cal_map)" % batches}
 
 
-def validate_sth_row(dev, b, t=8, p=128, batches=4):
-    """Something-Something loop end to end (evaluate.validate_sth = STH/evaluate.py:165-226): two fp32 frame streams from
-    host memory, glancer + continuous policy + gather + TSM-ResNet-50 (+ the reward-baseline branch, as the reference runs
-    it) + FC / consensus, accuracy over the set."""
+def validate_sth_row(dev, b, t=8, p=128, batches=8):
+    """Something-Something loop end to end (evaluate.validate_sth = STH/evaluate.py:165-226): two frame streams from host memory,
+    glancer + continuous policy + gather + TSM-ResNet-50 (+ the reward-baseline branch, as the reference runs it) + FC / consensus,
+    accuracy over the set.  From the loader's stacked uint8 clips (normalised on the GPU: 4x fewer bytes over PCIe; row f1) and from
+    the reference's fp32 clips."""
     from adafocus_amd import evaluate as E
     from adafocus_amd.gfv_net_sth import GFV
     a = sth_args(b, t, p)
@@ -177,28 +178,36 @@ def validate_sth_row(dev, b, t=8, p=128, batches=4):
     m = m.to(dev)
     n = b * batches
     g = torch.Generator().manual_seed(3)
+    labels = torch.randint(0, 174, (n,), generator=g)
+    gl8 = torch.randint(0, 256, (16, 224, 224, t * 3), dtype=torch.uint8, generator=g)
+    fo8 = torch.randint(0, 256, (16, 224, 224, t * 3), dtype=torch.uint8, generator=g)
     gl = torch.randn((16, t * 3, 224, 224), generator=g)
     fo = torch.randn((16, t * 3, 224, 224), generator=g)
-    labels = torch.randint(0, 174, (n,), generator=g)
 
     class DS:
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
         def __len__(self):
             return n
 
         def __getitem__(self, i):
-            return gl[i % 16], fo[(i + 5) % 16], labels[i]
+            return self.x[i % 16], self.y[(i + 5) % 16], labels[i]
     crit = torch.nn.CrossEntropyLoss()
     out = {}
-    for name, base in (("with_baseline_branch", True), ("without_baseline_branch", False)):
-        E.validate_sth(DS(), m, crit, a, quiet=True, with_baseline=base)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        E.validate_sth(DS(), m, crit, a, quiet=True, with_baseline=base)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[name] = {"value": round(n / dt, 1), "unit": "clips/s", "clips": n, "seconds": round(dt, 3), "ms_per_batch": round(dt / batches * 1e3, 2)}
-    out["note"] = ("evaluate.validate_sth from fp32 (T*3,H,W) clips in host memory (2 x %.0f MB per %d-clip batch over PCIe), T=%d, P=%d, "
-                   "video_div=1; the baseline branch doubles the local-CNN work for a logged-only reward" % (b * t * 3 * 224 * 224 * 4 / 1e6, b, t, p))
+    for tag, ds in (("", DS(gl8, fo8)), ("fp32_clips_", DS(gl, fo))):
+        for name, base in (("with_baseline_branch", True), ("without_baseline_branch", False)):
+            E.validate_sth(ds, m, crit, a, quiet=True, with_baseline=base)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            E.validate_sth(ds, m, crit, a, quiet=True, with_baseline=base)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[tag + name] = {"value": round(n / dt, 1), "unit": "clips/s", "clips": n, "seconds": round(dt, 3), "ms_per_batch": round(dt / batches * 1e3, 2)}
+    out["note"] = ("evaluate.validate_sth, T=%d + %d, P=%d, video_div=1, %d batches of %d clips per call; with_ / without_baseline_branch: from the "
+                   "loader's stacked uint8 (H,W,T*3) clips in host memory (2 x %.0f MB per batch over PCIe, normalised on the GPU); fp32_clips_*: from the "
+                   "reference's normalised fp32 (T*3,H,W) clips (2 x %.0f MB per batch); the baseline branch doubles the local-CNN work for a "
+                   "logged-only reward" % (t, t, p, batches, b, b * t * 3 * 224 * 224 / 1e6, b * t * 3 * 224 * 224 * 4 / 1e6))
     return out
 
 

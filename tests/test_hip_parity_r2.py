@@ -531,6 +531,44 @@ def test_mobilenetv2_f16_storage_vs_g5_golden(dev, ops):
 
 
 @pytest.mark.parametrize("vd", [1, 2])
+def test_validate_sth_loop_uint8_clips_equal_fp32_clips(dev, vd, O):
+    """The Something-Something loop fed with the loader's stacked uint8 clips ((H, W, T*3) per stream: what Stack() hands
+    ToTorchFormatTensor, STH/ops/transforms.py:303-336) -- normalised on the GPU, both streams staged in their own pinned
+    buffers, the glancer and the patch gather reading the pixel-major frames directly -- must give the logits of the same
+    clips normalised on the host as the reference does (GroupNormalize, :64-77): torch.equal, with the baseline branch
+    (same torch.rand stream) and without, for video_div = 1 (ragged last batch) and 2 (whole clip pairs: the temporal shift views
+    b * Tf / video_div frames as clips of Tf, so a partial pass needs an even batch -- in the reference too)."""
+    from adafocus_amd import evaluate as E
+    m, a = _sth_model(dev, vd)
+    a.batch_size, a.glance_size = 2, 224
+    gen = np.random.Generator(np.random.PCG64([19, vd]))
+    n = 5 if vd == 1 else 6
+    gu = gen.integers(0, 256, size=(n, 224, 224, 24), dtype=np.uint8)
+    fu = gen.integers(0, 256, size=(n, 224, 224, 24), dtype=np.uint8)
+    gf = torch.stack([O.ingest_uint8(gu[i]) for i in range(n)])
+    ff = torch.stack([O.ingest_uint8(fu[i]) for i in range(n)])
+    labels = torch.tensor([5, 100, 3, 77, 173, 9])[:n]
+
+    class DS:
+        def __init__(self, g, f):
+            self.g, self.f = g, f
+
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return self.g[i], self.f[i], labels[i]
+    for wb in (True, False):
+        torch.manual_seed(11)
+        r8 = E.validate_sth(DS(torch.from_numpy(gu), torch.from_numpy(fu)), m, torch.nn.CrossEntropyLoss(), a, quiet=True,
+                            with_baseline=wb, return_logits=True)
+        torch.manual_seed(11)
+        r32 = E.validate_sth(DS(gf, ff), m, torch.nn.CrossEntropyLoss(), a, quiet=True, with_baseline=wb, return_logits=True)
+        assert torch.equal(r8[4], r32[4]) and torch.equal(r8[5], r32[5])
+        assert r8[:3] == r32[:3], (r8[:3], r32[:3])
+
+
+@pytest.mark.parametrize("vd", [1, 2])
 def test_validate_sth_loop_against_golden(dev, vd):
     """evaluate.validate_sth = the loop of STH/evaluate.py:165-226 (two frame streams, video_div focusing steps, baseline
     branch + reward bookkeeping) on the HIP model: the last step's logits equal the reference's (G12), the metrics are
