@@ -562,7 +562,9 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         const double macs = (double)a.M * L.cout * L.k * L.k * L.cin;   // algorithmic: un-padded cin
         const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
         mark(2.0 * macs, bytes, 0);
-        const int used = adaf_launch_conv_gemm(a, (lat_ok && a.M <= lat_rows && li > 0 && !net->tiles[li]) ? 95 : p.tile, h->cus, st);
+        const bool want_lat = lat_ok && a.M <= lat_rows && li > 0 && !net->tiles[li];
+        int used = adaf_launch_conv_gemm(a, want_lat ? 95 : p.tile, h->cus, st);
+        if (used < 0 && want_lat) used = adaf_launch_conv_gemm(a, p.tile, h->cus, st);   // the latency form declined the shape: the engine takes it
         if (used < 0) return fail(h, ADAF_E_LAUNCH, "resnet50: no kernel for tile id %d (conv launch %d)", p.tile, li);
         if (info && !info->empty()) info->back().tile = used;
         *oh = a.OH; *ow = a.OW;

@@ -66,10 +66,13 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
 // ~2e-7 relative overall) -- expf() + an IEEE division are ~40 VALU instructions per element, which made the swish epilogues
 // of EfficientNet's expand convs (K = 24..384: hardly any MFMA work per output) VALU-bound.  Saturates correctly: v -> -inf
 // gives rcp(inf) = 0, v -> +inf gives rcp(1) = 1.
+// The fast form is for swish only.  A plain sigmoid (sig == 1) keeps expf + the IEEE division -- bit-comparable with conv_naive_kernel and
+// with what round 2 shipped: the continuous policy's actor ends in a sigmoid whose output becomes a crop origin through floor(), where
+// one ulp can move a patch by a pixel, and its epilogues are a handful of elements.
 __device__ __forceinline__ float finish_act(float v, int sig) {
     if (sig == 0) return v;
-    const float g = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
-    return sig == 1 ? g : v * g;
+    if (sig == 1) return 1.f / (1.f + expf(-v));
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }
 
 // ---- epilogue shared by both kernel families: BN affine, residual, activation ---------------

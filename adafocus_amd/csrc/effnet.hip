@@ -1769,7 +1769,8 @@ int adaf_pack_dw_weight_kxk_f32(adaf_handle* h, const float* w_c1kk, int channel
 size_t adaf_dwconv_same_workspace_bytes(int n, int hh, int ww, int c, int k, int stride, int dtype) {
     const int oh = ceil_div(hh, stride), ow = ceil_div(ww, stride);
     const int tiles = adaf_effnet_dw_tiles(c, oh, ow, k, stride, dtype);
-    return tiles > 0 ? (size_t)n * tiles * c * 4 : 0;
+    // (at least one partial per (image, channel): the tiny-map kernel writes n * c sums whatever the tile planner says -- ADVICE r3)
+    return (size_t)n * (tiles > 0 ? tiles : 1) * c * 4;
 }
 
 int adaf_dwconv_same_bn_act(adaf_handle* h, const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, const float* w_kkc,

@@ -208,7 +208,12 @@ class GFV(nn.Module):
         """Latency mode for small batches (BASELINE config 1 is B = 2; the reference's published CPU figure is a bs = 1
         latency): one hot-path step for a FIXED (B, T) captured into a HIP graph, so its ~50 dependent, nearly empty
         launches are replayed back to back by the runtime instead of being issued one by one from Python.  Same kernels,
-        same order: bit-identical to hot_path().  Returns a HotPathGraph; call it with (frames, glancer vectors, actions)."""
+        same order: bit-identical to hot_path().  Returns a HotPathGraph; call it with (frames, glancer vectors, actions).
+        EXCLUSIVE USE: a captured persistent GRU scan is outside the library's `scan_slots` throttle (slot events cannot be part of a
+        capture), so while a graph replays, no other stream may run hot paths / GRU scans on this device and one graph must not be
+        replayed on two streams at once -- more co-resident scans than the grid barrier was budgeted for starve each other; the only
+        symptom is the barrier time-out (NaN-poisoned logits, counted by hip_ops.gru_scan_timeouts(), which the evaluation loops
+        check).  Latency mode is one stream by definition; for overlapped batches use the eager hot_path on several streams."""
         return HotPathGraph(self, b, t, frame_shape)
 
     def glance(self, input_prime):

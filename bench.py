@@ -123,6 +123,25 @@ def config5_row(dev, b, streams, frames, steps=30):
     return out
 
 
+def init_failure_line(a, world, rank, backend, exc):
+    """The first unattended multi-GPU run must leave something diagnosable: rank 0 (or, failing that, whichever rank gets here) prints ONE
+    JSON line with the bench contract's keys, `error`, `rccl_ranks: 0`, the exception text and the HSA_* / NCCL_* / RCCL_* / rendezvous
+    environment; the other ranks say the same on stderr.  The process then exits non-zero (the counterpart of the reference's
+    mp.spawn + init_process_group, ACT/main_dist.py:59,79-80, which dies with a traceback per rank)."""
+    env = {k: v for k, v in sorted(os.environ.items())
+           if k.startswith(("HSA_", "NCCL_", "RCCL_", "HIP_", "ROCR_", "MASTER_", "GLOO_", "TORCH_NCCL", "TORCH_DIST")) or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    line = {"metric": "clips/sec (T=%d, patch=%d^2, ResNet-50 local)" % (a.frames, a.patch), "value": None, "unit": "clips/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "error": "distributed init failed on rank %d of %d (backend %s)" % (rank, world, backend), "rccl_ranks": 0,
+            "exception": ("%s: %s" % (type(exc).__name__, exc))[:2000],
+            "visible_gpus": (torch.cuda.device_count() if torch.cuda.is_available() else 0), "env": env}
+    text = json.dumps(line)
+    if rank == 0:
+        print(text, flush=True)
+    else:
+        print("bench.py rank %d: %s" % (rank, text), file=sys.stderr, flush=True)
+
+
 def load_effnet_traffic(dtype, patches, p):
     """HBM bytes per patch of the EfficientNet forward from the committed rocprofv3 PMC passes (profiles/r<N>_effnet_traffic.json, written by
     tools/publish_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/effnet_probe.py); null when not collected for this case."""
@@ -408,6 +427,7 @@ def main():
                     "trunk overlaps batch i's latency-bound GRU scan); 1 = strictly serial steps")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in for the step: tests the launcher and the protocol")
     ap.add_argument("--cpu-worker", type=str, default="", help="(internal) one process of the all-cores CPU baseline row")
+    ap.add_argument("--inject-init-failure", action="store_true", help="(tests) fail inside the distributed-init guard to exercise the error line")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks run the real step on GPU 0 and gather over gloo (RCCL refuses "
                     "two ranks on one device): exercises the N > 1 path on a single-GPU box; not a scaling measurement")
     a = ap.parse_args()
@@ -437,10 +457,25 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry or a.share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if (dry or a.share_gpu) else "nccl"
+        try:
+            # rendezvous + the FIRST collective inside one guard: an RCCL problem (IPC mode, topology, a missing device) usually shows
+            # up at communicator creation, i.e. at the first collective, not at init_process_group
+            if a.inject_init_failure:
+                raise RuntimeError("injected failure (--inject-init-failure): exercises the error line")
+            if backend == "gloo":
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            if not dry:
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("first all_reduce returned %r, expected %d" % (probe.item(), world))
+        except Exception as exc:      # noqa: BLE001 -- whatever it is, the driver must get ONE diagnosable line instead of N tracebacks
+            init_failure_line(a, world, rank, backend, exc)
+            raise SystemExit(3)
     numa_node = None
     if world > 1 and not dry:
         from adafocus_amd.parallel import bind_to_gpu_numa

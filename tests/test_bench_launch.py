@@ -48,3 +48,20 @@ def test_bench_eight_ranks_dry_run():
     assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp8" and r["scaling"] == "weak"
     assert len(r["per_rank_clips_per_s"]) == 8 and all(v > 0 for v in r["per_rank_clips_per_s"])
     assert abs(r["value"] - 32 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 0.01
+
+
+def test_bench_distributed_init_failure_leaves_one_diagnosable_line():
+    """A failure inside the distributed-init guard (rendezvous or the first collective -- where an RCCL problem shows up on the first
+    unattended 8-GPU run) must produce ONE JSON line on stdout with `error`, `rccl_ranks: 0`, the exception text and the HSA_* / NCCL_* /
+    rendezvous environment, and a non-zero exit -- not eight tracebacks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "8", "--steps", "3", "--warmup", "1",
+                          "--batch", "4", "--frames", "2", "--inject-init-failure"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 0 and r["value"] is None and "error" in r and "injected failure" in r["exception"]
+    assert r["env"]["WORLD_SIZE"] == "8" and r["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MASTER_ADDR" in r["env"]
+    assert out.stderr.count("bench.py rank") == 7            # the other ranks report on stderr
