@@ -280,7 +280,7 @@ def cpu_all_cores_row(t, p, threads, seconds=6):
             "per_process_clips_per_s": [round(r, 2) for r in rates]}
 
 
-def cpu_baseline(sd, t, p, threads):
+def cpu_baseline_leg(sd, t, p, threads):
     """Oracle (port of the reference's PyTorch-CPU path, pinned to it by tests/golden) on the host, SURVEY.md §8(d)
     protocol: fp32, `torch.set_num_threads(n)`, 2 warm-ups + the MEDIAN of 7 runs with `time.perf_counter`, at B = 2
     (BASELINE config 1's batch) and B = 8, batched structure and the reference's per-step loop structure, for the
@@ -367,13 +367,37 @@ def cpu_baseline(sd, t, p, threads):
             "cpu_model": model, "physical_cores": phys, "logical_cpus": ncpu, "threads": best_thr,
             "thread_sweep_B8_clips_per_s": sweep or None, "value_is": "B=%d, %s" % (best["B"], best["structure"]),
             "pinned_to_numa_node": node0[0], "all_cores": allrow,
-            "all_cores_note": "N processes x `threads` pinned to disjoint physical cores, run at the same time and summed; on the gpurun "
-                              "boxes the per-process rate collapses (a container CPU quota and/or shared memory bandwidth), so the sum is "
-                              "not N x the single-process row -- reported as measured",
+            "all_cores_note": "N processes x `threads` pinned to disjoint physical cores, run at the same time and summed -- reported as measured "
+                              "(shared hosts: a container CPU quota and / or the other tenants' memory traffic bound it)",
             "rows": rows,
             "sample": "oracle.act_hot_path (crop -> ResNet-50 -> GRU; torch-CPU fp32 restatement of the reference, pinned by "
                       "tests/golden), T=%d P=%d, B=2 and B=8 clips per call, %d threads, 2 warm-ups + median of 7 runs; `value` = the "
                       "best of those rows; other configs in `rows`" % (t, p, best_thr)}
+
+
+# glibc hands every tensor above 128 KB straight to mmap / munmap: a forward of the oracle then page-faults (and zeroes) hundreds of MB per
+# call, under the mm lock, with a thread team waiting -- on the 256-thread hosts that made B = 8 (4x larger maps) 15x slower per call than
+# B = 2.  With the heap kept (no mmap, no trim) the per-clip rate is flat in B; measured in the build container (8 cores,
+# T = 16, P = 96): B = 2 11.8 -> 14.4 clips/s, B = 8 8.1 -> 14.3.  The variables are read at process start, hence the subprocess.
+MALLOC_ENV = {"MALLOC_MMAP_THRESHOLD_": str(1 << 32), "MALLOC_TRIM_THRESHOLD_": str(1 << 33), "MALLOC_TOP_PAD_": str(1 << 30)}
+
+
+def cpu_baseline(t, p, threads):
+    """The CPU baseline leg in its own process (so that MALLOC_ENV applies): `bench.py --cpu-baseline-leg T,P,threads` prints the
+    dictionary cpu_baseline_leg() returns as one JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(MALLOC_ENV)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-leg", "%d,%d,%d" % (t, p, threads)],
+                         capture_output=True, text=True, timeout=900, env=env)
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{"):
+            res = json.loads(ln)
+            res["malloc_env"] = MALLOC_ENV
+            return res
+    raise RuntimeError("cpu baseline leg failed: %s" % out.stderr[-400:])
 
 
 def free_port():
@@ -427,6 +451,7 @@ def main():
                     "trunk overlaps batch i's latency-bound GRU scan); 1 = strictly serial steps")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in for the step: tests the launcher and the protocol")
     ap.add_argument("--cpu-worker", type=str, default="", help="(internal) one process of the all-cores CPU baseline row")
+    ap.add_argument("--cpu-baseline-leg", type=str, default="", help="(internal) T,P,threads: the CPU baseline leg, run as its own process")
     ap.add_argument("--inject-init-failure", action="store_true", help="(tests) fail inside the distributed-init guard to exercise the error line")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks run the real step on GPU 0 and gather over gloo (RCCL refuses "
                     "two ranks on one device): exercises the N > 1 path on a single-GPU box; not a scaling measurement")
@@ -435,6 +460,14 @@ def main():
         a.cpu_baseline = 0
     if a.cpu_worker:
         cpu_worker(a.cpu_worker)
+        return
+    if a.cpu_baseline_leg:
+        from adafocus_amd import synth
+        from tests.helpers import manifest
+        tt, pp, thr = (int(v) for v in a.cpu_baseline_leg.split(","))
+        torch.set_num_interop_threads(1)
+        sd_cpu = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(manifest()["ACT"], 1007).items()}
+        print(json.dumps(cpu_baseline_leg(sd_cpu, tt, pp, thr)), flush=True)
         return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -783,7 +816,7 @@ def main():
             except Exception as exc:  # upstream of the timed path; never fail the bench on it
                 res["full_forward"] = {"error": repr(exc)[:200]}
         if world == 1 and a.cpu_baseline and not a.skip_extras:
-            res["cpu_baseline"] = cpu_baseline(sd, t, p, a.cpu_threads)
+            res["cpu_baseline"] = cpu_baseline(t, p, a.cpu_threads)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -47,6 +47,34 @@ EXTRA = {   # round 3: summaries that are copied as they are (tools/profile_r3.s
     "resize_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/crop_resize_probe.py 5   (KB; x2 for wide coalesced reads)",
     "resize_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/crop_resize_probe.py 5   (KB)",
 }
+EXTRA_R4 = {   # round 4 (tools/profile_r4.sh)
+    "fullfwd_trace_serial": "rocprofv3 --kernel-trace -- python tools/fullfwd_probe.py serial 10, condensed by tools/overlap_report.py   (full forward from uint8 clips, B = 64, T = 16, P = 96: ingest + glancer + policy + hot path on ONE stream)",
+    "fullfwd_trace_2streams": "rocprofv3 --kernel-trace -- python tools/fullfwd_probe.py two 10, condensed by tools/overlap_report.py   (the same work through GFV.offline_forward_pipelined: front half of batch i+1 and back half of batch i on the model's two streams)",
+    "glancer_trace": "rocprofv3 --kernel-trace --stats -- python tools/glancer_probe.py 1024   (MobileNetV2 glancer, 1024 frames of 224^2, 2 warm-up + 3 timed forwards)",
+    "glancer_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/glancer_probe.py 1024   (KB; x2 for wide coalesced reads on gfx950, MI355X_MICROARCH.md)",
+    "glancer_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/glancer_probe.py 1024   (KB)",
+    "effnet_f16_trace": "rocprofv3 --kernel-trace --stats -- python tools/effnet_probe.py 1024 144 5 f16   (EfficientNet-B3 local CNN, fp16 storage, whole-block MBConv kernels on; 3 warm-up + 5 timed forwards)",
+    "effnet_f16_sq": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -- python tools/effnet_probe.py 1024 144 5 f16",
+    "effnet_f16_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB; x2 for wide coalesced reads on gfx950)",
+    "effnet_f16_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB)",
+}
+if tag >= "r4":
+    EXTRA = EXTRA_R4
+
+
+def all_kernels_sum(path, counter, once_per_forward):
+    """(sum of `counter` over every kernel of a summary, dispatches of the kernel that runs once per forward)"""
+    total, fwd = 0.0, 0
+    for line in open(path):
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        if len(cells) < 5 or cells[1] != counter:
+            continue
+        total += float(cells[3])
+        if once_per_forward in cells[0]:
+            fwd += int(cells[2])
+    return total, fwd
+
+
 for short, cmd in EXTRA.items():
     src = os.path.join(OUT, "%s_%s.md" % (tag, short))
     if os.path.exists(src):
@@ -79,3 +107,25 @@ json.dump({
     "algorithmic_bytes_note": "sum over the launches of in + out (+ residual) + weights, bench.py launch table: see roofline.flop_per_launch / DESIGN 3.2",
 }, open(os.path.join(PROF, "%s_traffic.json" % tag), "w"), indent=1)
 print("traffic: %d dispatches over %d passes, %.1f MB / launch" % (fd, passes, per_launch / 1e6))
+
+# EfficientNet-B3 (config 5): HBM bytes per patch of the whole forward, every kernel counted
+ef_f, ef_w = os.path.join(PROF, "%s_effnet_f16_fetch.md" % tag), os.path.join(PROF, "%s_effnet_f16_write.md" % tag)
+if os.path.exists(ef_f) and os.path.exists(ef_w):
+    fs, nf = all_kernels_sum(ef_f, "FETCH_SIZE", "ef_stem_kernel")
+    ws, nw = all_kernels_sum(ef_w, "WRITE_SIZE", "ef_stem_kernel")
+    per_patch = int((2 * fs / max(nf, 1) + ws / max(nw, 1)) * 1024 / 1024)
+    json.dump({"source": "profiles/%s_effnet_f16_fetch.md + %s_effnet_f16_write.md (rocprofv3 --pmc, separate passes, EVERY kernel of the forward)" % (tag, tag),
+               "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per forward / 1024 patches (FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950)",
+               "f16": {"patches": 1024, "P": 144, "forwards_counted": [nf, nw], "fetch_kb_per_forward": fs / max(nf, 1), "write_kb_per_forward": ws / max(nw, 1),
+                       "bytes_per_patch": per_patch}},
+              open(os.path.join(PROF, "%s_effnet_traffic.json" % tag), "w"), indent=1)
+    print("effnet traffic: %.2f MB / patch over %d forwards" % (per_patch / 1e6, nf))
+gl_f, gl_w = os.path.join(PROF, "%s_glancer_fetch.md" % tag), os.path.join(PROF, "%s_glancer_write.md" % tag)
+if os.path.exists(gl_f) and os.path.exists(gl_w):
+    fs, nf = all_kernels_sum(gl_f, "FETCH_SIZE", "mb_stem_b1")
+    ws, nw = all_kernels_sum(gl_w, "WRITE_SIZE", "mb_stem_b1")
+    # (the stem + block-1 kernel runs once per 512-frame chunk: two dispatches per 1024-frame forward)
+    per_frame = int((2 * fs / max(nf, 1) + ws / max(nw, 1)) * 1024 / 512)
+    json.dump({"source": "profiles/%s_glancer_fetch.md + %s_glancer_write.md" % (tag, tag), "frames": 1024, "chunks_counted": [nf, nw],
+               "bytes_per_frame": per_frame}, open(os.path.join(PROF, "%s_glancer_traffic.json" % tag), "w"), indent=1)
+    print("glancer traffic: %.2f MB / frame" % (per_frame / 1e6))
