@@ -40,6 +40,7 @@ struct AdafOptions {
     int latency_linear_rows = 128;  // "latency_linear_rows": the same for adaf_linear / GRU projections
     unsigned effnet_plan = 31u;   // "effnet_plan": ADAF_EF_PLAN_* bits
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
+    int gru_scan_slices = 2;      // "gru_scan_slices": clip slices a persistent GRU scan may be cut into (1 | 2; gru_scan.hip)
 };
 AdafOptions& adaf_options();
 
@@ -132,9 +133,10 @@ bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, in
 // gru_scan.hip
 int adaf_gru_scan_blocks_per_cu();
 bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int resident_blocks);
+int adaf_gru_scan_groups(int batch, int resident_blocks);
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
                                            unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
-                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts,
+                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, int groups,
                                            hipStream_t s);
 
 // conv_gemm.hip

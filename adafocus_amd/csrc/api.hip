@@ -79,7 +79,7 @@ namespace {
 struct OptKey { const char* name; int kind; double lo, hi; };      // kind: index into the switch of opt_ref
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
-                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 31}, {"effnet_chunk", 10, 1, 1 << 20}};
+                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 31}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
     for (const OptKey& k : kOptKeys)
@@ -160,6 +160,7 @@ int adaf_set_option(adaf_handle* h, const char* key, double value) {
         case 7: o.latency_rows = (int)value; break;
         case 8: o.latency_linear_rows = (int)value; break;
         case 9: o.effnet_plan = (unsigned)value; break;
+        case 11: o.gru_scan_slices = (int)value; break;
         default: o.effnet_chunk = (int)value; break;
     }
     return ADAF_OK;
@@ -180,6 +181,7 @@ double adaf_get_option(const char* key) {
         case 7: return o.latency_rows;
         case 8: return o.latency_linear_rows;
         case 9: return o.effnet_plan;
+        case 11: return o.gru_scan_slices;
         default: return o.effnet_chunk;
     }
 }
@@ -934,17 +936,23 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
         const bool capturing = cap != hipStreamCaptureStatusNone;
-        const int slot = h->scan_next;
+        // a scan cut into two slices (batch > 32) takes two sets of blocks, i.e. two of the slots the resident-block budget is made of
+        const int groups = (2 * steps + 2 <= batch * 3 * hidden) ? adaf_gru_scan_groups(batch, h->scan_resident) : 1;
+        const int need = groups > h->scan_slots ? h->scan_slots : groups;
+        int slots[2] = {h->scan_next, (h->scan_next + 1) % h->scan_slots};
         if (!capturing) {
-            h->scan_next = (slot + 1) % h->scan_slots;
-            if (h->scan_used[slot]) (void)hipStreamWaitEvent(st, h->scan_done[slot], 0);   // the scan scan_slots launches ago has finished
+            h->scan_next = (h->scan_next + need) % h->scan_slots;
+            for (int i = 0; i < need; ++i)
+                if (h->scan_used[slots[i]]) (void)hipStreamWaitEvent(st, h->scan_done[slots[i]], 0);   // the scans that held these slots have finished
         }
         hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), batch, steps, fc_w,
-                                                       fc_b, logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, st);
+                                                       fc_b, logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, groups, st);
         if (e != hipSuccess) return hip_fail(h, e, "gru scan launch");
         if (!capturing) {
-            (void)hipEventRecord(h->scan_done[slot], st);
-            h->scan_used[slot] = true;
+            for (int i = 0; i < need; ++i) {
+                (void)hipEventRecord(h->scan_done[slots[i]], st);
+                h->scan_used[slots[i]] = true;
+            }
         }
         return ADAF_OK;
     }

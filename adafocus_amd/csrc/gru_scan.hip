@@ -42,6 +42,7 @@ struct GruScanArgs {
     float* last;         // [B, C] or nullptr
     int C, cpb;          // classes, classes per block
     unsigned* timeouts;  // device counter bumped by a block whose barrier wait ran out (or nullptr)
+    int groups, bg;      // the batch in `groups` independent slices of `bg` clips, each with its own H / JB blocks and barrier words
 };
 
 template <int H, int JB>
@@ -50,9 +51,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     __shared__ float red[4][2][32][33];
     __shared__ int timed_out;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, nl = lane & 31;
-    const int j0 = blockIdx.x * JB;
-    const int c0 = blockIdx.x * a.cpb;                 // first class of this block
-    const int B = a.B, T = a.T;
+    // Clips are independent: with more than one m-tile of clips and CUs to spare the batch is cut into `groups` slices, each scanned
+    // by its own set of H / JB blocks with its own barrier words (B = 64: two slices of 32 clips on 256 CUs -- the products of a step
+    // take half the time; every clip's arithmetic is unchanged).
+    constexpr int NBLK = H / JB;
+    const int grp = blockIdx.x / NBLK, jb = blockIdx.x - grp * NBLK;
+    const int j0 = jb * JB;
+    const int c0 = jb * a.cpb;                         // first class of this block
+    const int T = a.T;
+    const int bbeg = grp * a.bg;
+    const int B = min(a.B, bbeg + a.bg);               // this slice's clips: [bbeg, B)
+    unsigned* bar = a.bar + grp * (T + 1);
     if (tid == 0) timed_out = 0;
 
     f32x4 wreg[NKK];
@@ -76,11 +85,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     const bool fc = a.fcw != nullptr;
     const int steps_total = T + (fc ? 1 : 0);
-    const int nchunk = (B + 63) >> 6;
+    const int nchunk = (B - bbeg + 63) >> 6;
     for (int t = 0; t < steps_total; ++t) {
         const bool have_prev = t > 0 || a.h0 != nullptr;
         for (int ch = 0; ch < nchunk; ++ch) {
-            const int b0 = ch << 6;
+            const int b0 = bbeg + (ch << 6);
             const int rows = B - b0 < 64 ? B - b0 : 64;
             if (have_prev) {
                 const int mt = (rows + 31) >> 5;
@@ -138,24 +147,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (t + 1 < steps_total) {
             __syncthreads();
             if (tid == 0) {
-                __threadfence();                      // release: this block's h_t is visible device-wide
-                atomicAdd(a.bar + t, 1u);
+                // release (write back this XCD's L2: the block's h_t becomes visible device-wide) -> arrive -> ONE relaxed poll loop ->
+                // acquire (invalidate this CU's L1).  Polling with acquire loads and two full __threadfence()s, as this barrier did
+                // until round 4, is 13 us per step on this device; this form 7 (MI355X_MICROARCH.md, barrier-counter row).  The asm wait
+                // keeps the arrive behind the write-back (the compiler may drop the fence's own wait when its scoreboard looks empty).
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(bar + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned spins = 0;
-                while (__hip_atomic_load(a.bar + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1u << 23)) { timed_out = 1; break; }
+                while (__hip_atomic_load(bar + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NBLK) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) { timed_out = 1; break; }
                 }
-                __threadfence();                      // acquire: the other blocks' h_t
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             if (timed_out) {   // never observed; refuses to hang the device if the grid cannot become co-resident
                 if (tid == 0 && a.timeouts) atomicAdd(a.timeouts, 1u);     // ... and tells the host (adaf_gru_scan_timeouts)
                 const float nan = __builtin_nanf("");
-                for (int idx = tid; idx < B * JB; idx += 256)
-                    for (int tt = t + 1; tt < T; ++tt) a.hs[((size_t)(idx / JB) * T + tt) * H + j0 + idx % JB] = nan;
+                for (int idx = tid; idx < (B - bbeg) * JB; idx += 256)
+                    for (int tt = t + 1; tt < T; ++tt) a.hs[((size_t)(bbeg + idx / JB) * T + tt) * H + j0 + idx % JB] = nan;
                 if (fc)
-                    for (int idx = tid; idx < B * a.cpb; idx += 256) {
-                        const int b = idx / a.cpb, cls = c0 + idx % a.cpb;
+                    for (int idx = tid; idx < (B - bbeg) * a.cpb; idx += 256) {
+                        const int b = bbeg + idx / a.cpb, cls = c0 + idx % a.cpb;
                         if (cls < a.C) {
                             for (int tt = t; tt < T; ++tt) a.logits[((size_t)b * T + tt) * a.C + cls] = nan;
                             if (a.last) a.last[(size_t)b * a.C + cls] = nan;
@@ -194,22 +208,30 @@ bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int residen
     return hidden == kH && batch >= 1 && batch <= 256 && classes <= 8 * kGrid && resident_blocks >= kGrid;
 }
 
+// slices a scan of `batch` clips is cut into (each takes H / 8 = 128 co-resident blocks): 2 when there is more than one m-tile of clips
+// and the device can hold both sets of blocks
+int adaf_gru_scan_groups(int batch, int resident_blocks) {
+    return (adaf_options().gru_scan_slices >= 2 && batch > 32 && resident_blocks >= 2 * kGrid) ? 2 : 1;
+}
+
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
                                            unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
-                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts,
+                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, int groups,
                                            hipStream_t s) {
     GruScanArgs a;
     a.timeouts = timeouts;
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;
     a.fcw = fcw; a.fcb = fcb; a.logits = logits; a.last = last; a.C = fcw ? classes : 0;
     a.cpb = fcw ? (classes + kGrid - 1) / kGrid : 0;
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, bar, steps + 1);
+    a.groups = groups < 1 ? 1 : groups;
+    a.bg = a.groups == 1 ? batch : ((batch + a.groups - 1) / a.groups + 31) / 32 * 32;      // whole m-tiles per slice
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, bar, a.groups * (steps + 1));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (cooperative) {
         void* params[] = {&a};
-        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel<kH, kJB>), dim3(kGrid), dim3(256), params, 0, s);
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel<kH, kJB>), dim3(kGrid * a.groups), dim3(256), params, 0, s);
     }
-    hipLaunchKernelGGL((gru_scan_kernel<kH, kJB>), dim3(kGrid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gru_scan_kernel<kH, kJB>), dim3(kGrid * a.groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -75,7 +75,7 @@ int adaf_set_conv_pos_major(adaf_handle* h, int on);
 /* Process-wide tuning / A-B switches (they replace the ADAF_* environment variables of earlier rounds; the defaults are the plan
  * every reported number is measured with, INTEGRATION.md lists them).  Keys:
  *   "conv_lean" 0|1, "pm_fill" 0..1, "conv_pool" 0|1, "resize_lds_kb", "mb_wave" 0|1, "dw3_variant" 0..4, "mbv2_chunk",
- *   "latency_rows", "latency_linear_rows", "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk".
+ *   "latency_rows", "latency_linear_rows", "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk", "gru_scan_slices" 1|2.
  * adaf_set_option returns ADAF_E_BADARG for an unknown key or a value out of range; adaf_get_option returns the current value
  * (NaN for an unknown key).  Not thread-safe against concurrent launches: set options between forwards. */
 enum {
