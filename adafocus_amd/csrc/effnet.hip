@@ -413,13 +413,18 @@ __global__ __launch_bounds__(1024) void ef_expand_kernel(const ExpArgs a) {
     const T* xb = static_cast<const T*>(a.x);
     const int stride = gridDim.x * nwaves;
     int strip = blockIdx.x * nwaves + wave;
-    auto load = [&](int st, u32x4 (&f)[KS]) {
+    auto load = [&](int st, u32x4 (&f)[KS]) {         // (unconditional loads from clamped addresses, zeroed afterwards)
         const long long row = (long long)st * 32 + nl;
         const bool ok = st < a.strips && row < a.M;
-        const T* src = xb + (size_t)(ok ? row : 0) * a.K + half * V;
+        const T* src = xb + (size_t)(ok ? row : 0) * a.K;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int k = kk * KSTEP + half * V;
+            f[kk] = *reinterpret_cast<const u32x4*>(src + (k < a.K ? k : 0));
+        }
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-            f[kk] = (ok && kk * KSTEP + half * V < a.K) ? *reinterpret_cast<const u32x4*>(src + kk * KSTEP) : u32x4{0u, 0u, 0u, 0u};
+            if (!(ok && kk * KSTEP + half * V < a.K)) f[kk] = u32x4{0u, 0u, 0u, 0u};
     };
     u32x4 af[KS], an[KS];
     load(strip, af);
@@ -548,23 +553,27 @@ __global__ __launch_bounds__(512) void ef_nproj_kernel(const NprojArgs a) {
         const long long row = (long long)st * 32 + nl;
         const bool ok = st < a.strips && row < a.M;
         const long long rr = ok ? row : 0;
-        const T* src = xb + (size_t)rr * a.K + half * V;
-        const float* g = a.gate + (size_t)(rr / a.HW) * a.K + half * V;
+        const T* src = xb + (size_t)rr * a.K;
+        const float* g = a.gate + (size_t)(rr / a.HW) * a.K;
+        u32x4 xv[KS];
+        f32x4 gq[KS][V / 4];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {                 // (unconditional loads from clamped addresses, every one in flight before the first use)
+            const int k = kk * KSTEP + half * V, kc = k < a.K ? k : 0;
+            xv[kk] = *reinterpret_cast<const u32x4*>(src + kc);
+#pragma unroll
+            for (int e = 0; e < V / 4; ++e) gq[kk][e] = *reinterpret_cast<const f32x4*>(g + kc + 4 * e);
+        }
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok && kk * KSTEP + half * V < a.K) {
-                v = *reinterpret_cast<const u32x4*>(src + kk * KSTEP);
-                float f32[V];
-                Chunk<T>::unpack(v, f32);
+            float f32[V];
+            Chunk<T>::unpack(xv[kk], f32);
 #pragma unroll
-                for (int e = 0; e < V; e += 4) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + kk * KSTEP + e);
-                    f32[e] *= gv.x; f32[e + 1] *= gv.y; f32[e + 2] *= gv.z; f32[e + 3] *= gv.w;
-                }
-                v = Chunk<T>::pack(f32);
+            for (int e = 0; e < V; e += 4) {
+                const f32x4 gv = gq[kk][e / 4];
+                f32[e] *= gv.x; f32[e + 1] *= gv.y; f32[e + 2] *= gv.z; f32[e + 3] *= gv.w;
             }
-            f[kk] = v;
+            f[kk] = (ok && kk * KSTEP + half * V < a.K) ? Chunk<T>::pack(f32) : u32x4{0u, 0u, 0u, 0u};
         }
     };
     u32x4 af[KS], an[KS];
@@ -780,32 +789,41 @@ __global__ __launch_bounds__(256) void gated_project_kernel(const ProjArgs a) {
         brow[p] = wb + (size_t)(bok[p] ? n : 0) * a.K;
     }
     u32x4 ra[4], rb[TN];
+    // (every load of a slice is UNCONDITIONAL, from a clamped address, and issued before the first use: written as `if (ok) { load; gate }`
+    // per row, hipcc gave each row its own branch with an s_waitcnt vmcnt(0) inside -- four round trips in a row per slice)
     auto gload = [&](int kt) {
         const int k0 = kt * BKE + q * V;
         const bool kok = k0 < a.K;
+        const int kc = kok ? k0 : 0;
+        u32x4 xv[4];
+        f32x4 gv[4][V / 4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (aok[p] && kok) {
-                v = *reinterpret_cast<const u32x4*>(arow[p] + k0);
-                if (a.gate) {
-                    float f[V];
-                    Chunk<T>::unpack(v, f);
+        for (int p = 0; p < 4; ++p) xv[p] = *reinterpret_cast<const u32x4*>(arow[p] + kc);
+        if (a.gate) {
 #pragma unroll
-                    for (int e = 0; e < V; e += 4) {
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(grow[p] + k0 + e);
-                        f[e] *= g.x; f[e + 1] *= g.y; f[e + 2] *= g.z; f[e + 3] *= g.w;
-                    }
-                    v = Chunk<T>::pack(f);
-                }
-            }
-            ra[p] = v;
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int e = 0; e < V / 4; ++e) gv[p][e] = *reinterpret_cast<const f32x4*>(grow[p] + kc + 4 * e);
         }
 #pragma unroll
-        for (int p = 0; p < TN; ++p) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (bok[p] && kok) v = *reinterpret_cast<const u32x4*>(brow[p] + k0);
-            rb[p] = v;
+        for (int p = 0; p < TN; ++p) rb[p] = *reinterpret_cast<const u32x4*>(brow[p] + kc);
+#pragma unroll
+        for (int p = 0; p < TN; ++p)
+            if (!(bok[p] && kok)) rb[p] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 v = xv[p];
+            if (a.gate) {
+                float f[V];
+                Chunk<T>::unpack(v, f);
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 g = gv[p][e / 4];
+                    f[e] *= g.x; f[e + 1] *= g.y; f[e + 2] *= g.z; f[e + 3] *= g.w;
+                }
+                v = Chunk<T>::pack(f);
+            }
+            ra[p] = (aok[p] && kok) ? v : u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto lstore = [&]() {
