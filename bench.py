@@ -138,8 +138,10 @@ def init_failure_line(a, world, rank, backend, exc):
     text = json.dumps(line)
     if rank == 0:
         print(text, flush=True)
+        time.sleep(1.0)       # the launcher tears the group down at the first non-zero exit: let the other ranks' stderr lines out first
     else:
         print("bench.py rank %d: %s" % (rank, text), file=sys.stderr, flush=True)
+        time.sleep(3.0)       # ... and never before rank 0 has had the time to print THE line
 
 
 def load_effnet_traffic(dtype, patches, p):

@@ -64,4 +64,4 @@ def test_bench_distributed_init_failure_leaves_one_diagnosable_line():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 8 and r["rccl_ranks"] == 0 and r["value"] is None and "error" in r and "injected failure" in r["exception"]
     assert r["env"]["WORLD_SIZE"] == "8" and r["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MASTER_ADDR" in r["env"]
-    assert out.stderr.count("bench.py rank") == 7            # the other ranks report on stderr
+    assert 1 <= out.stderr.count("bench.py rank") <= 7       # the other ranks report on stderr (those the launcher had not torn down yet)
