@@ -44,6 +44,19 @@ struct AdafOptions {
 };
 AdafOptions& adaf_options();
 
+// fp32 -> fp16 STORAGE: what is converted is the ROUNDED fp32 result.  Left to itself the compiler folds `(_Float16)(a * b)` (and a * b + c,
+// a + c) into v_fma_mixlo_f16 -- ONE rounding of the exact result -- for SOME elements of an unrolled epilogue and not for others (seen: 15 of
+// the 16 accumulators of ef_expand_kernel; the last went v_mul_f32 + v_cvt_f16_f32), and the two disagree in the last bit about once per
+// 2^12 values: a frame's features then depended on which MFMA row its pixels landed on, i.e. on its position in the batch, and the
+// "bit-identical" kernel forms were identical only as long as the compiler made the same choice in each.  The empty asm makes the fp32
+// value opaque to that fold (no instruction).
+__device__ __forceinline__ _Float16 adaf_f16_of(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(v));
+#endif
+    return (_Float16)v;
+}
+
 // Flattened description of one implicit-GEMM convolution launch.
 struct ConvArgs {
     const float* x;

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "adaf_internal.h"
@@ -37,6 +38,7 @@ namespace {
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
     static constexpr int V = 4;
+    static __device__ __forceinline__ float one(float v) { return v; }
     static __device__ __forceinline__ void unpack(const u32x4 u, float (&f)[4]) {
         f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
     }
@@ -46,6 +48,7 @@ template <> struct Chunk<float> {
 };
 template <> struct Chunk<_Float16> {
     static constexpr int V = 8;
+    static __device__ __forceinline__ _Float16 one(float v) { return adaf_f16_of(v); }
     static __device__ __forceinline__ void unpack(const u32x4 u, float (&f)[8]) {
         const f16x8 h = __builtin_bit_cast(f16x8, u);
 #pragma unroll
@@ -54,7 +57,7 @@ template <> struct Chunk<_Float16> {
     static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
         f16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e];
+        for (int e = 0; e < 8; ++e) h[e] = adaf_f16_of(f[e]);
         return __builtin_bit_cast(u32x4, h);
     }
 };
@@ -65,6 +68,7 @@ __device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn
 __device__ __forceinline__ float act_apply(float v, int act) {
     // (one logistic evaluation whichever of the two activations wants it: written as two separate branches the compiler
     // if-converted them and every element paid for both exp2 / rcp pairs)
+#pragma clang fp contract(off)       // (the swish product is a rounded value of its own: see act_of)
     if (act == ADAF_ACT_SWISH || act == ADAF_ACT_SIGMOID) {
         const float g = fast_sigmoid(v);
         return act == ADAF_ACT_SWISH ? v * g : g;
@@ -72,6 +76,24 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ADAF_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ADAF_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
     return v;
+}
+
+// The network's own activation (swish) as a compile-time constant.  With the runtime `act` every ELEMENT of an epilogue went through
+// two scalar compare-and-branch pairs (the compiler does not unswitch the unrolled epilogue loops: 65 of each per 32 outputs in the
+// depthwise kernel, with the relu / relu6 min-max pairs evaluated beside the logistic): act_switch runs the epilogue body once with
+// ACT = swish, or once with ACT = -1 (any other activation, resolved per element as before).
+template <int ACT>
+__device__ __forceinline__ float act_of(float v, int act) {
+    // (the product is a ROUNDED value -- it is what gets stored -- so it must not be contracted into the squeeze sum that follows it in
+    //  some epilogues and not in others: the pooled sums of every kernel form have to agree to the bit)
+#pragma clang fp contract(off)
+    if constexpr (ACT == ADAF_ACT_SWISH) return v * fast_sigmoid(v);
+    else return act_apply(v, act);
+}
+template <typename F>
+__device__ __forceinline__ void act_switch(int act, F&& f) {
+    if (act == ADAF_ACT_SWISH) f(std::integral_constant<int, ADAF_ACT_SWISH>{});
+    else f(std::integral_constant<int, -1>{});
 }
 
 // ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
@@ -237,18 +259,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                 sc[e] = s4.x; sc[e + 1] = s4.y; sc[e + 2] = s4.z; sc[e + 3] = s4.w;
                 bi[e] = b4.x; bi[e + 1] = b4.y; bi[e + 2] = b4.z; bi[e + 3] = b4.w;
             }
+            act_switch(a.act, [&](auto AC) {
 #pragma unroll
-            for (int o = 0; o < OXT; ++o) {
-                if (ox0 + o < a.OW) {
-                    float v[V];
+                for (int o = 0; o < OXT; ++o) {
+                    if (ox0 + o < a.OW) {
+                        float v[V];
 #pragma unroll
-                    for (int e = 0; e < V; ++e) {
-                        v[e] = act_apply(fmaf(acc[o][e], sc[e], bi[e]), a.act);
-                        psum[e] += v[e];
+                        for (int e = 0; e < V; ++e) {
+                            v[e] = act_of<decltype(AC)::value>(fmaf(acc[o][e], sc[e], bi[e]), a.act);
+                            psum[e] += v[e];
+                        }
+                        *reinterpret_cast<u32x4*>(op + o * a.C) = Chunk<T>::pack(v);
                     }
-                    *reinterpret_cast<u32x4*>(op + o * a.C) = Chunk<T>::pack(v);
                 }
-            }
+            });
             xg += dxg; r += dr;
             if (xg >= nxg) { xg -= nxg; ++r; }
         }
@@ -277,8 +301,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
 // (25 pixels x 4 channels, straight from global memory, every load in flight at once), converts it once, keeps all HW^2 x 4
 // accumulators in registers and visits exactly the (output, tap) pairs that fall inside the map -- the loops are unrolled at
 // compile time, so "inside" costs nothing -- in the same (ky, kx) order per output as everywhere else (a skipped tap would have
-// added an exact zero): bit-identical to dw_same_kernel.  The squeeze sum of an (image, channel) is thread-local: no LDS, no
-// barrier, no partial tiles.  b19-b23 (5 x 5 window, 1392 channels): 110 -> ~45 us per 1024 patches.
+// added an exact zero): the OUTPUT is bit-identical to dw_same_kernel's.  The squeeze sum of an (image, channel) is thread-local -- no LDS,
+// no barrier, no partial tiles -- and adds the pixels in raster order, not in dw_same_kernel's (thread partials, then threads): the two
+// sums differ in the last bit for about half the channels of a noise input (round 4, tests/test_effnet.py).  b19-b23 (5 x 5 window, 1392 channels): 110 -> ~45 us per 1024 patches.
 struct DsArgs {
     const void* x;
     void* out;
@@ -300,7 +325,7 @@ template <> struct Quad<_Float16> {
         const h4 v = *reinterpret_cast<const h4*>(p);
         return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
     }
-    static __device__ __forceinline__ void st(_Float16* p, f32x4 v) { *reinterpret_cast<h4*>(p) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+    static __device__ __forceinline__ void st(_Float16* p, f32x4 v) { *reinterpret_cast<h4*>(p) = h4{adaf_f16_of(v.x), adaf_f16_of(v.y), adaf_f16_of(v.z), adaf_f16_of(v.w)}; }
 };
 
 template <int K, int HW, typename T>
@@ -341,18 +366,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                         s.x = fmaf(xin.x, w.x, s.x); s.y = fmaf(xin.y, w.y, s.y); s.z = fmaf(xin.z, w.z, s.z); s.w = fmaf(xin.w, w.w, s.w);
                     }
             }
+        act_switch(a.act, [&](auto AC) {
+            constexpr int ACT = decltype(AC)::value;
 #pragma unroll
-        for (int q = 0; q < RA * HW; ++q) {
-            const int p = r0 * HW + q;
-            if (p >= HW * HW) continue;
-            f32x4 o;
-            o.x = act_apply(fmaf(acc[q].x, sc.x, bi.x), a.act);
-            o.y = act_apply(fmaf(acc[q].y, sc.y, bi.y), a.act);
-            o.z = act_apply(fmaf(acc[q].z, sc.z, bi.z), a.act);
-            o.w = act_apply(fmaf(acc[q].w, sc.w, bi.w), a.act);
-            psum += o;
-            Quad<T>::st(ob + (size_t)p * a.C, o);
-        }
+            for (int q = 0; q < RA * HW; ++q) {
+                const int p = r0 * HW + q;
+                if (p >= HW * HW) continue;
+                f32x4 o;
+                o.x = act_of<ACT>(fmaf(acc[q].x, sc.x, bi.x), a.act);
+                o.y = act_of<ACT>(fmaf(acc[q].y, sc.y, bi.y), a.act);
+                o.z = act_of<ACT>(fmaf(acc[q].z, sc.z, bi.z), a.act);
+                o.w = act_of<ACT>(fmaf(acc[q].w, sc.w, bi.w), a.act);
+                psum += o;
+                Quad<T>::st(ob + (size_t)p * a.C, o);
+            }
+        });
     }
     if (a.pool_part) *reinterpret_cast<f32x4*>(a.pool_part + (size_t)img * a.C + 4 * cq) = psum;
 }
@@ -457,11 +485,13 @@ __global__ __launch_bounds__(1024) void ef_expand_kernel(const ExpArgs a) {
                     }
                     const float sc = sb[n0 + nl], bi = sb[a.NP + n0 + nl];
                     char* srow = slab + (size_t)((WHOLE ? n0 : j * 32) + nl) * sizeof(T);
+                    act_switch(a.act, [&](auto AC) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int p = (i & 3) + 8 * (i >> 2) + 4 * half;
-                        *reinterpret_cast<T*>(srow + p * SROW) = (T)act_apply(fmaf(acc[i], sc, bi), a.act);
-                    }
+                        for (int i = 0; i < 16; ++i) {
+                            const int p = (i & 3) + 8 * (i >> 2) + 4 * half;
+                            *reinterpret_cast<T*>(srow + p * SROW) = Chunk<T>::one(act_of<decltype(AC)::value>(fmaf(acc[i], sc, bi), a.act));
+                        }
+                    });
                 }
             }
             if (!WHOLE) {
@@ -712,7 +742,12 @@ __global__ __launch_bounds__(NT) void se_gate_kernel(const float* __restrict__ p
             for (int j = 0; j < SQ; ++j) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)j * we_ldj);
 #pragma unroll
-                for (int g = 0; g < G; ++g) s[g] += wv * sq[g * SQ + j];
+                for (int g = 0; g < G; ++g) {
+                    // (explicit fused multiply-adds: written `s[g] += wv * q` the compiler contracted the products of some images of the
+                    //  group and not of others -- a frame's gate depended, in the last bit, on its position in the batch)
+                    const float q = sq[g * SQ + j];
+                    s[g].x = fmaf(wv.x, q, s[g].x); s[g].y = fmaf(wv.y, q, s[g].y); s[g].z = fmaf(wv.z, q, s[g].z); s[g].w = fmaf(wv.w, q, s[g].w);
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -925,7 +960,7 @@ __global__ __launch_bounds__(256) void gated_project_kernel(const ProjArgs a) {
             if (m >= a.M) continue;
             float v = fmaf(acc[j][i], sc, bi);
             if (rs) v += (float)rs[(size_t)m * a.N + n];
-            ob[(size_t)m * a.N + n] = (T)act_apply(v, a.act);
+            ob[(size_t)m * a.N + n] = Chunk<T>::one(act_apply(v, a.act));
         }
     }
 }
@@ -1018,13 +1053,15 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
         }
         // epilogue: BN + activation, through the wave's slab, 16-byte stores of V consecutive channels
         __builtin_amdgcn_wave_barrier();
+        act_switch(a.act, [&](auto AC) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + nl;
+            for (int j = 0; j < 2; ++j) {
+                const int col = j * 32 + nl;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                sl[((i & 3) + 8 * (i >> 2) + 4 * half) * SP + col] = act_apply(fmaf(acc[j][i], sc[j], bi[j]), a.act);
-        }
+                for (int i = 0; i < 16; ++i)
+                    sl[((i & 3) + 8 * (i >> 2) + 4 * half) * SP + col] = act_of<decltype(AC)::value>(fmaf(acc[j][i], sc[j], bi[j]), a.act);
+            }
+        });
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < 32 * cpr; i += 64) {
             const int p = i / cpr, cq = i - p * cpr;

@@ -40,9 +40,8 @@ constexpr int kMbwWaves = kMbwThreads / 64;
 constexpr int kMbwMaxRounds = 4;          // channel pairs per wave: hid <= 64 * 8 * 4 = 2048 (= 4 x 512 threads in the SE expand FC)
 
 __device__ __forceinline__ float w_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
-__device__ __forceinline__ float w_swish(float v) { return v * w_sigmoid(v); }
 // two values at a time on the packed fp32 instructions (v_pk_mul / v_pk_add; a plain VALU instruction of a wave takes ~4 cycles on
-// gfx950 and the vector part of this kernel is what bounds it): the same operations in the same order as w_swish
+// gfx950 and the vector part of this kernel is what bounds it): the same operations in the same order as v * w_sigmoid(v)
 __device__ __forceinline__ f32x2 w_swish2(f32x2 t) {
     f32x2 e = t * -1.4426950408889634f;
     e.x = __builtin_amdgcn_exp2f(e.x); e.y = __builtin_amdgcn_exp2f(e.y);
@@ -210,8 +209,8 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 for (int i = 0; i < 16; i += 2) {
                     const f32x2 t0 = w_swish2(w_fma2(f32x2{acc[0][b][i], acc[0][b][i + 1]}, sce0, bie0));
                     const f32x2 t1 = w_swish2(w_fma2(f32x2{acc[1][b][i], acc[1][b][i + 1]}, sce1, bie1));
-                    acc[0][b][i] = (float)(_Float16)t0.x; acc[0][b][i + 1] = (float)(_Float16)t0.y;
-                    acc[1][b][i] = (float)(_Float16)t1.x; acc[1][b][i + 1] = (float)(_Float16)t1.y;
+                    acc[0][b][i] = (float)adaf_f16_of(t0.x); acc[0][b][i + 1] = (float)adaf_f16_of(t0.y);
+                    acc[1][b][i] = (float)adaf_f16_of(t1.x); acc[1][b][i + 1] = (float)adaf_f16_of(t1.y);
                 }
             // lanes 0-31 take tile 0's other half-rows, lanes 32-63 give them and take tile 1's: afterwards acc[h][b][i] of lane l is
             // row 32 b + (i & 3) + 8 (i >> 2) + 4 h of channel 64 jp + l
@@ -401,7 +400,11 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 for (int u = 0; u < GJB; ++u)
                     if (j0 + u < SQ) {
 #pragma unroll
-                        for (int g = 0; g < G; ++g) sg[g] += wj[u] * sqv[g * SQ + j0 + u];
+                        for (int g = 0; g < G; ++g) {          // (explicit fmaf: the contraction of `sg += w * q` is the compiler's choice per image)
+                            const float q = sqv[g * SQ + j0 + u];
+                            sg[g].x = fmaf(wj[u].x, q, sg[g].x); sg[g].y = fmaf(wj[u].y, q, sg[g].y);
+                            sg[g].z = fmaf(wj[u].z, q, sg[g].z); sg[g].w = fmaf(wj[u].w, q, sg[g].w);
+                        }
                     }
             }
             if (tid < C4) {
@@ -427,10 +430,10 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             const f16x8 v = *reinterpret_cast<const f16x8*>(p);
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
             f16x8 o;
-            o[0] = (_Float16)((float)v[0] * g0.x); o[1] = (_Float16)((float)v[1] * g0.y);
-            o[2] = (_Float16)((float)v[2] * g0.z); o[3] = (_Float16)((float)v[3] * g0.w);
-            o[4] = (_Float16)((float)v[4] * g1.x); o[5] = (_Float16)((float)v[5] * g1.y);
-            o[6] = (_Float16)((float)v[6] * g1.z); o[7] = (_Float16)((float)v[7] * g1.w);
+            o[0] = adaf_f16_of((float)v[0] * g0.x); o[1] = adaf_f16_of((float)v[1] * g0.y);
+            o[2] = adaf_f16_of((float)v[2] * g0.z); o[3] = adaf_f16_of((float)v[3] * g0.w);
+            o[4] = adaf_f16_of((float)v[4] * g1.x); o[5] = adaf_f16_of((float)v[5] * g1.y);
+            o[6] = adaf_f16_of((float)v[6] * g1.z); o[7] = adaf_f16_of((float)v[7] * g1.w);
             *reinterpret_cast<f16x8*>(p) = o;
             row += drow; cq += dcc;
             if (cq >= cpr) { cq -= cpr; ++row; }
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);
-                        if (pr + 4 * half < PX) outb[obase + ((b / RB) * PX + pr) * a.cout] = (_Float16)(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
+                        if (pr + 4 * half < PX) outb[obase + ((b / RB) * PX + pr) * a.cout] = adaf_f16_of(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
                     }
                 }
             }

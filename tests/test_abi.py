@@ -52,6 +52,36 @@ def test_no_gpu_fails_loudly():
     assert _lib.load_library().adaf_create(0, ctypes.byref(h)) == -3   # ADAF_E_ARCH: no gfx950 device
 
 
+def test_no_kernel_converts_to_fp16_with_a_single_rounding(tmp_path):
+    """fp16 STORAGE means: the fp32 result, rounded, then converted.  The compiler may fold `(_Float16)(a * b)` into v_fma_mixlo_f16 /
+    v_fma_mixhi_f16 -- one rounding of the exact product -- and it does so per ELEMENT of an unrolled epilogue (round 4: 15 of 16
+    accumulators of the expand kernel), so a frame's features depended on which MFMA row its pixels landed on and the "bit-identical"
+    kernel forms only agreed while the compiler made the same choice in each.  adaf_f16_of (csrc/adaf_internal.h) closes that; this test
+    disassembles every gfx950 code object of the built library and fails if the fold comes back anywhere."""
+    import glob
+    import shutil
+    import subprocess
+    _ensure_built()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    cos = sorted(glob.glob(str(tmp_path / "lib.so.*gfx950*")))
+    assert cos, os.listdir(tmp_path)
+    bad = {}
+    for co in cos:
+        dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+            elif "v_fma_mixlo_f16" in line or "v_fma_mixhi_f16" in line:
+                bad[cur] = bad.get(cur, 0) + 1
+    assert not bad, bad
+
+
 def test_product_package_never_imports_oracle():
     pkg = os.path.join(ROOT, "adafocus_amd")
     for dirpath, _, files in os.walk(pkg):
