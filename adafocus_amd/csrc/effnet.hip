@@ -1024,18 +1024,41 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
     float* sl = slab[wave];
     // this lane's pixel of the band: row 2 wave + (nl >> 4), column nl & 15
     const float* win = xin + ((2 * (2 * wave + (nl >> 4))) * IW + 2 * (nl & 15)) * 4;
+    // the window of tile tx + 1 travels (in registers) under the products of tile tx: every load unconditional, from a clamped address, zeroed
+    // afterwards where it fell into the padding -- written as a guarded load per pixel the three loads of a thread were three round trips in a
+    // row at the head of every tile (SQ_WAIT_INST 37 % of the wave cycles, VALU 13 %)
+    constexpr int WPT = (IH * IW + 255) / 256;               // window pixels per thread
+    f32x4 wv[WPT];
+    const int iy0 = oy0 * 2 - a.pad;
+    int wr[WPT], wc[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int i = tid + 256 * u;
+        wr[u] = i / IW; wc[u] = i - wr[u] * IW;
+    }
+    auto wload = [&](int tx) {
+        const int ix0 = tx * TW * 2 - a.pad;
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int iy = iy0 + wr[u], ix = ix0 + wc[u];
+            const bool ok = (unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S;
+            wv[u] = *reinterpret_cast<const f32x4*>(xb + (ok ? ((size_t)iy * a.S + ix) * 4 : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int iy = iy0 + wr[u], ix = ix0 + wc[u];
+            if (!((unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S)) wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    wload(0);
     for (int tx = 0; tx < a.tiles_x; ++tx) {
         const int ox0 = tx * TW;
-        const int iy0 = oy0 * 2 - a.pad, ix0 = ox0 * 2 - a.pad;
         if (tx) __syncthreads();                              // the previous tile's window has been consumed
-        for (int i = tid; i < IH * IW; i += 256) {
-            const int r = i / IW, c = i - r * IW;
-            const int iy = iy0 + r, ix = ix0 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S) v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * a.S + ix) * 4);
-            *reinterpret_cast<f32x4*>(xin + i * 4) = v;
-        }
+#pragma unroll
+        for (int u = 0; u < WPT; ++u)
+            if (tid + 256 * u < IH * IW) *reinterpret_cast<f32x4*>(xin + (tid + 256 * u) * 4) = wv[u];
         __syncthreads();
+        if (tx + 1 < a.tiles_x) wload(tx + 1);
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
