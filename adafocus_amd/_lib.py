@@ -35,7 +35,7 @@ SYMBOLS = (
     "adaf_conv2d_bn_act_f16", "adaf_pack_conv_weight_f16", "adaf_cast_f32_f16", "adaf_dwconv3x3_bn_act_f16", "adaf_mobilenetv2_set_dtype",
     "adaf_pack_dw_weight_kxk_f32", "adaf_dwconv_same_workspace_bytes", "adaf_dwconv_same_bn_act", "adaf_se_gate_f32", "adaf_conv1x1_gated_bn",
     "adaf_effnet_create", "adaf_effnet_destroy", "adaf_effnet_feature_dim", "adaf_effnet_block_count", "adaf_effnet_block_info",
-    "adaf_effnet_set_dtype", "adaf_effnet_set_fusion", "adaf_effnet_whole_blocks", "adaf_effnet_set_param", "adaf_effnet_finalize", "adaf_effnet_workspace_bytes", "adaf_effnet_forward",
+    "adaf_effnet_set_dtype", "adaf_effnet_set_fusion", "adaf_effnet_whole_blocks", "adaf_effnet_fused_expand_blocks", "adaf_effnet_set_param", "adaf_effnet_finalize", "adaf_effnet_workspace_bytes", "adaf_effnet_forward",
 )
 
 
@@ -134,6 +134,7 @@ def load_library():
     lib.adaf_effnet_set_dtype.argtypes = [vp, ip]
     lib.adaf_effnet_set_fusion.argtypes = [vp, ip]
     lib.adaf_effnet_whole_blocks.argtypes = [vp, ip, ip]
+    lib.adaf_effnet_fused_expand_blocks.argtypes = [vp, ip, ip]
     lib.adaf_effnet_set_param.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.adaf_effnet_finalize.argtypes = [vp, vp]
     lib.adaf_effnet_workspace_bytes.restype = C.c_size_t
@@ -162,7 +163,7 @@ def handle(device):
     return _handles[idx]
 
 
-EF_PLAN_WHOLE_BLOCK, EF_PLAN_TINY_DW, EF_PLAN_STRIP_PROJECT, EF_PLAN_STRIP_EXPAND, EF_PLAN_OWN_STEM = 1, 2, 4, 8, 16
+EF_PLAN_WHOLE_BLOCK, EF_PLAN_TINY_DW, EF_PLAN_STRIP_PROJECT, EF_PLAN_STRIP_EXPAND, EF_PLAN_OWN_STEM, EF_PLAN_FUSED_EXPAND = 1, 2, 4, 8, 16, 32
 
 
 def get_option(key):

@@ -79,7 +79,8 @@ namespace {
 struct OptKey { const char* name; int kind; double lo, hi; };      // kind: index into the switch of opt_ref
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
-                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 31}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2}};
+                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 63}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
+                           {"effnet_fused_blocks", 12, 0, 4294967295.0}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
     for (const OptKey& k : kOptKeys)
@@ -161,6 +162,7 @@ int adaf_set_option(adaf_handle* h, const char* key, double value) {
         case 8: o.latency_linear_rows = (int)value; break;
         case 9: o.effnet_plan = (unsigned)value; break;
         case 11: o.gru_scan_slices = (int)value; break;
+        case 12: o.effnet_fused_blocks = (unsigned)value; break;
         default: o.effnet_chunk = (int)value; break;
     }
     return ADAF_OK;
@@ -182,6 +184,7 @@ double adaf_get_option(const char* key) {
         case 8: return o.latency_linear_rows;
         case 9: return o.effnet_plan;
         case 11: return o.gru_scan_slices;
+        case 12: return o.effnet_fused_blocks;
         default: return o.effnet_chunk;
     }
 }

@@ -96,6 +96,16 @@ __device__ __forceinline__ void act_switch(int act, F&& f) {
     else f(std::integral_constant<int, -1>{});
 }
 
+// a / d for small per-thread index splits (0 <= a < 2^20, d >= 1): trunc((a + 1/2) * (1 / d)) in fp32 -- the real (a + 1/2) / d is at least
+// 1 / (2 d) from an integer and the fp32 result within (a / d) 2^-22 of it, so the truncation is exact.  Three VALU instructions
+// instead of the ~22 of the emulated u32 division.
+struct FastDiv {
+    float inv, half_inv;
+    int d;
+    __device__ __forceinline__ explicit FastDiv(int d_) : inv(__builtin_amdgcn_rcpf((float)d_)), half_inv(0.5f * inv), d(d_) {}
+    __device__ __forceinline__ int div(int a) const { return (int)fmaf((float)a, inv, half_inv); }
+};
+
 // ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
 // A block owns IMB images x one channel slice (CS = LPP 16-byte chunks) x TH output rows.  Its input rows (with the padding
 // columns, zero-filled) are staged once in LDS; then thread (image, channel chunk cg, pixel-group lane pg) walks the
@@ -122,9 +132,22 @@ struct DwArgs {
     int IMB, PG;         // images per block, pixel-group lanes per (image, channel chunk): IMB * PG * LPP <= 256
     int igroups;         // ceil(n / IMB)
     int total;           // work items (= blocks): igroups * tiles * slices
+    // XN > 0 (the expand conv computed into the staged tile, see the kernel): x is the block INPUT [n][H][W][cin] and
+    const void* xw;      // the expand filter [C][cin] (fp16)
+    const float* xscale; // the expand BN [C]
+    const float* xbias;
+    int cin;
 };
 
-template <int K, int S, int OXT, typename T>
+//
+// XN > 0 (fp16 storage): the EXPAND conv of the MBConv block runs inside the staging step -- the 6x-expanded map never exists in HBM (it
+// is 2/3 of what the four-launch plan of blocks 2-8 moves).  a.x is the block's narrow input [n][H][W][cin]; the tile's window pixels
+// go through v_mfma_f32_16x16x32_f16 in groups of 16 with the slice's filter rows as the A operand (XN = CS / 16 row tiles held in
+// registers) and the pixels as B, so a lane ends up with FOUR CONSECUTIVE CHANNELS of one pixel per row tile: BN + swish on the four
+// accumulators at full lanes, one ds_write_b64 into the very layout the loaded path stages -- the taps below do not know the difference.
+// Window pixels in the SAME padding are written as zeros (not swish(bias)).  The halo of a tile is expanded again by its neighbours
+// (stride 2: 3-12 %; the 18 x 18 maps of blocks 6-7 fit whole: none), which is why the round-3 form of this idea lost on stride-1 tiles.
+template <int K, int S, int OXT, typename T, int XN = 0, int KSX = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 : 4, 8))) void dw_same_kernel(const DwArgs a) {
     constexpr int V = Chunk<T>::V;
     constexpr int NC = (OXT - 1) * S + K;    // input columns the OXT outputs of a thread touch
@@ -162,7 +185,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         wl[i] = a.wt[(size_t)tap * a.C + c0 + (i - tap * a.CS)];
     }
     for (int i = tid; i < 2 * a.CS; i += 256) sbl[i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
-    {
+    if constexpr (XN > 0) {
+        static_assert(sizeof(T) == 2, "the fused expand is an fp16-storage path");
+        const int lane = tid & 63, wave = tid >> 6;
+        const int px = lane & 15, kq = lane >> 4;
+        const int cin = a.cin;                                             // cin % 8 == 0, cin <= 32 KSX
+        const _Float16* wx = static_cast<const _Float16*>(a.xw) + (size_t)c0 * cin;
+        // the part of the window that lies inside the image: only those pixels are expanded; the SAME padding around them is zeros
+        const int vr0 = max(0, -iy0), vr1 = min(ihn, a.H - iy0), vc0 = max(0, -ix0), vc1 = min(a.WP, a.W - ix0);
+        const int vw = vc1 - vc0, nv = (vr1 - vr0) * vw;
+        if (nv < ihn * a.WP) {                                             // (block-uniform: tiles on the image border)
+            const int chunks = nimg * (img_lds >> 4);
+            for (int i = tid; i < chunks; i += 256) *reinterpret_cast<u32x4*>(xin + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+        u32x4 af[XN][KSX];
+        f32x4 xs[XN], xb[XN];
+#pragma unroll
+        for (int rt = 0; rt < XN; ++rt) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                const int k0 = 32 * ks + 8 * kq;
+                af[rt][ks] = *reinterpret_cast<const u32x4*>(wx + (size_t)(16 * rt + px) * cin + (k0 < cin ? k0 : 0));
+                if (k0 >= cin) af[rt][ks] = u32x4{0u, 0u, 0u, 0u};
+            }
+            xs[rt] = *reinterpret_cast<const f32x4*>(a.xscale + c0 + 16 * rt + 4 * kq);
+            xb[rt] = *reinterpret_cast<const f32x4*>(a.xbias + c0 + 16 * rt + 4 * kq);
+        }
+        const int ntot = nimg * nv, ngr = (ntot + 15) >> 4;
+        const FastDiv dnv(nv > 0 ? nv : 1), dvw(vw > 0 ? vw : 1);
+        const _Float16* xg = static_cast<const _Float16*>(a.x);
+        constexpr int GB = 8 / KSX;                            // pixel groups in flight per wave (32 registers of B fragments)
+        for (int g0 = wave; g0 < ngr; g0 += 4 * GB) {
+            u32x4 bf[GB][KSX];
+            int dst[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int p = 16 * (g0 + 4 * u) + px;
+                const bool valid = p < ntot;
+                const int pc = valid ? p : 0;
+                const int im = dnv.div(pc), q = pc - im * nv;
+                const int vr = dvw.div(q), vc = q - vr * vw;
+                const int row = vr0 + vr, col = vc0 + vc;
+                dst[u] = valid ? im * img_lds + (row * a.WP + col) * pitchB + 8 * kq : -1;
+                const _Float16* src = xg + (((size_t)(img0 + im) * a.H + (iy0 + row)) * a.W + (ix0 + col)) * cin;
+#pragma unroll
+                for (int ks = 0; ks < KSX; ++ks) {
+                    const int k0 = 32 * ks + 8 * kq;
+                    bf[u][ks] = *reinterpret_cast<const u32x4*>(src + (k0 < cin ? k0 : 0));
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks)
+                if (32 * ks + 8 * kq >= cin) {
+#pragma unroll
+                    for (int u = 0; u < GB; ++u) bf[u][ks] = u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                if (g0 + 4 * u >= ngr) break;                  // (wave-uniform)
+#pragma unroll
+                for (int rt = 0; rt < XN; ++rt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KSX; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[rt][ks]), __builtin_bit_cast(f16x8, bf[u][ks]), acc, 0, 0, 0);
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 o;
+                    o.x = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.x, xs[rt].x, xb[rt].x), ADAF_ACT_SWISH));
+                    o.y = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.y, xs[rt].y, xb[rt].y), ADAF_ACT_SWISH));
+                    o.z = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.z, xs[rt].z, xb[rt].z), ADAF_ACT_SWISH));
+                    o.w = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.w, xs[rt].w, xb[rt].w), ADAF_ACT_SWISH));
+                    if (dst[u] >= 0) *reinterpret_cast<h4*>(xin + dst[u] + 32 * rt) = o;
+                }
+            }
+        }
+    } else {
         // staging: lane (pixel slot, chunk) walks the tile's pixels slot, slot + PP, ...
         const int PP = 256 / a.LPP;
         const int cgl = tid % a.LPP, slot = tid / a.LPP;
@@ -1138,8 +1236,12 @@ constexpr size_t kDwLdsBudget = 48 * 1024;
 // Tile = TH output rows x TWG groups of OXT outputs, of IMB images, for one channel slice.  Chosen by a small cost model:
 // per output, (staged input chunks x the cost of a load + LDS store) + (thread passes x the tap work of a pass), the passes
 // counted with their idle lanes -- a tile whose items do not fill the block's lanes pays for the empty ones.
-bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
+// xp: the staged tile is COMPUTED (fused expand, dw_same_kernel XN > 0): a staged 16-byte chunk costs eight BN + swish evaluations, not a
+// load, so the model leans to tiles with little halo.  (Swept on the fp16 network, LDS budget 32 / 48 / 64 / 80 / 100 KB x chunk cost
+// 24 / 48 / 96 / 200: 7.00-7.07 ms at 32 KB, 6.67-6.76 everywhere else -- same-box, 7.65 with the two-launch plan.)
+bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p, bool xp = false) {
     const size_t budget = kDwLdsBudget;
+    const double stage_cost = xp ? 96.0 : 6.0;
     p->V = 16 / esize;
     if (C % p->V) return false;
     const int chunks = C / p->V;
@@ -1171,7 +1273,7 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
             if (imb < 1) imb = 1;
             const int passes = (groups + pg - 1) / pg;
             const double staged = (double)imb * ((th - 1) * S + K) * ((twg * p->OXT - 1) * S + K) * p->LPP;
-            const double cost = (staged * 6.0 + (double)passes * 256 * K * K * p->OXT + 600.0) / ((double)imb * groups * p->OXT * p->LPP);
+            const double cost = (staged * stage_cost + (double)passes * 256 * K * K * p->OXT + 600.0) / ((double)imb * groups * p->OXT * p->LPP);
             if (cost < best) { best = cost; p->TH = th; p->TWG = twg; p->IMB = imb; p->PG = pg; p->tiles_y = ty; p->tiles_x = tx; }
         }
     }
@@ -1184,24 +1286,26 @@ bool plan_dw(int C, int OH, int OW, int K, int S, int esize, DwPlan* p) {
     return true;
 }
 
-template <int K, int S, int OXT, typename T>
+template <int K, int S, int OXT, typename T, int XN = 0, int KSX = 1>
 void launch_dw_one(const DwArgs& a, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((dw_same_kernel<K, S, OXT, T>), dim3((unsigned)a.total), dim3(256), lds, s, a);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_same_kernel<K, S, OXT, T, XN, KSX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((dw_same_kernel<K, S, OXT, T, XN, KSX>), dim3((unsigned)a.total), dim3(256), lds, s, a);
 }
 
-template <int K, int S, typename T>
+template <int K, int S, typename T, int XN = 0, int KSX = 1>
 void launch_dw_oxt(const DwArgs& a, int oxt, size_t lds, hipStream_t s) {
-    if (oxt == 3) launch_dw_one<K, S, 3, T>(a, lds, s);
-    else if (oxt == 5) launch_dw_one<K, S, 5, T>(a, lds, s);
-    else launch_dw_one<K, S, 4, T>(a, lds, s);
+    if (oxt == 3) launch_dw_one<K, S, 3, T, XN, KSX>(a, lds, s);
+    else if (oxt == 5) launch_dw_one<K, S, 5, T, XN, KSX>(a, lds, s);
+    else launch_dw_one<K, S, 4, T, XN, KSX>(a, lds, s);
 }
 
-template <typename T>
+template <typename T, int XN = 0, int KSX = 1>
 bool launch_dw_t(const DwArgs& a, int K, int S, int oxt, size_t lds, hipStream_t s) {
-    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T>(a, oxt, lds, s);
-    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T>(a, oxt, lds, s);
-    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T>(a, oxt, lds, s);
-    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T>(a, oxt, lds, s);
+    if (K == 3 && S == 1) launch_dw_oxt<3, 1, T, XN, KSX>(a, oxt, lds, s);
+    else if (K == 3 && S == 2) launch_dw_oxt<3, 2, T, XN, KSX>(a, oxt, lds, s);
+    else if (K == 5 && S == 1) launch_dw_oxt<5, 1, T, XN, KSX>(a, oxt, lds, s);
+    else if (K == 5 && S == 2) launch_dw_oxt<5, 2, T, XN, KSX>(a, oxt, lds, s);
     else return false;
     return true;
 }
@@ -1230,6 +1334,37 @@ int adaf_effnet_dw_tiles(int c, int oh, int ow, int k, int stride, int dtype) {
     DwPlan p;
     if (!plan_dw(c, oh, ow, k, stride, dtype == ADAF_DTYPE_F16 ? 2 : 4, &p)) return -1;
     return p.tiles;
+}
+
+// expand 1x1 + BN + swish -> depthwise k x k + BN + act + squeeze sums in ONE launch (fp16 storage; dw_same_kernel XN > 0).  x: the block
+// input [n][hh][ww][cin] (fp16), xw: the expand filter [c][cin] (fp16).  Returns the partial-sum tiles per image (> 0), or < 0 when the
+// shape is not the kernel's (cin % 8, cin <= 64, a channel slice of 48 or 64) -- the caller then runs the two launches.
+int adaf_effnet_dw_tiles_fused(int c, int oh, int ow, int k, int stride) {
+    DwPlan p;
+    if (!plan_dw(c, oh, ow, k, stride, 2, &p, true)) return -1;
+    return (p.CS == 48 || p.CS == 64) ? p.tiles : -1;
+}
+
+int adaf_launch_dw_expand(const void* x, int n, int hh, int ww, int cin, const void* xw, const float* xscale, const float* xbias, int c, int k,
+                          int stride, int pad_t, int pad_l, int oh, int ow, const float* wt, const float* scale, const float* bias, int act,
+                          void* out, float* pool_part, hipStream_t s) {
+    if (cin % 8 || cin > 64 || cin <= 0 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return -1;
+    DwPlan p;
+    if (!plan_dw(c, oh, ow, k, stride, 2, &p, true)) return -1;
+    if (p.CS != 48 && p.CS != 64) return -1;
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.out = out; a.wt = wt; a.scale = scale; a.bias = bias; a.pool_part = pool_part;
+    a.xw = xw; a.xscale = xscale; a.xbias = xbias; a.cin = cin;
+    a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
+    a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
+    a.pitch16 = p.pitch16; a.WP = p.WP;
+    a.IMB = p.IMB; a.PG = p.PG; a.igroups = (n + p.IMB - 1) / p.IMB;
+    a.total = a.igroups * a.tiles * a.slices;
+    const bool k2 = cin > 32;                                // k steps of 32
+    const bool ok = p.CS == 48 ? (k2 ? launch_dw_t<_Float16, 3, 2>(a, k, stride, p.OXT, p.lds, s) : launch_dw_t<_Float16, 3, 1>(a, k, stride, p.OXT, p.lds, s))
+                               : (k2 ? launch_dw_t<_Float16, 4, 2>(a, k, stride, p.OXT, p.lds, s) : launch_dw_t<_Float16, 4, 1>(a, k, stride, p.OXT, p.lds, s));
+    return ok ? p.tiles : -1;
 }
 
 int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, int k, int stride, int pad_t, int pad_l, int oh,
@@ -1536,7 +1671,11 @@ void slab_sizes(const adaf_effnet* net, int size, int pad_size, int dtype, size_
         if (b.expand >= 0 && (size_t)hw * hw * b.hid > *ex) *ex = (size_t)hw * hw * b.hid;
         if ((size_t)ohw * ohw * b.hid > *dw) *dw = (size_t)ohw * ohw * b.hid;
         if ((size_t)ohw * ohw * b.cout > *io) *io = (size_t)ohw * ohw * b.cout;
-        const int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
+        int tiles = adaf_effnet_dw_tiles(b.hid, ohw, ohw, b.k, b.stride, dtype);
+        if (dtype == ADAF_DTYPE_F16) {                       // (the fused expand + depthwise launch has a tile plan of its own)
+            const int tf = adaf_effnet_dw_tiles_fused(b.hid, ohw, ohw, b.k, b.stride);
+            if (tf > tiles) tiles = tf;
+        }
         if ((size_t)(tiles > 0 ? tiles : 1) * b.hid > *pc) *pc = (size_t)(tiles > 0 ? tiles : 1) * b.hid;
         if ((size_t)b.hid > *gc) *gc = b.hid;
         hw = ohw;
@@ -1632,6 +1771,29 @@ int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size) {
         const int pbd = same_pad(ps, b.k, b.stride, &tot);
         const int ohw = conv_out_len(hw, b.k, b.stride, tot);
         if (b.expand >= 0 && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1 && adaf_mbw_eligible(hw, b.k, 1, b.cin, b.hid, b.cout, b.sq)) ++count;
+        hw = ohw;
+        ps = ceil_div(ps, b.stride);
+    }
+    return count;
+}
+
+int adaf_effnet_fused_expand_blocks(const adaf_effnet* net, int size, int pad_size) {
+    if (!net || size < 32) return 0;
+    if (pad_size <= 0) pad_size = size;
+    const unsigned plan = adaf_options().effnet_plan;
+    if (net->dtype != ADAF_DTYPE_F16 || !(plan & ADAF_EF_PLAN_FUSED_EXPAND)) return 0;
+    const bool whole_on = net->fuse && (plan & ADAF_EF_PLAN_WHOLE_BLOCK);
+    int tot, count = 0;
+    (void)same_pad(pad_size, 3, 2, &tot);
+    int hw = conv_out_len(size, 3, 2, tot), ps = ceil_div(pad_size, 2);
+    for (size_t bi = 0; bi < net->blocks.size(); ++bi) {
+        const EfBlock& b = net->blocks[bi];
+        const int pbd = same_pad(ps, b.k, b.stride, &tot);
+        const int ohw = conv_out_len(hw, b.k, b.stride, tot);
+        const bool whole = whole_on && b.expand >= 0 && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1 && adaf_mbw_eligible(hw, b.k, 1, b.cin, b.hid, b.cout, b.sq);
+        if (!whole && b.expand >= 0 && bi < 32 && ((adaf_options().effnet_fused_blocks >> bi) & 1u) && b.cin % 8 == 0 && b.cin <= 64 &&
+            adaf_effnet_dw_tiles_fused(b.hid, ohw, ohw, b.k, b.stride) > 0)
+            ++count;
         hw = ohw;
         ps = ceil_div(ps, b.stride);
     }
@@ -1795,7 +1957,13 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             }
             int tiles = -1;
             if (tiles <= 0) {
-                if (b.expand >= 0) {
+                if (b.expand >= 0 && f16 && (plan & ADAF_EF_PLAN_FUSED_EXPAND) && bi < 32 && ((adaf_options().effnet_fused_blocks >> bi) & 1u)) {
+                    // expand computed inside the depthwise launch's staging step: no expanded map in HBM
+                    const EfConv& E = net->convs[b.expand];
+                    tiles = adaf_launch_dw_expand(cur, nc, hw, hw, b.cin, E.w16, E.scale, E.bias, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w,
+                                                  D.scale, D.bias, ADAF_ACT_SWISH, bufD, part, st);
+                }
+                if (tiles <= 0 && b.expand >= 0) {
                     // (the expand GEMM stays on the conv engine: routed through gated_project_kernel -- 128 x 128 tiles, swish in its
                     // 16-byte epilogue -- the fp16 network measured 12.6 instead of 11.5 ms)
                     const EfConv& E = net->convs[b.expand];
@@ -1806,8 +1974,9 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
                         return efail(h, rc, "effnet: expand launch (block %zu)", bi);
                     dw_in = bufE;
                 }
-                tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
-                                            D.bias, ADAF_ACT_SWISH, bufD, part, st);
+                if (tiles <= 0)
+                    tiles = adaf_launch_dw_same(dw_in, net->dtype, nc, hw, hw, b.hid, b.k, b.stride, pbd, pbd, ohw, ohw, D.w, D.scale,
+                                                D.bias, ADAF_ACT_SWISH, bufD, part, st);
             }
             if (tiles <= 0) return efail(h, ADAF_E_LAUNCH, "effnet: depthwise launch (block %zu)", bi);
             adaf_launch_se_gate(part, tiles, ohw * ohw, nc, b.hid, b.se_wr, b.se_br, b.sq, b.se_wet, 1, b.hid, b.se_be, gate, st);

@@ -751,6 +751,10 @@ class EffNetNet:
         """MBConv blocks of a forward at this input size that run as one launch each (csrc/mbconv_whole.hip)."""
         return int(self._lib.adaf_effnet_whole_blocks(self._net, int(size), int(self.pad_size if pad_size is None else pad_size)))
 
+    def fused_expand_blocks(self, size, pad_size=None):
+        """MBConv blocks of a forward at this input size whose expand conv runs inside the depthwise launch (fp16 storage; effnet.hip XN > 0)."""
+        return int(self._lib.adaf_effnet_fused_expand_blocks(self._net, int(size), int(self.pad_size if pad_size is None else pad_size)))
+
     def load(self, params):
         keep = []
         for name, t in params.items():

@@ -75,7 +75,8 @@ int adaf_set_conv_pos_major(adaf_handle* h, int on);
 /* Process-wide tuning / A-B switches (they replace the ADAF_* environment variables of earlier rounds; the defaults are the plan
  * every reported number is measured with, INTEGRATION.md lists them).  Keys:
  *   "conv_lean" 0|1, "pm_fill" 0..1, "conv_pool" 0|1, "resize_lds_kb", "mb_wave" 0|1, "dw3_variant" 0..4, "mbv2_chunk",
- *   "latency_rows", "latency_linear_rows", "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk", "gru_scan_slices" 1|2.
+ *   "latency_rows", "latency_linear_rows", "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk", "gru_scan_slices" 1|2,
+ *   "effnet_fused_blocks" (bit b = MBConv block b may use the fused expand + depthwise launch).
  * adaf_set_option returns ADAF_E_BADARG for an unknown key or a value out of range; adaf_get_option returns the current value
  * (NaN for an unknown key).  Not thread-safe against concurrent launches: set options between forwards. */
 enum {
@@ -83,7 +84,8 @@ enum {
     ADAF_EF_PLAN_TINY_DW = 2,        /* register-resident depthwise kernel for maps up to 5 x 5 */
     ADAF_EF_PLAN_STRIP_PROJECT = 4,  /* strip kernel for the narrow gated project convs (K <= 64, N <= 32) */
     ADAF_EF_PLAN_STRIP_EXPAND = 8,   /* strip kernel for the narrow-input expand convs (K <= 64) */
-    ADAF_EF_PLAN_OWN_STEM = 16       /* EfficientNet's own 3x3 / stride-2 stem kernel instead of the generic engine */
+    ADAF_EF_PLAN_OWN_STEM = 16,      /* EfficientNet's own 3x3 / stride-2 stem kernel instead of the generic engine */
+    ADAF_EF_PLAN_FUSED_EXPAND = 32   /* fp16 storage: the expand conv computed inside the depthwise launch (no expanded map in HBM) */
 };
 int adaf_set_option(adaf_handle* h, const char* key, double value);
 double adaf_get_option(const char* key);
@@ -374,6 +376,11 @@ int adaf_effnet_set_dtype(adaf_effnet* net, int dtype);
 int adaf_effnet_set_fusion(adaf_effnet* net, int on);
 /* how many MBConv blocks of a forward at this input size take the one-launch form (0 in fp32 storage or with fusion off) */
 int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size);
+/* how many MBConv blocks of a forward at this input size compute their expand conv inside the depthwise launch (fp16 storage,
+ * ADAF_EF_PLAN_FUSED_EXPAND: narrow-input blocks -- cin <= 64 -- that are not whole-image blocks; blocks 2-8 of B3 at 144^2): the
+ * expanded map of those blocks never exists in HBM.  Same arithmetic per stored value as the two launches (the two MFMA shapes
+ * give the same bits); the tile plan, and with it the order of the squeeze partial sums, is its own. */
+int adaf_effnet_fused_expand_blocks(const adaf_effnet* net, int size, int pad_size);
 int adaf_effnet_set_param(adaf_effnet* net, const char* name, const float* dev_ptr, size_t numel);
 int adaf_effnet_finalize(adaf_effnet* net, void* stream);
 size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int pad_size);

@@ -323,6 +323,35 @@ def test_b3_whole_block_kernels_equal_the_four_launch_plan(dev, size, image_size
     assert m32.engine().whole_blocks(size) == 0          # fp32 storage keeps the four-launch plan
 
 
+@pytest.mark.parametrize("size,image_size", [(144, "native"), (100, "native"), (75, "native"), (100, None), (75, None), (128, None)])
+def test_b3_fused_expand_depthwise_equals_the_two_launch_plan(dev, size, image_size):
+    """fp16 storage: the expand conv computed inside the depthwise launch's staging step (dw_same_kernel XN > 0: blocks 2-8, no expanded
+    map in HBM) against expand launch + depthwise launch, at every block boundary behind a fused block, on a smooth and on a noise batch.
+    Same arithmetic per stored value (the 16x16x32 MFMA here and the strip kernel's two 32x32x16 give the same bits: where the two tile
+    plans coincide -- 75^2 with dynamic padding -- the networks agree exactly); the fused launch's tile plan, hence the order of the squeeze
+    partial sums, is its own, which can move a gated value across an fp16 rounding: agreement to a few fp16 ulps.  The sizes put odd
+    maps (25, 13, 7), partial tiles, asymmetric SAME padding and both k-step counts (cin 24 / 32 / 48) under the kernel; n = 5 leaves
+    ragged image groups."""
+    from adafocus_amd import _lib as L
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, "efficientnet-b3", 200, dtype="f16", image_size=image_size)
+    g = torch.Generator().manual_seed(5100 + size)
+    for x in (_smooth((5, 3, size, size), 900 + size), torch.randn((5, 3, size, size), generator=g) * 0.5):
+        x4 = nchw_to_nhwc4(x.to(dev))
+        with torch.no_grad():
+            eng = m.engine()
+            assert int(L.get_option("effnet_plan")) & L.EF_PLAN_FUSED_EXPAND 
+            # blocks 2-8, less those small enough for the whole-image kernel (75^2 with the native padding: blocks 6-7 sit on 9 x 9 maps)
+            assert eng.fused_expand_blocks(size) == (5 if (size, image_size) == (75, "native") else 7)
+            fused = [eng.forward_blocks(x4, k).float().clone() for k in range(3, 10)] + [m.features_nhwc4(x4).clone()]
+            with L.option("effnet_plan", int(L.get_option("effnet_plan")) - L.EF_PLAN_FUSED_EXPAND):
+                assert eng.fused_expand_blocks(size) == 0
+                plain = [eng.forward_blocks(x4, k).float().clone() for k in range(3, 10)] + [m.features_nhwc4(x4).clone()]
+        for k, (f, p) in enumerate(zip(fused, plain)):
+            assert f.shape == p.shape
+            assert (f - p).abs().max().item() <= 4e-3 * max(1.0, float(p.abs().max())), (size, k, (f - p).abs().max().item())
+
+
 def test_b3_whole_block_kernel_single_block_vs_torch(dev, R):
     """One fused block against the oracle's mbconv on the block's own fp16 input (so only this block's arithmetic is compared):
     block 14 (5x5 window, 9 x 9 map, identity skip) and block 24 (3x3 window, 5 x 5 map, 232 -> 384, no skip), 3 images."""
@@ -384,7 +413,7 @@ def test_b3_every_position_in_the_batch_gives_the_same_bits(dev):
                 # expand / stem strip kernels replace the generic engine, whose k order is its own: not part of the claim)
                 from adafocus_amd import _lib as L
                 want = net.forward_blocks(x4, 26).clone()
-                for plan in (31 - L.EF_PLAN_STRIP_PROJECT,):
+                for plan in (int(L.get_option("effnet_plan")) - L.EF_PLAN_STRIP_PROJECT,):
                     with L.option("effnet_plan", plan):
                         got = net.forward_blocks(x4, 26)
                     assert torch.equal(got, want), (dtype, trial, plan, int((got != want).sum()))
