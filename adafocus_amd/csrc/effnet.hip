@@ -215,10 +215,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         const int ntot = nimg * nv, ngr = (ntot + 15) >> 4;
         const FastDiv dnv(nv > 0 ? nv : 1), dvw(vw > 0 ? vw : 1);
         const _Float16* xg = static_cast<const _Float16*>(a.x);
-        constexpr int GB = 8 / KSX;                            // pixel groups in flight per wave (32 registers of B fragments)
-        for (int g0 = wave; g0 < ngr; g0 += 4 * GB) {
-            u32x4 bf[GB][KSX];
-            int dst[GB];
+        // the wave's pixel groups g = wave, wave + 4, ... in batches of GB, two batches deep: the B fragments of batch i + 1 are in flight
+        // (unconditional loads, 16 bytes per lane) while batch i goes through the MFMAs and the swish
+        constexpr int GB = 4 / KSX;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        auto xload = [&](int g0, u32x4 (&bf)[GB][KSX], int (&dst)[GB]) {
 #pragma unroll
             for (int u = 0; u < GB; ++u) {
                 const int p = 16 * (g0 + 4 * u) + px;
@@ -235,6 +236,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                     bf[u][ks] = *reinterpret_cast<const u32x4*>(src + (k0 < cin ? k0 : 0));
                 }
             }
+        };
+        auto xcompute = [&](int g0, u32x4 (&bf)[GB][KSX], const int (&dst)[GB]) {
 #pragma unroll
             for (int ks = 0; ks < KSX; ++ks)
                 if (32 * ks + 8 * kq >= cin) {
@@ -250,7 +253,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
 #pragma unroll
                     for (int ks = 0; ks < KSX; ++ks)
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[rt][ks]), __builtin_bit_cast(f16x8, bf[u][ks]), acc, 0, 0, 0);
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 o;
                     o.x = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.x, xs[rt].x, xb[rt].x), ADAF_ACT_SWISH));
                     o.y = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.y, xs[rt].y, xb[rt].y), ADAF_ACT_SWISH));
@@ -258,6 +260,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                     o.w = adaf_f16_of(act_of<ADAF_ACT_SWISH>(fmaf(acc.w, xs[rt].w, xb[rt].w), ADAF_ACT_SWISH));
                     if (dst[u] >= 0) *reinterpret_cast<h4*>(xin + dst[u] + 32 * rt) = o;
                 }
+            }
+        };
+        u32x4 bfA[GB][KSX], bfB[GB][KSX];
+        int dstA[GB], dstB[GB];
+        constexpr int GSTEP = 4 * GB;
+        if (wave < ngr) xload(wave, bfA, dstA);
+        for (int g0 = wave; g0 < ngr; g0 += 2 * GSTEP) {
+            if (g0 + GSTEP < ngr) xload(g0 + GSTEP, bfB, dstB);
+            xcompute(g0, bfA, dstA);
+            if (g0 + GSTEP < ngr) {
+                if (g0 + 2 * GSTEP < ngr) xload(g0 + 2 * GSTEP, bfA, dstA);
+                xcompute(g0 + GSTEP, bfB, dstB);
             }
         }
     } else {

@@ -180,6 +180,23 @@ def effnet_whole_block(b, elem=2):
     return False
 
 
+def effnet_fused_expand_block(b, elem=2):
+    """Does block `b` compute its expand conv inside the depthwise launch (dw_same_kernel XN > 0, csrc/effnet.hip)?  Mirror of
+    adaf_launch_dw_expand: fp16 storage, an expand conv, cin a multiple of 8 and at most 64, a channel slice of 48 or 64, and not a
+    whole-image block."""
+    if elem != 2 or b["expand"] == 1 or effnet_whole_block(b, elem) or b["cin"] % 8 or b["cin"] > 64:
+        return False
+    return effnet_fused_expand_slices(b) > 0
+
+
+def effnet_fused_expand_slices(b):
+    """Channel slices of the fused launch (each slice's workgroups read the block input again; L2 absorbs most of it): hid / (8 LPP) with
+    LPP the largest divisor <= 8 of hid / 8 (plan_dw); 0 when the slice is not 48 or 64 channels."""
+    chunks = b["hid"] // 8
+    lpp = next(d for d in range(8, 0, -1) if chunks % d == 0)
+    return b["hid"] // (8 * lpp) if 8 * lpp in (48, 64) else 0
+
+
 def effnet_block_bytes_per_frame(name="efficientnet-b3", size=144, elem=2):
     """BLOCK-LEVEL algorithmic bytes per frame: the patch (3 channels, fp32) read once, every tensor that crosses a block boundary
     (stem -> block 0 -> ... -> block 25 -> head) written once and read once in the storage type, the identity skip re-read where a
@@ -199,8 +216,9 @@ def effnet_block_bytes_per_frame(name="efficientnet-b3", size=144, elem=2):
 def effnet_bytes_per_frame(name="efficientnet-b3", size=144, elem=2, fused=True):
     """HBM bytes per frame of the launch plan of csrc/effnet.hip + csrc/mbconv_whole.hip that RUNS (activation inputs + outputs of every
     launch; the 12 M parameters are shared by >= 1024 frames per launch and ignored): patch in (fp32 x 4 lanes), stem out; per block
-    either ONE launch (block in, out, + identity: the whole-image kernel, fused=True and effnet_whole_block) or expand (in, out),
-    depthwise (in, out), project (in, out, + identity); head (in, fp32 out), pooled vector.  elem = bytes per stored activation
+    either ONE launch (block in, out, + identity: the whole-image kernel, fused=True and effnet_whole_block), or expand + depthwise in one
+    launch (block in once per channel slice, depthwise out: effnet_fused_expand_block) + project, or expand (in, out), depthwise (in, out),
+    project (in, out, + identity); head (in, fp32 out), pooled vector.  elem = bytes per stored activation
     (2 = fp16 storage, 4 = fp32)."""
     c0, blocks, ch = effnet_blocks(name, size)
     hw = -(-size // 2)
@@ -212,9 +230,12 @@ def effnet_bytes_per_frame(name="efficientnet-b3", size=144, elem=2, fused=True)
             if b["cin"] == b["cout"]:
                 b_ += hout * b["cout"] * elem
             continue
-        if b["expand"] != 1:
-            b_ += (hin * b["cin"] + hin * b["hid"]) * elem
-        b_ += (hin * b["hid"] + hout * b["hid"]) * elem                       # depthwise
+        if fused and effnet_fused_expand_block(b, elem):
+            b_ += (hin * b["cin"] * effnet_fused_expand_slices(b) + hout * b["hid"]) * elem      # expand + depthwise in one launch: narrow input (once per channel slice), depthwise output
+        else:
+            if b["expand"] != 1:
+                b_ += (hin * b["cin"] + hin * b["hid"]) * elem
+            b_ += (hin * b["hid"] + hout * b["hid"]) * elem                   # depthwise
         b_ += (hout * b["hid"] + hout * b["cout"]) * elem                      # project
         if b["stride"] == 1 and b["cin"] == b["cout"]:
             b_ += hout * b["cout"] * elem

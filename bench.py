@@ -104,6 +104,7 @@ def config5_row(dev, b, streams, frames, steps=30):
                           "plan_frac": round(plan / cnn_ms / 1e6 / HBM_PEAK_GBS, 4),
                           "traffic_bytes_per_patch": load_effnet_traffic(dtype, b * t, p),
                           "whole_block_launches": int(net.engine().whole_blocks(p)),
+                          "fused_expand_launches": int(net.engine().fused_expand_blocks(p)),
                           "tflops": round(2.0 * workload.effnet_macs_per_frame("efficientnet-b3", p) * b * t / cnn_ms / 1e9, 1)}}
         if ref is None:
             ref = lg
@@ -118,7 +119,7 @@ def config5_row(dev, b, streams, frames, steps=30):
                    "local_cnn = the network alone (HIP events): achieved / frac are priced on the BLOCK-LEVEL algorithmic bytes (every tensor that crosses a block "
                    "boundary written once and read once + identity rows + patch in + feature out: workload.effnet_block_bytes_per_frame), plan_* on the activation "
                    "in + out of every launch of the plan that runs (workload.effnet_bytes_per_frame; whole_block_launches of the 26 MBConv blocks are one launch "
-                   "each, csrc/mbconv_whole.hip), traffic_bytes_per_patch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes (null if none); "
+                   "each, csrc/mbconv_whole.hip; fused_expand_launches more compute their expand conv inside the depthwise launch, csrc/effnet.hip XN > 0), traffic_bytes_per_patch = 2 x FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 passes (null if none); "
                    "parity unpinned (no reference implementation of this config)" % (b * t, b))
     return out
 
