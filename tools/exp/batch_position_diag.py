@@ -1,3 +1,5 @@
+"""Does a frame's EfficientNet output depend on its position in the batch?  Images 1 and 3 of a batch of five against the same frames alone, after
+blocks 3 ... 12, for several `effnet_plan` settings (the round-4 hunt for the single-rounding fp16 conversions).  usage: python tools/exp/batch_position_diag.py"""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from adafocus_amd import synth, _lib as L
@@ -14,7 +16,7 @@ x4 = nchw_to_nhwc4(x)
 with torch.no_grad():
     m.features_nhwc4(x4)
     net = m._net
-    for plan in (31, 31 - 8, 31 - 4, 31 - 16, 31 - 1, 0):
+    for plan in (63, 31, 31 - 8, 31 - 4, 31 - 16, 31 - 1, 0):
         with L.option("effnet_plan", plan):
             res = []
             for bi in (3, 4, 5, 6, 9, 12):
