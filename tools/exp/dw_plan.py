@@ -1,6 +1,6 @@
 """Python restatement of plan_dw (csrc/effnet.hip) to look at the tile plans; usage: python tools/exp/dw_plan.py"""
 def plan(C, OH, OW, K, S, esize=2, xp=False, budget=None, stage_cost=None):
-    budget = budget or (64 * 1024 if xp else 48 * 1024)
+    budget = budget or 48 * 1024
     stage_cost = stage_cost or (96.0 if xp else 6.0)
     V = 16 // esize
     chunks = C // V
