@@ -37,8 +37,9 @@ for dt in dtypes:
         host = (time.perf_counter() - t0) * 1e3 / iters
     ms = e0.elapsed_time(e1) / iters
     res[dt] = ms
-    by = workload.effnet_bytes_per_frame("efficientnet-b3", p, 2 if dt == "f16" else 4) if hasattr(workload, "effnet_bytes_per_frame") else 0
-    print("effnet-b3 %s: %d x %d^2: %.3f ms (host %.3f ms)  %.0f patches/s  algorithmic %.2f MB/frame -> %.2f TB/s"
-          % (dt, n, p, ms, host, n / ms * 1e3, by / 1e6, by * n / ms / 1e9))
+    el = 2 if dt == "f16" else 4
+    by, blk = workload.effnet_bytes_per_frame("efficientnet-b3", p, el), workload.effnet_block_bytes_per_frame("efficientnet-b3", p, el)
+    print("effnet-b3 %s: %d x %d^2: %.3f ms (host %.3f ms)  %.0f patches/s  plan bytes %.2f MB/frame -> %.2f TB/s, block-level %.2f MB/frame -> %.2f TB/s"
+          % (dt, n, p, ms, host, n / ms * 1e3, by / 1e6, by * n / ms / 1e9, blk / 1e6, blk * n / ms / 1e9))
 if "f32" in res and "f16" in res:
     print("fp16 / fp32 storage speed-up: %.2fx" % (res["f32"] / res["f16"]))
