@@ -37,6 +37,22 @@ def test_b3_topology():
     assert bl[0]["expand"] == 1 and bl[1]["sq"] == 6 and bl[-1]["hid"] == 2304 and bl[-1]["sq"] == 96
 
 
+def test_byte_models_of_the_launch_plan_for_b3_at_144():
+    """bench.py's three byte counts for config 5 (workload.effnet_*): the block-level figure, the plan that runs (whole-image blocks 9-17 and
+    19-24, the expand conv inside the depthwise launch for blocks 2-8) and the four-launch plan; the Python mirrors of the two eligibility
+    rules pick the blocks the library picks (the GPU tests assert the library's own counts: 15 and 7)."""
+    from adafocus_amd import workload as W
+    _, blocks, _ = W.effnet_blocks("efficientnet-b3", 144)
+    whole = [i for i, b in enumerate(blocks) if W.effnet_whole_block(b)]
+    fused = [i for i, b in enumerate(blocks) if W.effnet_fused_expand_block(b)]
+    assert whole == list(range(9, 18)) + list(range(19, 25)) and fused == list(range(2, 9))
+    assert [W.effnet_fused_expand_slices(blocks[i]) for i in fused] == [3, 3, 3, 3, 6, 6, 6]          # 144 / 48, 192 / 64, 288 / 48
+    assert not any(W.effnet_fused_expand_block(b, 4) or W.effnet_whole_block(b, 4) for b in blocks)  # fp32 storage: four launches
+    blk, plan, plain = W.effnet_block_bytes_per_frame(), W.effnet_bytes_per_frame(), W.effnet_bytes_per_frame(fused=False)
+    assert abs(blk / 1e6 - 4.06) < 0.01 and abs(plan / 1e6 - 11.87) < 0.01 and abs(plain / 1e6 - 23.15) < 0.01
+    assert blk < plan < plain
+
+
 def test_same_padding_known_answers():
     # Conv2dStaticSamePadding: total = max((ceil(i/s) - 1) s + k - i, 0), before = total // 2
     assert R.same_pad(144, 3, 2) == (0, 1) and R.same_pad(300, 3, 2) == (0, 1)
