@@ -25,7 +25,7 @@ SYMBOLS = (
     "adaf_crop_gather_f32", "adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32", "adaf_pack_conv_weight_f32",
     "adaf_fold_bn_f32", "adaf_maxpool3x3s2_f32", "adaf_global_avgpool_f32", "adaf_temporal_shift_f32",
     "adaf_resnet50_create", "adaf_resnet50_destroy", "adaf_resnet50_set_param", "adaf_resnet50_finalize",
-    "adaf_resnet50_workspace_bytes", "adaf_resnet50_forward", "adaf_resnet50_launch_count",
+    "adaf_resnet50_workspace_bytes", "adaf_resnet50_forward", "adaf_resnet50_map_size", "adaf_resnet50_forward_map", "adaf_resnet50_launch_count",
     "adaf_resnet50_forward_profiled", "adaf_resnet50_set_tiles", "adaf_resnet50_set_math", "adaf_resnet50_set_fusion", "adaf_resnet50_set_latency_rows", "adaf_gru_cls_workspace_bytes",
     "adaf_gru_cls_forward_f32", "adaf_fc_meanpool_forward_f32", "adaf_copy2d_f32",
     "adaf_pack_dw_weight_f32", "adaf_dwconv3x3_bn_act_f32", "adaf_mobilenetv2_create", "adaf_mobilenetv2_destroy",
@@ -87,6 +87,8 @@ def load_library():
     lib.adaf_resnet50_workspace_bytes.restype = C.c_size_t
     lib.adaf_resnet50_workspace_bytes.argtypes = [vp, ip, ip]
     lib.adaf_resnet50_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, vp, C.c_size_t, vp]
+    lib.adaf_resnet50_map_size.argtypes = [ip]
+    lib.adaf_resnet50_forward_map.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, C.c_size_t, vp]
     lib.adaf_resnet50_launch_count.argtypes = [vp]
     lib.adaf_resnet50_forward_profiled.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, vp, C.c_size_t, vp, vp, vp, vp, vp]
     lib.adaf_resnet50_set_tiles.argtypes = [vp, vp, ip]

@@ -522,7 +522,7 @@ struct Launch {   // one enqueued kernel of the forward pass, for the profiler
 
 // Walks the trunk; `rec` (optional) gets one hipEvent before each launch plus one at the end.
 int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int tsm_div, float* feat, int ldfeat,
-              void* ws, size_t ws_bytes, hipStream_t st, std::vector<hipEvent_t>* rec, std::vector<Launch>* info) {
+              void* ws, size_t ws_bytes, hipStream_t st, std::vector<hipEvent_t>* rec, std::vector<Launch>* info, float* featmap = nullptr) {
     adaf_handle* h = net->h;
     if (!net->finalized) return fail(h, ADAF_E_STATE, "resnet50: finalize() has not been called");
     if (!x4 || !feat || !ws) return fail(h, ADAF_E_BADARG, "resnet50: null pointer");
@@ -674,7 +674,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             } else {
                 if ((rc = conv(t1, h1, w1, ADAF_ACT_RELU, nullptr, t2, 0, &h2, &w2, 0))) return rc;
                 const bool last = s == 3 && b == kStageBlocks[3] - 1;
-                if (last && fuse && !rec && net->math == ADAF_MATH_F32 && !net->tiles[li] && !(lat_ok && n * h2 * w2 <= lat_rows)) {
+                if (last && fuse && !rec && !featmap && net->math == ADAF_MATH_F32 && !net->tiles[li] && !(lat_ok && n * h2 * w2 <= lat_rows)) {
                     // the trunk's last conv3: the global average pool rides in its epilogue (conv_epilogue_pool) -- no 2048-channel map,
                     // no pooling launch -- when whole images fill its row tiles (3x3 / 4x4 / 5x5 maps); bit-identical to conv + pool
                     const ConvLayer& L3 = net->convs[li];
@@ -698,6 +698,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             float* t = cur; cur = nxt; nxt = t;
         }
     }
+    if (featmap)        // get_featmap(pooled=False): the last block's map leaves the workspace (NHWC)
+        (void)hipMemcpyAsync(featmap, cur, (size_t)n * hh * ww * 2048 * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (!pooled) {
         mark(0.0, 4.0 * ((double)n * hh * ww * 2048 + (double)n * 2048), 0);
         adaf_launch_avgpool(cur, n, hh * ww, 2048, feat, ldfeat, st);
@@ -830,6 +832,22 @@ int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n,
     if (!net) return ADAF_E_BADARG;
     return run_trunk(net, patches_nhwc4, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream,
                      nullptr, nullptr);
+}
+
+int adaf_resnet50_map_size(int patch) {
+    if (patch < 32) return 0;
+    int s = (patch + 6 - 7) / 2 + 1;          // conv1 7x7 / 2 / pad 3
+    s = (s + 2 - 3) / 2 + 1;                  // max-pool 3x3 / 2 / pad 1
+    for (int i = 0; i < 3; ++i) s = (s + 2 - 3) / 2 + 1;      // layer2-4: 3x3 / 2 / pad 1
+    return s;
+}
+
+int adaf_resnet50_forward_map(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments, int tsm_div,
+                              float* featmap_nhwc, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream) {
+    if (!net) return ADAF_E_BADARG;
+    if (!featmap_nhwc || !aligned16(featmap_nhwc)) return fail(net->h, ADAF_E_BADARG, "resnet50: forward_map needs a 16-byte aligned map buffer");
+    return run_trunk(net, patches_nhwc4, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr,
+                     featmap_nhwc);
 }
 
 int adaf_resnet50_launch_count(const adaf_resnet50* net) { return net ? (int)net->convs.size() + 2 : 0; }

@@ -279,6 +279,19 @@ class ResNet50Trunk:
                                                 out.stride(0), L.ptr(ws), need, L.stream_ptr()), self._h)
         return out
 
+    def forward_map(self, patches_nhwc4, tsm_segments=0, tsm_div=8):
+        """patches (N,P,P,4) -> (featmap (N,s,s,2048) NHWC, pooled feature (N,2048)): ResNet.get_featmap(x, pooled=False)."""
+        L.need_gpu_f32(patches_nhwc4)
+        x = patches_nhwc4.contiguous()
+        n, p = x.shape[0], x.shape[1]
+        s = int(self._lib.adaf_resnet50_map_size(p))
+        fmap = torch.empty((n, s, s, 2048), device=x.device, dtype=torch.float32)
+        feat = torch.empty((n, 2048), device=x.device, dtype=torch.float32)
+        ws, need = self._workspace(n, p)
+        L.check(self._lib.adaf_resnet50_forward_map(self._net, L.ptr(x), n, p, int(tsm_segments), int(tsm_div), L.ptr(fmap), L.ptr(feat), 2048,
+                                                    L.ptr(ws), need, L.stream_ptr()), self._h)
+        return fmap, feat
+
     def profile(self, patches_nhwc4, tsm_segments=0, tsm_div=8):
         """One forward bracketed by HIP events per launch.  Returns a list of dicts
         {ms, flops, bytes, tile} (flops = 0 for the pooling launches)."""

@@ -106,8 +106,13 @@ class ResNet(nn.Module):
         return self._sync().forward(patches_nhwc4, self.tsm_segments, self.tsm_div, out=out)
 
     def get_featmap(self, x, pooled=True):
+        """ACT/models/resnet.py:211-225: the trunk up to layer4, then the global average pool (pooled=True: (N,2048,1,1), the call the
+        Focuser makes) or the map itself (pooled=False: (N,2048,s,s), NCHW like the reference's return value)."""
+        if self.training:
+            raise RuntimeError("adafocus_amd.ResNet implements the eval-mode (offline inference) path only")
         if not pooled:
-            raise NotImplementedError("get_featmap(pooled=False) is not on the offline-inference path")
+            fmap, _ = self._sync().forward_map(nchw_to_nhwc4(x), self.tsm_segments, self.tsm_div)
+            return fmap.permute(0, 3, 1, 2)
         feat = self.features_nhwc4(nchw_to_nhwc4(x))
         return feat.view(feat.shape[0], 2048, 1, 1)
 

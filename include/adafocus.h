@@ -246,6 +246,12 @@ size_t adaf_resnet50_workspace_bytes(const adaf_resnet50* net, int n, int patch)
  * tsm_segments = 0 for the ActivityNet model. */
 int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
                           int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream);
+/* ResNet.get_featmap(x, pooled=False) (ACT/models/resnet.py:211-225, the branch `return x` before avgpool): the same pass, with the last
+ * block's map written to featmap_nhwc [n][s][s][2048] (s = adaf_resnet50_map_size(patch): 3 at 96^2, 4 at 128^2) and the pooled feature to
+ * `feat` as in adaf_resnet50_forward (the pool runs as its own launch here: same values). */
+int adaf_resnet50_map_size(int patch);
+int adaf_resnet50_forward_map(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments, int tsm_div,
+                              float* featmap_nhwc, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream);
 /* Same as forward, but brackets every launch with HIP events on `stream` and reports per-launch
  * milliseconds, algorithmic FLOPs (2*MAC, 0 for non-conv launches) and algorithmic bytes.
  * Arrays must hold adaf_resnet50_launch_count() entries.  Synchronises the stream. */

@@ -326,6 +326,12 @@ def test_resnet50_trunk_golden(dev, O):
     assert feat.shape == (2, 2048, 1, 1)
     err = np.abs(feat.cpu().numpy().reshape(2, -1) - g["trunk"]).max()
     assert err < 2e-4, err
+    # ... and the reference's get_featmap(pooled=False) on the same input (the golden's `trunk_map`, (2,2048,2,2))
+    with torch.no_grad():
+        fmap = net.get_featmap(xt.to(dev), pooled=False)
+    assert tuple(fmap.shape) == g["trunk_map"].shape
+    errm = np.abs(fmap.cpu().numpy() - g["trunk_map"]).max()
+    assert errm < 3e-4 * max(1.0, float(np.abs(g["trunk_map"]).max())), errm
 
 
 @pytest.mark.parametrize("p,tsm", [(96, 0), (128, 0), (144, 0), (128, 8), (100, 0), (72, 4)])
@@ -340,6 +346,24 @@ def test_resnet50_trunk_vs_oracle(dev, O, p, tsm):
     err = (got - ref).abs().max().item()
     assert err < 3e-4, err
     assert ref.abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("p,tsm", [(96, 0), (128, 8), (100, 0), (64, 0)])
+def test_resnet50_featmap_unpooled_vs_oracle(dev, O, p, tsm):
+    """ResNet.get_featmap(x, pooled=False) (ACT/models/resnet.py:211-225: the map before the average pool), NCHW like the reference's
+    return value: against the oracle's trunk, and consistent with the pooled call (whose pool rides in the last conv's epilogue)."""
+    net, sd = _trunk(dev, 1107 + p)
+    net.tsm_segments = tsm
+    n = 8 if p != 100 else 5
+    x = rnd((n, 3, p, p), 350 + p)
+    with torch.no_grad():
+        fmap = net.get_featmap(x.to(dev), pooled=False)
+        pooled = net.get_featmap(x.to(dev), pooled=True)
+        ref = O.resnet50_trunk(sd, "", x, tsm_segments=tsm, pooled=False)
+    assert fmap.shape == ref.shape and fmap.shape[1] == 2048
+    err = (fmap.cpu() - ref).abs().max().item()
+    assert err < 3e-4 * max(1.0, ref.abs().max().item()), err
+    assert (fmap.mean(dim=(2, 3)) - pooled.view(n, -1)).abs().max().item() < 1e-5
 
 
 @pytest.mark.parametrize("p,tsm", [(96, 0), (128, 8), (100, 0)])
