@@ -419,6 +419,23 @@ def test_b3_every_position_in_the_batch_gives_the_same_bits(dev):
                     assert torch.equal(got, want), (dtype, trial, plan, int((got != want).sum()))
 
 
+def test_b3_full_size_batch_with_a_ragged_chunk_equals_small_batches(dev):
+    """BASELINE config 5's 1024 patches of 144^2 plus a ragged tail (1030 frames: one full 1024-frame chunk and a 6-frame one, odd image groups
+    in every kernel that owns two images): frames from the head, the chunk boundary and the tail give the bits they give in a batch of three."""
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, "efficientnet-b3", 200, dtype="f16")
+    g = torch.Generator().manual_seed(4300)
+    base = nchw_to_nhwc4((torch.randn((6, 3, 144, 144), generator=g) * 0.5).to(dev))
+    x4 = base[torch.arange(1030, device=dev) % 6].contiguous()
+    with torch.no_grad():
+        full = m.features_nhwc4(x4)
+        small = m.features_nhwc4(base[[1, 5, 3]].contiguous())           # frames 1, 5, 3
+    assert torch.isfinite(full).all()
+    for row in (1, 5, 3, 1023, 1025, 1027, 1029):           # head, last frame of the full chunk, the ragged chunk; row % 6 in {1, 5, 3}
+        want = {1: 0, 5: 1, 3: 2}[row % 6]
+        assert torch.equal(full[row], small[want]), (row, float((full[row] - small[want]).abs().max()))
+
+
 # ------------------------------------------------------------------------------------ BASELINE config 5 as named
 def _act_args(**over):
     class A:
