@@ -124,7 +124,7 @@ def config5_row(dev, b, streams, frames, steps=30):
     return out
 
 
-def init_failure_line(a, world, rank, backend, exc):
+def init_failure_line(a, world, rank, backend, exc, launched=True):
     """The first unattended multi-GPU run must leave something diagnosable: rank 0 (or, failing that, whichever rank gets here) prints ONE
     JSON line with the bench contract's keys, `error`, `rccl_ranks: 0`, the exception text and the HSA_* / NCCL_* / RCCL_* / rendezvous
     environment; the other ranks say the same on stderr.  The process then exits non-zero (the counterpart of the reference's
@@ -136,7 +136,12 @@ def init_failure_line(a, world, rank, backend, exc):
             "error": "distributed init failed on rank %d of %d (backend %s)" % (rank, world, backend), "rccl_ranks": 0,
             "exception": ("%s: %s" % (type(exc).__name__, exc))[:2000],
             "visible_gpus": (torch.cuda.device_count() if torch.cuda.is_available() else 0), "env": env}
+    line["env"]["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES")
+    line["env"]["ROCR_VISIBLE_DEVICES"] = os.environ.get("ROCR_VISIBLE_DEVICES")
     text = json.dumps(line)
+    if not launched:          # the parent, before any rank exists
+        print(text, flush=True)
+        return
     if rank == 0:
         print(text, flush=True)
         time.sleep(1.0)       # the launcher tears the group down at the first non-zero exit: let the other ranks' stderr lines out first
@@ -474,6 +479,15 @@ def main():
         return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not a.dry_run and not a.share_gpu:
+            # the likeliest failure of a first unattended multi-GPU run: the box exposes fewer devices than --gpus.  Say so in ONE
+            # line (the init-failure form) from the parent, before N ranks each die with a traceback in torch.cuda.set_device
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < a.gpus:
+                init_failure_line(a, a.gpus, 0, "nccl", RuntimeError(
+                    "--gpus %d but this process sees %d HIP device(s) (HIP_VISIBLE_DEVICES=%r, ROCR_VISIBLE_DEVICES=%r)"
+                    % (a.gpus, have, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"))), launched=False)
+                raise SystemExit(3)
         self_launch(a.gpus)                       # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -482,18 +496,28 @@ def main():
     if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     dry = a.dry_run
+    backend = "gloo" if (dry or a.share_gpu) else "nccl"
     if dry:
         dev = torch.device("cpu")
     else:
         if a.share_gpu:
             local = 0
-        torch.cuda.set_device(local)              # rank i <-> GPU i of this node
+        try:                                       # inside the guard too: a rank whose device does not exist must not die with a bare traceback
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            need = 1 if a.share_gpu else max(local + 1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            if have < need:       # EVERY rank of the node sees the same shortfall, so rank 0 is among those that report it
+                raise RuntimeError("rank %d wants HIP device %d (of %d local ranks) but this process sees %d device(s) (HIP_VISIBLE_DEVICES=%r, "
+                                   "ROCR_VISIBLE_DEVICES=%r)" % (rank, local, need, have, os.environ.get("HIP_VISIBLE_DEVICES"),
+                                                                 os.environ.get("ROCR_VISIBLE_DEVICES")))
+            torch.cuda.set_device(local)          # rank i <-> GPU i of this node
+        except Exception as exc:      # noqa: BLE001
+            init_failure_line(a, world, rank, backend, exc)
+            raise SystemExit(3)
         dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if (dry or a.share_gpu) else "nccl"
         try:
             # rendezvous + the FIRST collective inside one guard: an RCCL problem (IPC mode, topology, a missing device) usually shows
             # up at communicator creation, i.e. at the first collective, not at init_process_group
@@ -796,6 +820,7 @@ def main():
             eargs = act_args(t, p, b)
             extra("next_rows", "evaluate_loop", lambda: X.evaluate_loop_row(dev, model, eargs, b, t))
             extra("also", "validate_sth_loop_T8_P128", lambda: X.validate_sth_row(dev, b))
+            extra("also", "sth_shipped_T8_12_P144", lambda: X.sth_shipped_row(dev, b, streams))
         if world == 1 and not a.skip_extras and (t, p) == (16, 96):
             try:
                 res.setdefault("also", {})["config5_T16_P144_efficientnet_b3"] = config5_row(dev, b, streams, frames)

@@ -24,10 +24,10 @@ def act_args(t, p, b, **over):
     return a
 
 
-def sth_args(b, t=8, p=128, video_div=1):
+def sth_args(b, t=8, p=128, video_div=1, tf=None):
     """Something-Something V1 configuration (STH/evaluate.py argparse defaults + the README's command line): TSM-MobileNetV2
-    glancer, TSM-ResNet-50 focuser, continuous policy."""
-    return Args(num_segments_glancer=t, num_segments_focuser=t, num_classes=174, batch_size=b, patch_size=p, input_size=224,
+    glancer over `t` frames, TSM-ResNet-50 focuser over `tf` (default: t) frames, continuous policy."""
+    return Args(num_segments_glancer=t, num_segments_focuser=tf or t, num_classes=174, batch_size=b, patch_size=p, input_size=224,
                 with_glancer=True, feature_map_channels=1280, video_div=video_div, glance_size=224, action_dim=49,
                 hidden_state_dim=1024, policy_conv=True, gpu=0, ppo_continuous=True, gamma=0.7, policy_lr=0.0003,
                 action_std=0.25, actorcritic_with_bn=True, modality="RGB", base_model="resnet50", partial_bn=False,
@@ -74,20 +74,22 @@ def act_hot_path_row(dev, t, p, b, streams, steps):
             "frac_of_f32_mfma_peak": round(flop / sec / 1e12 / 157.3, 4)}
 
 
-def sth_hot_path_row(dev, b, streams, steps, t=8, p=128):
+def sth_hot_path_row(dev, b, streams, steps, t=8, p=128, tg=None):
     """BASELINE config 4: Something-Something V1, TSM-ResNet-50 local CNN (temporal shift fused into every Bottleneck conv1's
     operand load), T = 8, P = 128: gather (one (y, x) per clip) -> TSM trunk -> FC + temporal mean + glancer logits
-    (GFV.action_stage3 in eval mode with the action given: the hot path without its producers)."""
+    (GFV.action_stage3 in eval mode with the action given: the hot path without its producers).  `t` = focuser frames per clip,
+    `tg` = glancer frames (default t)."""
     from adafocus_amd import synth, workload
     from adafocus_amd.gfv_net_sth import GFV
-    a = sth_args(b, t, p)
+    tg = tg or t
+    a = sth_args(b, tg, p, tf=t)
     m = GFV(a).eval()
     m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])     # STH/evaluate.py:83
     m.load_state_dict(synth_model_state(m, 1007), strict=True)
     m = m.to(dev)
     fo = torch.from_numpy(synth.synth_frames(b, t, 224, seed=4)).view(b, t, 3, 224, 224).to(dev)
-    fm = torch.randn((b, t, 7, 7, 1280), device=dev).permute(0, 1, 4, 2, 3)     # glancer map, reference-layout view
-    glog = torch.randn((b, t, 174), device=dev)
+    fm = torch.randn((b, tg, 7, 7, 1280), device=dev).permute(0, 1, 4, 2, 3)     # glancer map, reference-layout view
+    glog = torch.randn((b, tg, 174), device=dev)
     forced = torch.rand((b, 2), device=dev)
     with torch.no_grad():
         sec = _clock(lambda: m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced), streams, steps)
@@ -164,14 +166,15 @@ def evaluate_loop_row(dev, model, args, b, t, batches=24):
                     "%d batches per call (a call carries ~50 ms of un-overlapped first-batch staging, drain and cal_map)" % batches}
 
 
-def validate_sth_row(dev, b, t=8, p=128, batches=8):
+def validate_sth_row(dev, b, t=8, p=128, batches=8, tf=None, fp32_clips=True):
     """Something-Something loop end to end (evaluate.validate_sth = STH/evaluate.py:165-226): two frame streams from host memory,
     glancer + continuous policy + gather + TSM-ResNet-50 (+ the reward-baseline branch, as the reference runs it) + FC / consensus,
     accuracy over the set.  From the loader's stacked uint8 clips (normalised on the GPU: 4x fewer bytes over PCIe; row f1) and from
     the reference's fp32 clips."""
     from adafocus_amd import evaluate as E
     from adafocus_amd.gfv_net_sth import GFV
-    a = sth_args(b, t, p)
+    tf = tf or t
+    a = sth_args(b, t, p, tf=tf)
     m = GFV(a).eval()
     m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])
     m.load_state_dict(synth_model_state(m, 1007), strict=True)
@@ -180,9 +183,9 @@ def validate_sth_row(dev, b, t=8, p=128, batches=8):
     g = torch.Generator().manual_seed(3)
     labels = torch.randint(0, 174, (n,), generator=g)
     gl8 = torch.randint(0, 256, (16, 224, 224, t * 3), dtype=torch.uint8, generator=g)
-    fo8 = torch.randint(0, 256, (16, 224, 224, t * 3), dtype=torch.uint8, generator=g)
-    gl = torch.randn((16, t * 3, 224, 224), generator=g)
-    fo = torch.randn((16, t * 3, 224, 224), generator=g)
+    fo8 = torch.randint(0, 256, (16, 224, 224, tf * 3), dtype=torch.uint8, generator=g)
+    gl = torch.randn((16, t * 3, 224, 224), generator=g) if fp32_clips else None
+    fo = torch.randn((16, tf * 3, 224, 224), generator=g) if fp32_clips else None
 
     class DS:
         def __init__(self, x, y):
@@ -195,7 +198,7 @@ def validate_sth_row(dev, b, t=8, p=128, batches=8):
             return self.x[i % 16], self.y[(i + 5) % 16], labels[i]
     crit = torch.nn.CrossEntropyLoss()
     out = {}
-    for tag, ds in (("", DS(gl8, fo8)), ("fp32_clips_", DS(gl, fo))):
+    for tag, ds in (("", DS(gl8, fo8)),) + ((("fp32_clips_", DS(gl, fo)),) if fp32_clips else ()):
         for name, base in (("with_baseline_branch", True), ("without_baseline_branch", False)):
             E.validate_sth(ds, m, crit, a, quiet=True, with_baseline=base)
             torch.cuda.synchronize()
@@ -207,7 +210,49 @@ def validate_sth_row(dev, b, t=8, p=128, batches=8):
     out["note"] = ("evaluate.validate_sth, T=%d + %d, P=%d, video_div=1, %d batches of %d clips per call; with_ / without_baseline_branch: from the "
                    "loader's stacked uint8 (H,W,T*3) clips in host memory (2 x %.0f MB per batch over PCIe, normalised on the GPU); fp32_clips_*: from the "
                    "reference's normalised fp32 (T*3,H,W) clips (2 x %.0f MB per batch); the baseline branch doubles the local-CNN work for a "
-                   "logged-only reward" % (t, t, p, batches, b, b * t * 3 * 224 * 224 / 1e6, b * t * 3 * 224 * 224 * 4 / 1e6))
+                   "logged-only reward" % (t, tf, p, batches, b, b * (t + tf) / 2 * 3 * 224 * 224 / 1e6, b * (t + tf) / 2 * 3 * 224 * 224 * 4 / 1e6))
+    return out
+
+
+def sth_shipped_row(dev, b, streams):
+    """The reference's SHIPPED Something-Something evaluation configuration (STH/evaluate.sh:5-15, STH/conf/evaluate.yaml:29-30):
+    num_segments_glancer = 8, num_segments_focuser = 12, patch_size = 144, video_div = 1 -- the only configuration with a published
+    throughput (figure/sthsth.png, Table 3: AdaFocus-TSM 144^2, MobileNetV2 + ResNet-50, 8 + 12 frames: 143.8 videos/s at bs = 64 on
+    an RTX 2080 Ti).  Rows: the hot path (gather -> 12-segment TSM-ResNet-50 -> FC + consensus), the whole model forward from uint8
+    clips resident in HBM (ingest + TSM-MobileNetV2 glancer + continuous policy + hot path, without the reward baseline: what an
+    inference throughput measures), and the evaluate.validate_sth loop from host memory."""
+    from adafocus_amd import workload
+    from adafocus_amd.gfv_net_sth import GFV
+    from adafocus_amd.transforms import ingest_uint8
+    tg, tf, p = 8, 12, 144
+    out = {"T_glancer": tg, "T_focuser": tf, "P": p, "B": b,
+           "published": {"value": 143.8, "unit": "videos/s", "hardware": "RTX 2080 Ti", "batch": 64, "source": "figure/sthsth.png",
+                         "note": "context only: other hardware, the reference's PyTorch 1.8 / cuDNN per-step loop"}}
+    out["hot_path"] = sth_hot_path_row(dev, b, streams, 30, t=tf, p=p, tg=tg)
+    a = sth_args(b, tg, p, tf=tf)
+    m = GFV(a).eval()
+    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])     # STH/evaluate.py:83
+    m.load_state_dict(synth_model_state(m, 1007), strict=True)
+    m = m.to(dev)
+    gu = torch.randint(0, 256, (b, 224, 224, tg * 3), dtype=torch.uint8, device=dev)
+    fu = torch.randint(0, 256, (b, 224, 224, tf * 3), dtype=torch.uint8, device=dev)
+
+    def forward():
+        g4 = ingest_uint8(gu, tg, m.input_mean, m.input_std)
+        f4 = ingest_uint8(fu, tf, m.input_mean, m.input_std)
+        fm4, glog = m.glance_nhwc4(g4, b)
+        return m.action_stage2_nhwc4(f4, fm4, glog, 0, a, with_baseline=False)[0]
+    with torch.no_grad():
+        sec = _clock(forward, streams[:1], 10, warm=3)
+    flop = 2.0 * (workload.resnet50_macs_per_patch(p) * tf + workload.mobilenetv2_macs_per_frame(224) * tg) * b
+    out["full_forward_from_uint8"] = {"value": round(b / sec, 1), "unit": "videos/s", "ms_per_batch": round(sec * 1e3, 3), "streams": 1,
+                                      "gflop_per_video": round(flop / b / 1e9, 2), "tflops": round(flop / sec / 1e12, 1),
+                                      "vs_published_other_hardware": round(b / sec / 143.8, 1),
+                                      "note": "uint8 clips resident in HBM -> ingest -> glance_nhwc4 -> action_stage2_nhwc4(with_baseline=False)"}
+    del m, gu, fu
+    torch.cuda.empty_cache()
+    loop = validate_sth_row(dev, b, t=tg, p=p, batches=6, tf=tf, fp32_clips=False)
+    out["validate_sth_loop"] = loop
     return out
 
 

@@ -220,11 +220,15 @@ def policy_encode_act(sd, p, state):
     return F.relu(F.linear(y.flatten(1), sd[p + "state_encoder.3.weight"], sd[p + "state_encoder.3.bias"]))
 
 
-def policy_act_discrete(sd, p, state, hidden):
+def policy_act_discrete(sd, p, state, hidden, return_gap=False):
     """One step of ActorCritic.act(training=False) -- ACT/models/ppo.py:67-96.  Returns
-    (action index (B,) int64, new hidden (B,Hd))."""
+    (action index (B,) int64, new hidden (B,Hd)); with return_gap also log p(top-1) - log p(top-2) per clip, the margin
+    an arg-max flip would have to overcome (tests assert it before comparing policy-driven outputs)."""
     h = gru_cell(policy_encode_act(sd, p, state), hidden, *_gru_params(sd, p + "gru."))
     probs = torch.softmax(F.linear(h, sd[p + "actor.0.weight"], sd[p + "actor.0.bias"]), dim=-1)
+    if return_gap:
+        top = torch.log(probs).topk(2, dim=1)[0]
+        return probs.max(1)[1], h, top[:, 0] - top[:, 1]
     return probs.max(1)[1], h
 
 
@@ -298,13 +302,14 @@ def backbone_pred(sd, images, which):
 # a9: end-to-end compositions
 # --------------------------------------------------------------------------------------
 def act_forward(sd, images, scan, patch_size, action_dim=49, forced_action_idx=None, per_step=True,
-                return_aux=False):
+                return_aux=False, return_gap=False):
     """GFV.forward(one_step=True, training=False) -- ACT/models/gfv_net.py:95-133.
 
     per_step=True follows the reference's structure literally (T sequential focuser calls of
     batch B); per_step=False is the offline restructuring (all actions, one batched crop, one
     batched local-CNN pass, one GRU scan) that SURVEY.md §0.4 shows is exactly equivalent.
     forced_action_idx (B,T) int64 overrides the policy's argmax (parity tests need varied crops).
+    return_gap appends the policy's arg-max margins (B,T) (policy_act_discrete) to the result.
     """
     b, tc, hh, ww = images.shape
     t = tc // 3
@@ -315,10 +320,11 @@ def act_forward(sd, images, scan, patch_size, action_dim=49, forced_action_idx=N
     table = standard_actions(action_dim)
     pol = "focuser.policy.policy_old."
     hid = images.new_zeros(b, sd[pol + "gru.weight_hh_l0"].shape[1])
-    feats, idx_all = [], []
+    feats, idx_all, gaps = [], [], []
     if per_step:
         for s in range(t):
-            idx, hid = policy_act_discrete(sd, pol, fm[:, s], hid)
+            idx, hid, gap = policy_act_discrete(sd, pol, fm[:, s], hid, return_gap=True)
+            gaps.append(gap)
             if forced_action_idx is not None:
                 idx = forced_action_idx[:, s]
             idx_all.append(idx)
@@ -329,14 +335,17 @@ def act_forward(sd, images, scan, patch_size, action_dim=49, forced_action_idx=N
         idx_all = torch.stack(idx_all, 1)
     else:
         for s in range(t):
-            idx, hid = policy_act_discrete(sd, pol, fm[:, s], hid)
+            idx, hid, gap = policy_act_discrete(sd, pol, fm[:, s], hid, return_gap=True)
+            gaps.append(gap)
             idx_all.append(idx)
         idx_all = torch.stack(idx_all, 1) if forced_action_idx is None else forced_action_idx
         patch = get_patch(frames.reshape(b * t, 3, hh, ww), table[idx_all.reshape(-1)], patch_size)
         local = resnet50_trunk(sd, "focuser.net.", patch).view(b, t, -1)
         feature = torch.cat([fv, local], dim=2)
     out = recurrent_classifier(sd, "classifier.", feature)
-    return out + (idx_all, feature) if return_aux else out
+    if return_aux:
+        out = out + (idx_all, feature)
+    return out + (torch.stack(gaps, 1),) if return_gap else out
 
 
 def act_hot_path(sd, frames_nchw, glancer_vec, actions, patch_size):

@@ -65,3 +65,45 @@ def test_bench_distributed_init_failure_leaves_one_diagnosable_line():
     assert r["n_gpus"] == 8 and r["rccl_ranks"] == 0 and r["value"] is None and "error" in r and "injected failure" in r["exception"]
     assert r["env"]["WORLD_SIZE"] == "8" and r["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MASTER_ADDR" in r["env"]
     assert 1 <= out.stderr.count("bench.py rank") <= 7       # the other ranks report on stderr (those the launcher had not torn down yet)
+
+
+def _bare(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "4", "--frames", "2"] + extra,
+                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+
+def test_bench_more_gpus_asked_than_visible_leaves_one_json_line():
+    """`bench.py --gpus 2` WITHOUT --dry-run on a box that exposes fewer than 2 devices (this container has none; a driver box with a
+    narrower HIP_VISIBLE_DEVICES is the likeliest first multi-GPU failure): exactly one parseable line in the init-failure form from the
+    parent -- no torchrun error report, no per-rank traceback -- and exit code 3."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has >= 2 GPUs: the launch would be real")
+    out = _bare(["--gpus", "2"])
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] is None and r["rccl_ranks"] == 0 and "error" in r
+    assert "--gpus 2" in r["exception"] and "HIP_VISIBLE_DEVICES" in r["exception"]
+    assert "visible_gpus" in r and r["visible_gpus"] < 2 and "HIP_VISIBLE_DEVICES" in r["env"] and "ROCR_VISIBLE_DEVICES" in r["env"]
+    assert "Traceback" not in out.stderr
+
+
+def test_bench_rank_without_its_device_reports_through_the_guard():
+    """The same condition met INSIDE a rank (launched by the driver's own torchrun, so the parent check never ran): rank 1 of 2 asks for
+    HIP device 1 on a box without it -> the init-failure line (rank 0 on stdout, others on stderr), exit code 3, no bare traceback."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has >= 2 GPUs")
+    out = _bare(["--gpus", "2"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["value"] is None and r["rccl_ranks"] == 0 and "wants HIP device 1" in r["exception"]
+    assert "Traceback" not in out.stderr

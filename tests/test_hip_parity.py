@@ -191,6 +191,8 @@ CONV_CASES = [
     (6, 7, 7, 24, 144, 1, 1, 0, 2, False, 0),           # MobileNetV2 expand, ReLU6, K = 24 (< one k slice)
     (8, 6, 6, 64, 64, 1, 1, 0, 1, False, 4),            # fused temporal shift, 2 clips x 4 segments
     (8, 3, 3, 256, 128, 1, 1, 0, 1, True, 8),           # fused temporal shift, one clip of 8
+    (24, 6, 6, 64, 64, 1, 1, 0, 1, False, 12),          # ... two clips of TWELVE segments (STH/evaluate.sh: num_segments_focuser=12)
+    (24, 3, 3, 256, 128, 1, 1, 0, 1, True, 12),         # ... with a residual
 ]
 
 
@@ -334,11 +336,11 @@ def test_resnet50_trunk_golden(dev, O):
     assert errm < 3e-4 * max(1.0, float(np.abs(g["trunk_map"]).max())), errm
 
 
-@pytest.mark.parametrize("p,tsm", [(96, 0), (128, 0), (144, 0), (128, 8), (100, 0), (72, 4)])
+@pytest.mark.parametrize("p,tsm", [(96, 0), (128, 0), (144, 0), (128, 8), (100, 0), (72, 4), (144, 12)])
 def test_resnet50_trunk_vs_oracle(dev, O, p, tsm):
     net, sd = _trunk(dev, 1007 + p)
     net.tsm_segments = tsm
-    n = 8 if p != 100 else 5            # 5: no dimension is a multiple of any tile
+    n = 5 if p == 100 else 24 if tsm == 12 else 8    # 5: no dimension is a multiple of any tile; 24: two clips of 12 segments
     x = rnd((n, 3, p, p), 300 + p)
     with torch.no_grad():
         got = net.get_featvec(x.to(dev)).cpu()
@@ -348,13 +350,13 @@ def test_resnet50_trunk_vs_oracle(dev, O, p, tsm):
     assert ref.abs().max().item() > 0.1
 
 
-@pytest.mark.parametrize("p,tsm", [(96, 0), (128, 8), (100, 0), (64, 0)])
+@pytest.mark.parametrize("p,tsm", [(96, 0), (128, 8), (100, 0), (64, 0), (144, 12)])
 def test_resnet50_featmap_unpooled_vs_oracle(dev, O, p, tsm):
     """ResNet.get_featmap(x, pooled=False) (ACT/models/resnet.py:211-225: the map before the average pool), NCHW like the reference's
     return value: against the oracle's trunk, and consistent with the pooled call (whose pool rides in the last conv's epilogue)."""
     net, sd = _trunk(dev, 1107 + p)
     net.tsm_segments = tsm
-    n = 8 if p != 100 else 5
+    n = 5 if p == 100 else 24 if tsm == 12 else 8
     x = rnd((n, 3, p, p), 350 + p)
     with torch.no_grad():
         fmap = net.get_featmap(x.to(dev), pooled=False)
@@ -558,11 +560,11 @@ def test_act_full_forward_golden(dev):
     assert np.abs(feat[:, :, :1280].cpu().numpy() - g["glancer_vec"]).max() < 1e-3
     assert np.abs(logits.cpu().numpy() - g["logits_forced"]).max() < TOL
     assert np.abs(last.cpu().numpy() - g["last_forced"]).max() < TOL
-    if np.array_equal(pol_idx.cpu().numpy(), g["policy_idx"]):       # argmax ties may flip across backends
-        assert np.abs(lg2.cpu().numpy() - g["logits"]).max() < TOL
-        assert np.abs(last2.cpu().numpy() - g["last"]).max() < TOL
-    else:
-        pytest.xfail("policy argmax flipped on a near-tie (different fp32 summation order); forced-action parity passed")
+    # the reference's own arg-max margins are stored with the fixture (the generator asserts a floor), so no escape hatch
+    assert g["policy_argmax_gap"].min() >= 2e-3
+    assert np.array_equal(pol_idx.cpu().numpy(), g["policy_idx"])
+    assert np.abs(lg2.cpu().numpy() - g["logits"]).max() < TOL
+    assert np.abs(last2.cpu().numpy() - g["last"]).max() < TOL
 
 
 def test_hot_path_concurrent_streams_deterministic(dev):
@@ -687,15 +689,11 @@ def test_sth_end_to_end_golden(dev):
     assert np.abs(pred_f.cpu().numpy() - g["logits_forced"]).max() < TOL
     assert np.abs(pred3.cpu().numpy() - g["logits_stage3_forced"]).max() < TOL
     assert torch.equal(patch3, patch_f)
-    # policy-driven action: continuous output of a PyTorch-ROCm producer; the crop origin floor() may differ
-    # by one pixel if the action lands within float noise of a pixel boundary, so compare when coords agree
-    ref_xy = np.floor(g["policy_action"] * (224 - 128)).astype(np.int32)
-    got_xy = np.floor(act.cpu().numpy() * (224 - 128)).astype(np.int32)
-    assert np.abs(act.cpu().numpy() - g["policy_action"]).max() < 1e-3
-    assert np.abs(act_t.cpu().numpy() - g["policy_action"]).max() < 1e-3
-    if not np.array_equal(ref_xy, got_xy):       # loud, so a skipped value check shows up in the GPU test record
-        pytest.skip("policy action within float noise of a pixel boundary: crop origin %s vs the reference's %s; the "
-                    "forced-action parity above passed" % (got_xy.tolist(), ref_xy.tolist()))
+    # policy-driven action: the reference's crop origins sit >= 0.02 px from a pixel boundary (stored with the fixture, the
+    # generator asserts it) and the engine's actions must land within 1e-4 of them (0.01 px): same origins, unconditionally
+    assert g["policy_action_px_margin"].min() >= 0.02
+    assert np.abs(act.cpu().numpy() - g["policy_action"]).max() < 1e-4
+    assert np.abs(act_t.cpu().numpy() - g["policy_action"]).max() < 1e-4
     assert np.array_equal(patch[:, :, :, :4, :4].cpu().numpy(), g["patch_corner"])
     assert np.abs(pred.cpu().numpy() - g["logits"]).max() < TOL
 

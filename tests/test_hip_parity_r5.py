@@ -1,0 +1,195 @@
+"""GPU parity tests added in round 5 (through the C ABI): the reference's SHIPPED Something-Something evaluation configuration
+-- STH/evaluate.sh:5-15, STH/conf/evaluate.yaml:29-30: num_segments_glancer = 8, num_segments_focuser = 12, patch_size = 144 --
+against G13 (tools/gen_golden_r2.py:gen_sth_shipped, the real reference's outputs).  Tg != Tf: the policy's state is 1280 * 8
+channels, the gather emits 12 patches per clip from one (y, x), and the local CNN's fused temporal shift runs over clips of
+TWELVE segments (not a power of two: STH/ops/temporal_shift.py:28-46 with n_segment = 12)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from adafocus_amd import synth
+from tests.helpers import golden, synth_sd
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("trunk_math")]
+
+TOL = 1e-3
+TG, TF, P = 8, 12, 144
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import ref_model
+    return ref_model
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def _shipped_model(dev):
+    from adafocus_amd.gfv_net_sth import GFV
+    from tests.test_state_dict_compat import sth_args
+    a = sth_args()
+    a.gpu, a.num_segments_focuser, a.patch_size = 0, TF, P
+    m = GFV(a).eval()
+    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])  # evaluate.py:83
+    m.load_state_dict(synth_sd("STH", 1007), strict=True)
+    pol = {k[len("policy."):]: v for k, v in synth_sd("STH_POLICY", 1007).items()}
+    m.focuser.policy.policy_old.load_state_dict(pol)
+    m.focuser.policy.policy.load_state_dict(pol)
+    m.focuser.policy.policy_old.eval()
+    m.focuser.policy.policy.eval()
+    return m.to(dev), a
+
+
+def _clips():
+    gl = torch.from_numpy(synth.synth_frames(2, TG, 224, seed=3))
+    fo = torch.from_numpy(synth.synth_frames(2, TF, 224, seed=13))
+    return gl, fo
+
+
+def test_sth_shipped_configuration_golden(dev):
+    """glance + action_stage2 (policy-driven, with the reward baseline on the reference's recorded torch.rand draw; forced action) +
+    action_stage3 at Tg = 8 / Tf = 12 / P = 144: logits within 1e-3 of the reference's, patches bit-exact (sha256 of all
+    2 x 12 x 3 x 144 x 144 values), the policy's GRU state within 1e-3.  No escape hatch: the reference's crop origins sit
+    >= 0.02 px from a pixel boundary (stored with the fixture)."""
+    g = golden("g13_sth_shipped")
+    m, a = _shipped_model(dev)
+    assert m.focuser.net.num_segments == TF and m.glancer.net.tsm_segments == TG
+    gl, fo = _clips()
+    gl, fo = gl.to(dev), fo.view(2, TF, 3, 224, 224).to(dev)
+    forced = torch.from_numpy(g["forced_action"]).to(dev)
+    with torch.no_grad():
+        fm, glog = m.glance(gl)
+        assert fm.shape == (2, TG, 1280, 7, 7) and glog.shape == (2, TG, 174)
+        assert np.abs(glog.cpu().numpy() - g["glancer_logit"]).max() < TOL
+        pred, base, patch = m.action_stage2(fo, fm, glog, 0, a, prev_local_patch=None, training=False,
+                                            baseline_action=torch.from_numpy(g["rand"]).to(dev))
+        hid = m.focuser.memory.hidden[-1]
+        act = m.focuser.policy.policy_old.act_nhwc(fm.permute(0, 1, 3, 4, 2).reshape(2 * TG, 7, 7, 1280), 2, TG)
+        pred3, patch3 = m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None)
+        pred_f, base_f, patch_f = m.action_stage2(fo, fm, glog, 0, a, prev_local_patch=None, training=False, forced_action=forced,
+                                                  baseline_action=torch.from_numpy(g["rand_forced"]).to(dev))
+        pred3_f, patch3_f = m.action_stage3(fo, fm, glog, 0, a, prev_local_patch=None, forced_action=forced)
+        nb, none, patch_nb = m.action_stage2(fo, fm, glog, 0, a, prev_local_patch=None, training=False, with_baseline=False)
+    assert patch.shape == (2, TF, 3, P, P) and base.shape == (2, 174)
+    assert g["policy_action_px_margin"].min() >= 0.02
+    assert np.abs(act.cpu().numpy() - g["policy_action"]).max() < 1e-4
+    assert np.abs(hid[0].cpu().numpy() - g["hidden"]).max() < TOL
+    assert np.array_equal(_sha(patch.cpu().numpy()), g["patch_sha"])
+    assert np.array_equal(patch[:, :, :, :4, :4].cpu().numpy(), g["patch_corner"])
+    assert np.abs(pred.cpu().numpy() - g["logits"]).max() < TOL
+    assert np.abs(base.cpu().numpy() - g["baseline"]).max() < TOL
+    assert np.abs(pred3.cpu().numpy() - g["logits_stage3"]).max() < TOL and torch.equal(patch3, patch)
+    assert np.array_equal(_sha(patch_f.cpu().numpy()), g["patch_forced_sha"])
+    assert np.abs(pred_f.cpu().numpy() - g["logits_forced"]).max() < TOL
+    assert np.abs(base_f.cpu().numpy() - g["baseline_forced"]).max() < TOL
+    assert np.abs(pred3_f.cpu().numpy() - g["logits_stage3_forced"]).max() < TOL and torch.equal(patch3_f, patch_f)
+    # the baseline branch is a second half of the same trunk pass: clips of 12 must not shift into the other half
+    assert none is None and torch.equal(patch_nb, patch) and torch.equal(nb, pred)
+
+
+def test_sth_shipped_tsm_trunk_clip_independence(dev):
+    """A 12-segment temporal shift touches only the frames of its own clip: the features of clip k in a 5-clip batch (60 patches of
+    144^2: ragged against every tile) are those of clip k run alone -- bit for bit (fp32 MFMA chains in one k order)."""
+    from adafocus_amd.tsn import TSN
+    from tests.helpers import rnd
+    m, _ = _shipped_model(dev)
+    net = m.focuser.net
+    assert isinstance(net, TSN)
+    x = rnd((5 * TF, P, P, 4), 77).to(dev)
+    x[..., 3] = 0
+    with torch.no_grad():
+        full = net.features_nhwc4(x)
+        alone = [net.features_nhwc4(x[k * TF:(k + 1) * TF].contiguous()) for k in (0, 3, 4)]
+    assert full.shape == (5 * TF, 2048)
+    for k, f in zip((0, 3, 4), alone):
+        assert torch.equal(full[k * TF:(k + 1) * TF], f), k
+
+
+def test_sth_shipped_trunk_vs_oracle(dev, O):
+    """The TSM-ResNet-50 of the shipped configuration (12 segments, 144^2) against the oracle's trunk on 2 clips, through TSN's
+    reference-layout forward (STH/models/tsn.py:215-241, no_reshape=True)."""
+    from tests.helpers import rnd
+    m, _ = _shipped_model(dev)
+    sd = synth_sd("STH", 1007)
+    sd = O.canonical_resnet_keys(sd, "focuser.net.base_model.")
+    x = rnd((2 * TF, 3, P, P), 78)
+    with torch.no_grad():
+        got = m.focuser.net(x.to(dev), no_reshape=True).cpu()
+        ref = O.resnet50_trunk(sd, "focuser.net.base_model.", x, TF, 8).flatten(1)
+    assert got.shape == ref.shape == (2 * TF, 2048)
+    assert (got - ref).abs().max().item() < 3e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("with_baseline", [True, False])
+def test_validate_sth_shipped_configuration(dev, O, with_baseline):
+    """evaluate.validate_sth (the loop of STH/evaluate.py:165-226) at the shipped configuration: from the loader's fp32 clips the last
+    step's logits are G13's; from stacked uint8 clips (two streams of DIFFERENT length: 8 x 3 and 12 x 3 channels) they are
+    torch.equal to the same clips normalised on the host."""
+    from adafocus_amd import evaluate as E
+    g = golden("g13_sth_shipped")
+    m, a = _shipped_model(dev)
+    a.batch_size, a.glance_size = 2, 224
+    gl, fo = _clips()
+    labels = torch.tensor([5, 100])
+
+    class DS:
+        def __init__(self, g_, f_, n):
+            self.g, self.f, self.n = g_, f_, n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return self.g[i], self.f[i], labels[i % 2]
+
+    torch.manual_seed(5)
+    r = E.validate_sth(DS(gl, fo, 2), m, torch.nn.CrossEntropyLoss(), a, quiet=True, with_baseline=with_baseline, return_logits=True)
+    assert np.abs(r[4].numpy() - g["logits"]).max() < TOL
+    assert np.abs(m.focuser.memory.hidden[-1][0].cpu().numpy() - g["hidden"]).max() < TOL
+    assert torch.equal(r[5], labels) and len(r[2]) == 1
+    assert (r[2][0] is None) != with_baseline and (not with_baseline or np.isfinite(r[2][0]))
+    ref1 = float(E.accuracy(torch.from_numpy(g["logits"]), labels)[0])
+    assert abs(r[0] - ref1) < 1e-4
+
+    gen = np.random.Generator(np.random.PCG64([23, 5]))
+    n = 3                                                                           # ragged last batch
+    gu = gen.integers(0, 256, size=(n, 224, 224, 3 * TG), dtype=np.uint8)
+    fu = gen.integers(0, 256, size=(n, 224, 224, 3 * TF), dtype=np.uint8)
+    gf = torch.stack([O.ingest_uint8(gu[i]) for i in range(n)])
+    ff = torch.stack([O.ingest_uint8(fu[i]) for i in range(n)])
+    assert gf.shape == (n, 3 * TG, 224, 224) and ff.shape == (n, 3 * TF, 224, 224)
+    torch.manual_seed(11)
+    r8 = E.validate_sth(DS(torch.from_numpy(gu), torch.from_numpy(fu), n), m, torch.nn.CrossEntropyLoss(), a, quiet=True,
+                        with_baseline=with_baseline, return_logits=True)
+    torch.manual_seed(11)
+    r32 = E.validate_sth(DS(gf, ff, n), m, torch.nn.CrossEntropyLoss(), a, quiet=True, with_baseline=with_baseline, return_logits=True)
+    assert torch.equal(r8[4], r32[4]) and torch.equal(r8[5], r32[5]) and r8[:3] == r32[:3]
+    # ... and against the oracle on the fp32 clips (main branch)
+    sd = synth_sd("STH", 1007)
+    sd.update(synth_sd("STH_POLICY", 1007))
+    sd = O.canonical_resnet_keys(sd, "focuser.net.base_model.")
+    with torch.no_grad():
+        ref, _, _ = O.sth_forward(sd, gf[:2], ff[:2].view(2, TF, 3, 224, 224), P, TG, TF)
+    assert (r32[4][:2] - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+
+
+def test_sth_shipped_glancer_and_focuser_in_one_model_forward(dev, O):
+    """GFV.forward (STH/models/gfv_net.py:74-99, eval): the TSM glancer at 8 segments beside the TSM focuser at 12 in one model --
+    the two shift lengths live in different sub-modules and must not leak into each other."""
+    m, _ = _shipped_model(dev)
+    g = golden("g13_sth_shipped")
+    gl, fo = _clips()
+    with torch.no_grad():
+        out = m(input=fo.to(dev), scan=gl.to(dev))
+    assert out.shape == (2, 174)
+    assert np.abs(out.cpu().numpy() - g["logits"]).max() < TOL

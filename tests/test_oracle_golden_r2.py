@@ -98,3 +98,63 @@ def test_g12_sth_video_div_and_baseline():
                 assert np.array_equal(prev[:, :, :, :4, :4].numpy(), g["vd%d_patch_corner_%d" % (vd, step)])
                 np.testing.assert_allclose(total.numpy(), g["vd%d_total_%d" % (vd, step)], rtol=1e-4, atol=3e-5)
                 np.testing.assert_allclose(base.numpy(), g["vd%d_base_%d" % (vd, step)], rtol=1e-4, atol=3e-5)
+
+
+def test_g13_sth_shipped_configuration():
+    """The reference's shipped Something-Something evaluation configuration (STH/evaluate.sh:5-15, conf/evaluate.yaml:29-30):
+    Tg = 8 glancer frames, Tf = 12 focuser frames, P = 144.  The policy's state stays 1280 * 8 channels; the patches, the local
+    CNN's batch and its temporal shift run over clips of TWELVE frames."""
+    g = golden("g13_sth_shipped")
+    sd = sth_state(1)
+    gl = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=3))
+    fo = torch.from_numpy(synth.synth_frames(2, 12, 224, seed=13)).view(2, 12, 3, 224, 224)
+    with torch.no_grad():
+        fm, glog = O.glancer_sth(sd, "glancer.net.", gl.view(16, 3, 224, 224), 8, 8)
+        fm, glog = fm.view(2, 8, *fm.shape[1:]), glog.view(2, 8, -1)
+        np.testing.assert_allclose(glog.numpy(), g["glancer_logit"], rtol=1e-4, atol=3e-5)
+        total, base, patch, action, hid = O.sth_stage(sd, fm, glog, fo, 0, 1, 144, 12, None, None,
+                                                      baseline_action=torch.from_numpy(g["rand"]))
+        np.testing.assert_allclose(action.numpy(), g["policy_action"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(hid.numpy(), g["hidden"], rtol=1e-4, atol=1e-5)
+        assert patch.shape == (2, 12, 3, 144, 144)
+        assert np.array_equal(_sha(patch.numpy()), g["patch_sha"])
+        assert np.array_equal(patch[:, :, :, :4, :4].numpy(), g["patch_corner"])
+        np.testing.assert_allclose(total.numpy(), g["logits"], rtol=1e-4, atol=3e-5)
+        np.testing.assert_allclose(total.numpy(), g["logits_stage3"], rtol=1e-4, atol=3e-5)     # stage 3 = the main branch
+        np.testing.assert_allclose(base.numpy(), g["baseline"], rtol=1e-4, atol=3e-5)
+        forced = torch.from_numpy(g["forced_action"])
+        total_f, base_f, patch_f, _, _ = O.sth_stage(sd, fm, glog, fo, 0, 1, 144, 12, None, None, forced_action=forced,
+                                                     baseline_action=torch.from_numpy(g["rand_forced"]))
+        assert np.array_equal(_sha(patch_f.numpy()), g["patch_forced_sha"])
+        np.testing.assert_allclose(total_f.numpy(), g["logits_forced"], rtol=1e-4, atol=3e-5)
+        np.testing.assert_allclose(total_f.numpy(), g["logits_stage3_forced"], rtol=1e-4, atol=3e-5)
+        np.testing.assert_allclose(base_f.numpy(), g["baseline_forced"], rtol=1e-4, atol=3e-5)
+        # sth_forward (the evaluate.py:195-201 composition) at the same configuration
+        t2, p2, a2 = O.sth_forward(sd, gl, fo, 144, 8, 12)
+        assert torch.equal(p2, patch) and torch.equal(a2, action)
+        np.testing.assert_allclose(t2.numpy(), g["logits"], rtol=1e-4, atol=3e-5)
+    assert g["policy_action_px_margin"].min() >= 0.02       # the generator's floor: the GPU tests compare unconditionally
+
+
+def test_policy_fixtures_carry_their_decision_margins():
+    """Every policy-driven fixture stores how far the REFERENCE's policy output sat from a decision boundary (tools/gen_golden.py:
+    ARGMAX_GAP_MIN, PIXEL_MARGIN_MIN), so no GPU test needs an escape hatch for an arg-max tie or a one-pixel crop move."""
+    assert golden("g7_act_e2e")["policy_argmax_gap"].shape == (2, 8) and golden("g7_act_e2e")["policy_argmax_gap"].min() >= 2e-3
+    assert golden("g7_act_c3")["policy_argmax_gap"].shape == (2, 16) and golden("g7_act_c3")["policy_argmax_gap"].min() >= 2e-3
+    assert golden("g7_sth_e2e")["policy_action_px_margin"].min() >= 0.02
+    g = golden("g12_sth_steps")
+    for vd in (1, 2):
+        for step in range(vd):
+            assert g["vd%d_action_px_margin_%d" % (vd, step)].min() >= 0.02
+    # the gap the fixtures store is the oracle's too (same policy arithmetic)
+    sd = synth_sd("ACT", 1007)
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=0))
+    with torch.no_grad():
+        fm, _ = O.glancer_act(sd, "glancer.net.", frames.view(16, 3, 224, 224))
+        fm = fm.view(2, 8, *fm.shape[1:])
+        hid = frames.new_zeros(2, 1024)
+        gaps = []
+        for s in range(8):
+            _, hid, gap = O.policy_act_discrete(sd, "focuser.policy.policy_old.", fm[:, s], hid, return_gap=True)
+            gaps.append(gap.numpy())
+    np.testing.assert_allclose(np.stack(gaps, 1), golden("g7_act_e2e")["policy_argmax_gap"], rtol=0, atol=2e-4)

@@ -109,6 +109,41 @@ def save(name, **arrays):
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
 
 
+# ------------------------------------------------------------------ margins (so the GPU tests need no escape hatch)
+ARGMAX_GAP_MIN = 2e-3      # top-1 minus top-2 actor log-probability: 20x the 1e-4 the HIP policy's logits may differ by
+PIXEL_MARGIN_MIN = 0.02    # distance of action * (H - P) from an integer, in pixels (1e-3 action error at H - P = 96 is 0.1 px;
+                           # the HIP policy's actions differ from torch-CPU's by ~1e-6)
+
+
+class ActorGap:
+    """Forward hook on the REFERENCE policy's `actor` head: records every output while active.  Discrete policies
+    (ACT/models/ppo.py:49-53: Linear + Softmax) -> `gaps()` = log p(top-1) - log p(top-2) per (call, clip), the logit gap an
+    arg-max flip would have to overcome; continuous (STH/models/ppo_continuous.py:59-61: Linear + Sigmoid) -> `outputs`."""
+
+    def __init__(self, actor):
+        self.actor, self.outputs = actor, []
+
+    def __enter__(self):
+        self._h = self.actor.register_forward_hook(lambda m, i, o: self.outputs.append(o.detach().clone()))
+        return self
+
+    def __exit__(self, *exc):
+        self._h.remove()
+
+    def gaps(self):
+        out = []
+        for probs in self.outputs:
+            top = torch.log(probs).topk(2, dim=1)[0]
+            out.append((top[:, 0] - top[:, 1]).numpy())
+        return np.stack(out, 1).astype(np.float32)          # (B, calls)
+
+
+def pixel_margin(action, image_size, patch_size):
+    """Distance of every crop coordinate `action * (H - P)` (ACT/models/utils.py:42) from the nearest integer, in pixels."""
+    v = np.asarray(action, dtype=np.float64) * (image_size - patch_size)
+    return np.abs(v - np.round(v)).astype(np.float32)
+
+
 # ------------------------------------------------------------------ ACT tree
 def gen_act():
     _enter_tree(ACT)
@@ -217,9 +252,12 @@ def gen_act():
         # record the policy's own choices by replaying select_action
         fm, fv = model.glance(frames)
         idxs = []
-        for s in range(8):
-            idxs.append(model.focuser.policy.select_action(fm[:, s], model.focuser.memory, s == 0, False))
+        with ActorGap(model.focuser.policy.policy_old.actor) as ag:
+            for s in range(8):
+                idxs.append(model.focuser.policy.select_action(fm[:, s], model.focuser.memory, s == 0, False))
         pol_idx = torch.stack(idxs, 1)
+        pol_gap = ag.gaps()
+        assert pol_gap.min() >= ARGMAX_GAP_MIN, "G7a: arg-max near-tie (%g): pick another frame seed" % pol_gap.min()
         # forced actions: patch the policy so crops vary
         forced_idx, _ = synth.synth_actions(16, 7, seed=2)
         forced = torch.from_numpy(forced_idx).view(2, 8)
@@ -262,7 +300,7 @@ def gen_act():
          mAP_multi=np.array([float(m_ap2)]), ap_multi=ap2.numpy())
 
     save("g7_act_e2e", seed_weights=np.array([1007]), weights_sha256=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8),
-         policy_idx=pol_idx.numpy(), logits=logits.numpy(), last=last.numpy(), forced_idx=forced.numpy(),
+         policy_idx=pol_idx.numpy(), policy_argmax_gap=pol_gap, logits=logits.numpy(), last=last.numpy(), forced_idx=forced.numpy(),
          logits_forced=logits_f.numpy(), last_forced=last_f.numpy(), glancer_vec=fv.numpy(),
          keys=np.array(sorted(shapes)), )
     return sorted(shapes.items())
@@ -310,8 +348,10 @@ def gen_sth(md):
         model.focuser.policy.select_action = lambda *a, **k: forced
         pred_f, _b2, patch_f = model.action_stage2(fo, fm, glog, 0, args, prev_local_patch=None, training=False)
         pred3, patch3 = model.action_stage3(fo, fm, glog, 0, args, prev_local_patch=None)
+    px = pixel_margin(act.numpy(), 224, 128)
+    assert px.min() >= PIXEL_MARGIN_MIN, "G7b: crop origin within %g px of a pixel boundary: pick another frame seed" % px.min()
     save("g7_sth_e2e", seed_weights=np.array([1007]),
-         weights_sha256=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8), policy_action=act.numpy(),
+         weights_sha256=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8), policy_action=act.numpy(), policy_action_px_margin=px,
          logits=pred.numpy(), forced_action=forced.numpy(), logits_forced=pred_f.numpy(),
          logits_stage3_forced=pred3.numpy(), glancer_logit=glog.numpy(),
          patch_corner=patch[:, :, :, :4, :4].numpy(), patch_forced_corner=patch_f[:, :, :, :4, :4].numpy(),
