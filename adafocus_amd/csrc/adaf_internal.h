@@ -149,7 +149,7 @@ int adaf_gru_scan_blocks_per_cu();
 bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int resident_blocks);
 int adaf_gru_scan_groups(int batch, int resident_blocks);
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
-                                           unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
+                                           unsigned* bar, size_t bar_words, int batch, int steps, const float* fcw, const float* fcb,
                                            float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, int groups,
                                            hipStream_t s);
 

@@ -484,6 +484,7 @@ struct adaf_resnet50 {
     int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
     bool fuse = true;              // stage 1: conv2 -> conv3 (-> next conv1) in one launch; stem + max-pool in one launch
     bool fuse_stem_always = false; // (tests) take the fused stem launch at every patch size, not only where it is faster
+    bool tsm_block = false;        // temporal shift in front of the WHOLE Bottleneck (shift_place = 'block') instead of its conv1 ('blockres')
     int lat_rows = -1;             // convs with at most this many GEMM rows take the small-batch form (-1 = the "latency_rows" option, 1536)
     float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
     bool finalized = false;
@@ -538,11 +539,18 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     // `lat_rows` rows is as long as ONE accumulator chain on the engine, and runs on the latency form instead (conv_lat.hip:
     // v_mfma_f32_16x16x4_f32 chains, 3.2x shorter and bit-identical).  ADAF_LATENCY_ROWS: the row limit (0 = never).
     const int lat_rows = net->lat_rows >= 0 ? net->lat_rows : adaf_options().latency_rows;
-    const bool lat_ok = lat_rows > 0 && tsm_T == 0 && net->math == ADAF_MATH_F32;
+    const bool lat_ok = lat_rows > 0 && tsm_T == 0 && net->math == ADAF_MATH_F32;     // (run_trunk's tsm_T: either shift placement)
     const bool fuse = net->fuse;
-    const size_t slab = adaf_resnet50_workspace_bytes(net, n, P) / (5 * sizeof(float));  // largest activation, floats
-    float* buf[5];
-    for (int i = 0; i < 5; ++i) buf[i] = static_cast<float*>(ws) + i * slab;
+    // shift_place = 'block' (STH/ops/temporal_shift.py:104-121): TemporalShift wraps the whole Bottleneck, so conv1, the downsample
+    // conv AND the identity see the shifted block input.  The shifted map is materialised in a sixth slab in front of every block and
+    // the block then runs exactly as a block without a shift (every fused form applies, except the next block's conv1 riding in a
+    // fused tail: it needs the SHIFTED output).  'blockres' (every shipped configuration) keeps the shift inside conv1's operand load.
+    const bool tsm_block = net->tsm_block && tsm_T > 0;
+    const int tsm_c1 = tsm_block ? 0 : tsm_T;     // the temporal shift conv1's operand load carries
+    const int nslab = net->tsm_block ? 6 : 5;
+    const size_t slab = adaf_resnet50_workspace_bytes(net, n, P) / (nslab * sizeof(float));  // largest activation, floats
+    float* buf[6];
+    for (int i = 0; i < nslab; ++i) buf[i] = static_cast<float*>(ws) + i * slab;
 
     auto mark = [&](double flops, double bytes, int tile) {
         if (rec) {   // events are created up front by the caller: recording is the only work between launches
@@ -608,11 +616,17 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     for (int s = 0; s < 4; ++s) {
         for (int b = 0; b < kStageBlocks[s]; ++b) {
             int h1 = hh, w1 = ww, h2, w2, h3, w3;
+            if (tsm_block) {       // the block's input, shifted along its clip: conv1, downsample and identity all read this copy
+                const int cin = net->convs[li].cin;
+                mark(0.0, 8.0 * (double)n * hh * ww * cin, 0);
+                adaf_launch_tshift(cur, n, cin, hh * ww, tsm_T, tsm_div, ADAF_LAYOUT_NHWC, buf[5], st);
+                float* t = cur; cur = buf[5]; buf[5] = t;
+            }
             const int i_c2 = li + 1, i_c3 = li + 2, i_ds = li + 3;
             const int i_next = li + 3 + (b == 0 ? 1 : 0);          // the next block's conv1 (or convs.size())
             // conv1 (1x1, optional fused temporal shift) -> conv2 (3x3, stride) -> conv3 (1x1) + identity
             bool ds_done = false;
-            if (s == 0 && b == 0 && !c1_done && fuse && net->l10_w && tsm_T == 0 && net->math == ADAF_MATH_F32 &&
+            if (s == 0 && b == 0 && !c1_done && fuse && net->l10_w && tsm_c1 == 0 && net->math == ADAF_MATH_F32 &&
                 !net->tiles[li] && !net->tiles[i_ds]) {
                 // layer1.0: conv1 and the downsample conv in ONE launch (same input, same 1x1 geometry; N = 64 + 256): the
                 // pooled map is read once instead of twice and a 0.07 ms launch disappears.  128x64 tiles: column tile 0 is conv1.
@@ -635,7 +649,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
                 ++li;
                 ds_done = true;
             } else if (!c1_done) {
-                if ((rc = conv(cur, hh, ww, ADAF_ACT_RELU, nullptr, t1, tsm_T > 0, &h1, &w1, 0))) return rc;
+                if ((rc = conv(cur, hh, ww, ADAF_ACT_RELU, nullptr, t1, tsm_c1 > 0, &h1, &w1, 0))) return rc;
             } else ++li;
             c1_done = false;
             const float* identity = cur;
@@ -659,7 +673,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
                 ConvArgs a2;
                 if ((rc = make_conv_args(h, &p, t1, L2.w, L2.scale, L2.bias, nullptr, t2, &a2))) return rc;
                 // the next block's conv1 rides along unless it carries a temporal shift or a tile override
-                const ConvLayer* Ln = (tsm_T == 0 && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;
+                const ConvLayer* Ln = (tsm_T == 0 && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;   // (either placement)
                 if (Ln && !(Ln->k == 1 && Ln->stride == 1 && Ln->cin == L3.cout && (Ln->cout == 64 || Ln->cout == 128))) Ln = nullptr;
                 const double M = (double)a2.M;
                 double macs = M * 64 * 9 * 64 + M * L3.cout * 64 + (Ln ? M * Ln->cout * L3.cout : 0.0);
@@ -818,13 +832,13 @@ int adaf_resnet50_finalize(adaf_resnet50* net, void* stream) {
 }
 
 size_t adaf_resnet50_workspace_bytes(const adaf_resnet50* net, int n, int patch) {
-    (void)net;
     if (n <= 0 || patch <= 0) return 0;
     // five slabs (block input, block output, two bottleneck temporaries, downsample branch), each as
-    // large as the biggest activation: the stem output or the first stage's 256-channel map
+    // large as the biggest activation: the stem output or the first stage's 256-channel map; a sixth for the
+    // shifted block input when the temporal shift wraps whole blocks (adaf_resnet50_set_shift_place)
     const int s1 = conv_out(patch, 7, 2, 3), s2 = conv_out(s1, 3, 2, 1);
     const size_t a = (size_t)s1 * s1 * 64, b = (size_t)s2 * s2 * 256;
-    return (size_t)5 * n * (a > b ? a : b) * sizeof(float);
+    return (size_t)((net && net->tsm_block) ? 6 : 5) * n * (a > b ? a : b) * sizeof(float);
 }
 
 int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
@@ -850,7 +864,7 @@ int adaf_resnet50_forward_map(adaf_resnet50* net, const float* patches_nhwc4, in
                      featmap_nhwc);
 }
 
-int adaf_resnet50_launch_count(const adaf_resnet50* net) { return net ? (int)net->convs.size() + 2 : 0; }
+int adaf_resnet50_launch_count(const adaf_resnet50* net) { return net ? (int)net->convs.size() + 2 + (net->tsm_block ? 16 : 0) : 0; }
 
 int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
                                    int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream,
@@ -896,6 +910,13 @@ int adaf_resnet50_set_fusion(adaf_resnet50* net, int on) {
     if (!net) return ADAF_E_BADARG;
     net->fuse = on != 0;
     net->fuse_stem_always = on == 2;
+    return ADAF_OK;
+}
+
+int adaf_resnet50_set_shift_place(adaf_resnet50* net, int place) {
+    if (!net) return ADAF_E_BADARG;
+    if (place != ADAF_SHIFT_BLOCKRES && place != ADAF_SHIFT_BLOCK) return fail(net->h, ADAF_E_BADARG, "set_shift_place: unknown placement %d", place);
+    net->tsm_block = place == ADAF_SHIFT_BLOCK;
     return ADAF_OK;
 }
 
@@ -966,7 +987,7 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
             for (int i = 0; i < need; ++i)
                 if (h->scan_used[slots[i]]) (void)hipStreamWaitEvent(st, h->scan_done[slots[i]], 0);   // the scans that held these slots have finished
         }
-        hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), batch, steps, fc_w,
+        hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), (size_t)batch * 3 * hidden, batch, steps, fc_w,
                                                        fc_b, logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, groups, st);
         if (e != hipSuccess) return hip_fail(h, e, "gru scan launch");
         if (!capturing) {

@@ -1699,9 +1699,12 @@ bool adaf_conv_glds_ok(const ConvArgs& a) {
 bool adaf_conv_tile_exists(int tile) {
     switch (tile) {
         case 1: case 2: case 3: case 4: case 5:
-        case 21: case 22: case 23: case 24: case 25: case 26: case 27:
-        case 31: case 32: case 33: case 34: case 37: case 38: case 39:
-        case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47:
+        case 21: case 22: case 23: case 24: case 25: case 26:
+        case 31: case 32: case 33: case 34: case 38: case 39:
+        case 40: case 41: case 42: case 43: case 44: case 45: case 46:
+#ifdef ADAF_EXP_TILES      // 256 x 256 block tiles: experiments only (tools/exp/build_exp_tiles.sh), not in the product library
+        case 27: case 37: case 47:
+#endif
         case 51: case 52: case 53: case 54:
         case 61: case 62: case 63: case 64: case 65: case 66: case 67:
         case 71: case 72: case 73: case 74:
@@ -1793,12 +1796,16 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 24: launch_glds<64, 128, 2, 2, false>(a, dense, s); break;
         case 25: launch_glds<256, 128, 4, 2, false>(a, dense, s); break;        // 8 waves of 64x64
         case 26: launch_glds<256, 128, 2, 2, false>(a, dense, s); break;        // 4 waves of 128x64
+#ifdef ADAF_EXP_TILES
         case 27: launch_glds<256, 256, 2, 4, false>(a, dense, s); break;        // 8 waves of 128x64
+#endif
         case 31: launch_glds<128, 128, 2, 2, true>(a, dense, s); break;   // 3x = 2x with the DMA issued between MFMA groups
         case 32: launch_glds<128, 64, 2, 2, true>(a, dense, s); break;
         case 33: launch_glds<64, 64, 2, 2, true>(a, dense, s); break;
         case 34: launch_glds<64, 128, 2, 2, true>(a, dense, s); break;
+#ifdef ADAF_EXP_TILES
         case 37: launch_glds<256, 256, 2, 4, true>(a, dense, s); break;
+#endif
         case 38: launch_glds<128, 32, 4, 1, true>(a, dense, s); break;    // narrow outputs (cout <= 32): four waves of 32x32
         case 39: launch_glds<256, 32, 4, 1, true>(a, dense, s); break;    // narrow outputs: four waves of 64x32
         // 7x: fp32 pipe with the barrier between steps 2 and 3 of a slice (next slice's first fragments prefetched)
@@ -1813,7 +1820,9 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s) {
         case 44: launch_glds<64, 128, 2, 2, true, 6>(a, dense, s); break;
         case 45: launch_glds<256, 128, 4, 2, true, 6>(a, dense, s); break;        // 8 waves of 64x64
         case 46: launch_glds<256, 128, 2, 2, true, 6>(a, dense, s); break;        // 4 waves of 128x64
+#ifdef ADAF_EXP_TILES
         case 47: launch_glds<256, 256, 2, 4, true, 6>(a, dense, s); break;        // 8 waves of 128x64
+#endif
         // 6x: split tiles with the weights pre-split at load time (ConvArgs::wsp)
         case 61: launch_glds<128, 128, 2, 2, true, 6, true>(a, dense, s); break;
         case 62: launch_glds<128, 64, 2, 2, true, 6, true>(a, dense, s); break;

@@ -215,9 +215,12 @@ int adaf_gru_scan_groups(int batch, int resident_blocks) {
 }
 
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
-                                           unsigned* bar, int batch, int steps, const float* fcw, const float* fcb,
+                                           unsigned* bar, size_t bar_words, int batch, int steps, const float* fcw, const float* fcb,
                                            float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, int groups,
                                            hipStream_t s) {
+    // `bar` lends groups * (steps + 1) words to the grid barriers: the launcher checks the capacity itself (it used to trust the caller)
+    if (groups > 1 && (size_t)groups * (steps + 1) > bar_words) groups = 1;
+    if ((size_t)(steps + 1) > bar_words) return hipErrorInvalidValue;
     GruScanArgs a;
     a.timeouts = timeouts;
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;

@@ -1,6 +1,6 @@
 // Whole-image MBConv blocks of EfficientNet (BASELINE config 5, fp16 storage): expand 1x1 + BN + swish -> depthwise k x k + BN + swish
 // -> squeeze-and-excite -> gated project 1x1 + BN (+ identity) as ONE launch for the blocks whose map is small enough that a
-// workgroup owns whole images (9 x 9 and 5 x 5 at 144^2 patches: 16 of B3's 26 blocks).  The 6x-expanded map never exists in HBM
+// workgroup owns whole images (9 x 9 and 5 x 5 at 144^2 patches: 15 of B3's 26 blocks: 9-17 and 19-24; block 25's 2304 hidden channels exceed the 2048 the kernel walks).  The 6x-expanded map never exists in HBM
 // (it does not even exist in LDS: it goes from the MFMA accumulators straight into the depthwise taps), the depthwise output
 // lives in LDS only, the squeeze is an in-block reduction and the two SE matrix products run inside the block -- four launches
 // and three HBM round trips of the widest tensors of the block become one launch that reads the block input and writes the block
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
 #pragma unroll
             for (int r = 0; r < SEB; ++r) {
                 const int j = j0 + r * kMbwWaves < SQ ? j0 + r * kMbwWaves : SQ - 1;
-                const float* wrow = a.se_wr + (size_t)j * hid + 4 * lane;
+                const float* wrow = a.se_wr + (size_t)j * hid + 4 * (lane < C4 ? lane : 0);      // (hid < 256: lanes past the row read lane 0's piece, never used)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) wv[r][q] = *reinterpret_cast<const f32x4*>(wrow + (lane + 64 * q < C4 ? 256 * q : 0));
             }
@@ -568,11 +568,9 @@ bool plan_mbw(int hw, int cin, int hid, int cout, int sq, int gmax, MbwPlan* p) 
 
 template <int HW, int K, int G>
 void launch_mbw_one(const MbwArgs& a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {      // dynamic LDS above 64 KB has to be asked for
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_whole_kernel<HW, K, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-        attr_set = true;
-    }
+    // dynamic LDS above 64 KB has to be asked for -- per DEVICE (function attributes are per device and a process may hold handles on
+    // several), so on every launch like the other launchers of effnet.hip; it is a host-side table update, not a device call
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_whole_kernel<HW, K, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     hipLaunchKernelGGL((mbconv_whole_kernel<HW, K, G>), dim3((unsigned)((a.n + G - 1) / G)), dim3(kMbwThreads), lds, s, a);
 }
 

@@ -10,6 +10,7 @@ on the hot path).  ``cal_map`` keeps the reference's label handling, including i
 label values that occur in the evaluated set (utils.py:56-60, called with assumes_starts_zero=False).
 """
 import os
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -98,25 +99,40 @@ def cal_map(output, old_test_y):
 
 
 STAGE_THREADS = 4    # worker threads that copy a batch's clips into pinned memory
-HOST_THREADS = 4     # torch intra-op threads while a loop runs (restored afterwards)
+HOST_THREADS = int(os.environ.get("ADAF_EVAL_HOST_THREADS", "4"))     # torch intra-op threads while a loop runs (restored afterwards); 0 = leave the team alone
 
 
 class _HostThreads:
     """The evaluation loops keep the host busy with many small jobs (launches, per-clip copies into pinned memory, three scalars per
     batch); torch's default intra-op team is one thread per core (128 on the GPU boxes' hosts) and every Tensor.copy_ / small CPU op
     wakes all of it.  Measured on validate_sth from uint8 clips (64-clip batches, 28.6 ms of GPU work each): 128 threads 34-38 ms per
-    batch, 1-4 threads 31 ms; without the baseline branch 24-29 -> 19.9 ms (17.7 ms of GPU work)."""
+    batch, 1-4 threads 31 ms; without the baseline branch 24-29 -> 19.9 ms (17.7 ms of GPU work).
+    SIDE EFFECT: torch.set_num_threads is process-wide, so any other thread doing CPU torch work during an evaluation call runs on the
+    capped team too (dataset transforms in DataLoader WORKER PROCESSES are not affected).  Overlapping calls are reference-counted under
+    a lock: the first one in saves the team size, the last one out restores it.  ADAF_EVAL_HOST_THREADS=0 opts out (no cap)."""
+    _lock = threading.Lock()
+    _depth = 0
+    _saved = None
 
     def __enter__(self):
-        self.old = torch.get_num_threads()
-        if self.old > HOST_THREADS:
-            torch.set_num_threads(HOST_THREADS)
+        cls = _HostThreads
+        with cls._lock:
+            if cls._depth == 0:
+                cls._saved = torch.get_num_threads()
+                if HOST_THREADS > 0 and cls._saved > HOST_THREADS:
+                    torch.set_num_threads(HOST_THREADS)
+            cls._depth += 1
         return self
 
     def __exit__(self, *exc):
-        if torch.get_num_threads() != self.old:
-            torch.set_num_threads(self.old)
+        cls = _HostThreads
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._saved is not None and torch.get_num_threads() != cls._saved:
+                torch.set_num_threads(cls._saved)
         return False
+
+
 _PINNED = {}     # (slot, batch size, item shape, dtype) -> pinned staging buffer, reused across validate() calls
 
 

@@ -299,7 +299,7 @@ class ResNet50Trunk:
         n, p = x.shape[0], x.shape[1]
         out = torch.empty((n, 2048), device=x.device, dtype=torch.float32)
         ws, need = self._workspace(n, p)
-        k = self.n_launches
+        k = self.n_launches = self._lib.adaf_resnet50_launch_count(self._net)
         ms = (C.c_float * k)()
         fl = (C.c_double * k)()
         by = (C.c_double * k)()
@@ -312,6 +312,12 @@ class ResNet50Trunk:
     def set_fusion(self, on):
         """Stage-1 conv2 -> conv3 (-> next conv1) and stem + max-pool as single launches (default on; bit-identical)."""
         L.check(self._lib.adaf_resnet50_set_fusion(self._net, int(on)), self._h)   # 2 = also the fused stem where it does not pay (tests)
+
+    def set_shift_place(self, place):
+        """'blockres' (default: the shift inside every Bottleneck conv1's operand load) or 'block' (the shift in front of the whole
+        Bottleneck: conv1, downsample and identity read the shifted map) -- STH/ops/temporal_shift.py:99-142."""
+        code = {"blockres": 0, "block": 1}[place]
+        L.check(self._lib.adaf_resnet50_set_shift_place(self._net, code), self._h)
 
     def set_latency_rows(self, rows):
         """Convs whose GEMM has at most `rows` rows take the small-batch form (conv_lat.hip; bit-identical); 0 = never, < 0 = default."""

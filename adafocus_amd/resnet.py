@@ -59,6 +59,7 @@ class ResNet(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self.tsm_segments = 0     # > 0: temporal shift before every Bottleneck conv1 (TSM, STH)
         self.tsm_div = 8
+        self.tsm_place = "blockres"   # 'blockres': shift inside every Bottleneck conv1; 'block': in front of the whole Bottleneck
         self._trunk = None
         self._sig = None
 
@@ -83,6 +84,9 @@ class ResNet(nn.Module):
                 self._trunk.set_fusion(getattr(self, "_fusion", True))
             self._trunk.load(params)
             self._sig = sig
+        if getattr(self._trunk, "_place", "blockres") != self.tsm_place:
+            self._trunk.set_shift_place(self.tsm_place)
+            self._trunk._place = self.tsm_place
         return self._trunk
 
     def set_fusion(self, on):

@@ -1,8 +1,9 @@
 """Temporal Shift Module -- host mirror of STH/ops/temporal_shift.py.
 
 ``TemporalShift.shift`` (temporal_shift.py:28-46) is a HIP kernel (`adaf_temporal_shift_f32`);
-inside the local CNN the shift is never materialised at all: ``make_temporal_shift`` only marks the
-ResNet so the trunk fuses it into every Bottleneck conv1's operand load.
+inside the local CNN the shift is never materialised at all with the shipped placement ('blockres'):
+``make_temporal_shift`` only marks the ResNet so the trunk fuses it into every Bottleneck conv1's operand load
+(DESIGN.md §3.2); place='block' materialises the shifted block input once per block.
 ``InplaceShift`` / ``TemporalPool`` are dead code in the reference (inplace raises, :36-38) and absent.
 """
 from torch import nn
@@ -34,12 +35,20 @@ class TemporalShift(nn.Module):
 
 
 def make_temporal_shift(net, n_segment, n_div=8, place="blockres", temporal_pool=False):
-    """temporal_shift.py:99-142 for the configuration the drivers use (place='blockres', ResNet-50,
-    no temporal pooling): every Bottleneck conv1 sees the shifted block input."""
+    """temporal_shift.py:99-142 for ResNet-50 without temporal pooling.  place='blockres' (every shipped configuration,
+    :123-140): every Bottleneck conv1 sees the shifted block input -- fused into that conv's operand load.  place='block'
+    (:104-121): TemporalShift wraps the whole Bottleneck, so conv1, the downsample conv and the identity all see it -- the shifted
+    map is materialised once per block (adaf_resnet50_set_shift_place)."""
     if temporal_pool:
         raise NotImplementedError("temporal_pool is unused by the reference drivers")
-    if "blockres" not in place:
-        raise NotImplementedError("only shift_place='blockres' is used by the reference configs")
+    if place == "block":
+        net.tsm_place = "block"
+    elif "blockres" in place:
+        net.tsm_place = "blockres"
+    else:
+        # (the reference silently inserts NO shift for any other string -- its `else: raise` belongs to the isinstance test,
+        #  temporal_shift.py:111-142; refused here rather than running a model that is not the one asked for)
+        raise NotImplementedError(place)
     net.tsm_segments = int(n_segment)
     net.tsm_div = int(n_div)
     return net

@@ -3,7 +3,8 @@ Something-Something drivers use (ResNet-50, RGB, TSM 'blockres', no temporal poo
 
 ``forward(input, no_reshape=True)`` (tsn.py:215-241) = TSM-ResNet-50 trunk -> (N, 2048), executed by
 ``adaf_resnet50_forward`` with the shift fused into conv1.  State-dict compatibility: the reference
-wraps every Bottleneck conv1 in ``TemporalShift`` (key ``...conv1.net.weight``) and
+wraps every Bottleneck conv1 in ``TemporalShift`` (key ``...conv1.net.weight``; with shift_place='block' the
+whole Bottleneck: ``layer1.0.net.conv1.weight``) and
 STH/evaluate.py:83 re-wraps the children in a Sequential to drop fc (keys ``base_model.4.0.conv1.net.
 weight``); both spellings load and save here.
 """
@@ -58,7 +59,8 @@ class TSN(nn.Module):
     def _canonicalise_keys(self, state_dict, prefix, *args):
         p = prefix + "base_model."
         for k in [k for k in state_dict if k.startswith(p)]:
-            rest = k[len(p):].replace(".conv1.net.", ".conv1.")
+            rest = k[len(p):].replace(".conv1.net.", ".conv1.")                      # shift_place = 'blockres': TemporalShift(conv1)
+            rest = re.sub(r"^((?:layer)?\d\.\d+)\.net\.", r"\1.", rest)                 # shift_place = 'block': TemporalShift(Bottleneck)
             head, _, tail = rest.partition(".")
             if head in _SEQ_INV:
                 rest = _SEQ_INV[head] + "." + tail
@@ -72,7 +74,9 @@ class TSN(nn.Module):
         p = prefix + "base_model."
         for k in [k for k in state_dict if k.startswith(p)]:
             rest = k[len(p):]
-            if self.is_shift:
+            if self.is_shift and self.shift_place == "block":
+                rest = re.sub(r"^(layer\d\.\d+)\.", r"\1.net.", rest)
+            elif self.is_shift:
                 rest = re.sub(r"^(layer\d\.\d+\.conv1)\.", r"\1.net.", rest)
             if self._stripped:
                 head, _, tail = rest.partition(".")

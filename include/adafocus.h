@@ -278,6 +278,16 @@ int adaf_resnet50_set_fusion(adaf_resnet50* net, int on);
  * (tests/test_hip_parity_r3.py).  ADAF_MATH_F32 without temporal shift only.  No reference counterpart (the reference's
  * published latency is a CPU bs = 1 figure). */
 int adaf_resnet50_set_latency_rows(adaf_resnet50* net, int rows);
+/* Where the temporal shift sits (make_temporal_shift(net, n_segment, n_div, place), STH/ops/temporal_shift.py:99-142):
+ *   ADAF_SHIFT_BLOCKRES (default; every shipped configuration, the STH/conf yaml files: `shift_place: blockres`): TemporalShift wraps the
+ *                       conv1 of every Bottleneck (:123-140) -- fused into that conv's operand load, no shifted tensor exists;
+ *   ADAF_SHIFT_BLOCK    TemporalShift wraps the WHOLE Bottleneck (:104-121): conv1, the downsample conv and the identity all see
+ *                       the shifted block input.  The shifted map is materialised once per block (adaf_temporal_shift_f32's
+ *                       kernel) in a sixth workspace slab -- adaf_resnet50_workspace_bytes(net, ...) grows accordingly, so set
+ *                       the placement before sizing the workspace.
+ * Only read when a forward is called with tsm_segments > 0. */
+enum { ADAF_SHIFT_BLOCKRES = 0, ADAF_SHIFT_BLOCK = 1 };
+int adaf_resnet50_set_shift_place(adaf_resnet50* net, int place);
 /* Arithmetic of the trunk's convolutions (no reference counterpart; the reference is plain fp32).
  *   ADAF_MATH_F32            (default) v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain per output.
  *   ADAF_MATH_F32_SPLIT_BF16 (opt-in)  every fp32 operand x is decomposed EXACTLY into bf16 parts h + m + l (round-to-
@@ -373,7 +383,7 @@ int adaf_effnet_feature_dim(const adaf_effnet* net);
 int adaf_effnet_block_count(const adaf_effnet* net);
 int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8);
 int adaf_effnet_set_dtype(adaf_effnet* net, int dtype);
-/* on (DEFAULT): fp16 storage only -- the stride-1 MBConv blocks whose map is at most 9 x 9 (blocks 9-17 and 19-25 of B3 at 144^2
+/* on (DEFAULT): fp16 storage only -- the stride-1 MBConv blocks whose map is at most 9 x 9 (blocks 9-17 and 19-24 of B3 at 144^2: 15 blocks; block 25 (hid 2304 > 2048) keeps the four-launch plan;
  * patches) run as ONE launch per block: a workgroup owns whole images, the 6x-expanded map goes from the MFMA accumulators
  * straight into the depthwise taps, the depthwise output and the squeeze-and-excite live in LDS, the block reads its input and
  * writes its output (csrc/mbconv_whole.hip).  off = the four-launch plan (expand, depthwise, SE gate, gated project).  Same

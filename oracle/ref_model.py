@@ -15,6 +15,8 @@ STH/ = "Experiments on Something-Something V1&V2/" under /root/reference.
 """
 import math
 
+import re
+
 import torch
 import torch.nn.functional as F
 
@@ -96,9 +98,13 @@ def _bn(sd, p, x):
                         sd[p + ".bias"], False, 0.0, BN_EPS)
 
 
-def bottleneck(sd, p, x, stride, tsm_segments=0, tsm_div=8):
-    """ACT/models/resnet.py:94-114; stride sits on conv2 (:86); TSM wraps conv1
-    (STH/ops/temporal_shift.py:123-140)."""
+def bottleneck(sd, p, x, stride, tsm_segments=0, tsm_div=8, shift_place="blockres"):
+    """ACT/models/resnet.py:94-114; stride sits on conv2 (:86); TSM wraps conv1 (shift_place 'blockres',
+    STH/ops/temporal_shift.py:123-140) or the whole block ('block', :104-121: the identity and the downsample conv see
+    the shifted input too)."""
+    if tsm_segments and shift_place == "block":
+        x = temporal_shift(x, tsm_segments, tsm_div)
+        tsm_segments = 0
     y = temporal_shift(x, tsm_segments, tsm_div) if tsm_segments else x
     y = F.relu(_bn(sd, p + ".bn1", F.conv2d(y, sd[p + ".conv1.weight"])))
     y = F.relu(_bn(sd, p + ".bn2", F.conv2d(y, sd[p + ".conv2.weight"], stride=stride, padding=1)))
@@ -117,13 +123,13 @@ def resnet50_stem(sd, p, x):
     return F.max_pool2d(y, 3, 2, 1)
 
 
-def resnet50_trunk(sd, p, x, tsm_segments=0, tsm_div=8, pooled=True):
+def resnet50_trunk(sd, p, x, tsm_segments=0, tsm_div=8, pooled=True, shift_place="blockres"):
     """ResNet.get_featmap(x, pooled) -- ACT/models/resnet.py:211-225.  p = key prefix such as
     'focuser.net.'.  Returns (N,2048,1,1) if pooled."""
     y = resnet50_stem(sd, p, x)
     for li, nblk, stride in RESNET50_STAGES:
         for b in range(nblk):
-            y = bottleneck(sd, "%slayer%d.%d" % (p, li, b), y, stride if b == 0 else 1, tsm_segments, tsm_div)
+            y = bottleneck(sd, "%slayer%d.%d" % (p, li, b), y, stride if b == 0 else 1, tsm_segments, tsm_div, shift_place)
     return F.adaptive_avg_pool2d(y, 1) if pooled else y
 
 
@@ -425,6 +431,7 @@ def canonical_resnet_keys(sd, prefix):
     for k, v in sd.items():
         if k.startswith(prefix):
             rest = k[len(prefix):].replace(".conv1.net.", ".conv1.")
+            rest = re.sub(r"^((?:layer)?\d\.\d+)\.net\.", r"\1.", rest)      # shift_place = 'block': TemporalShift(Bottleneck), :104-121
             head, _, tail = rest.partition(".")
             if head in _SEQ_TO_NAME:
                 rest = _SEQ_TO_NAME[head] + "." + tail

@@ -89,3 +89,65 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+# Kernels of the product library that may use scratch (private segment), with the most bytes each is allowed: a ratchet -- an entry may
+# only shrink or disappear.  Everything else must compile to ZERO scratch (a spill in an MFMA loop is a 10-30 % loss that no test notices).
+# Keys: the demangled name up to the argument list, anonymous namespace stripped.
+SCRATCH_ALLOWED = {
+    "mbconv_whole_kernel<9, 5, 1>": 184, "mbconv_whole_kernel<9, 3, 1>": 120, "mbconv_whole_kernel<5, 5, 2>": 80,
+    "mbconv_whole_kernel<4, 5, 2>": 80, "mbconv_whole_kernel<3, 5, 2>": 80,
+    "ef_expand_kernel<float, 8, false>": 104, "ef_expand_kernel<float, 8, true>": 84, "ef_expand_kernel<float, 7, false>": 48,
+    "ef_expand_kernel<float, 7, true>": 40, "ef_expand_kernel<_Float16, 8, true>": 76, "ef_expand_kernel<_Float16, 8, false>": 44,
+    "ef_expand_kernel<_Float16, 7, true>": 28,
+    "stem7x7_pool_kernel<6>": 28, "mb_block_w_kernel<32>": 8,
+}
+
+
+def kernel_scratch_table(lib_path, workdir):
+    """{short kernel name: (private_segment_fixed_size, vgpr_count, vgpr_spill_count)} for every gfx950 kernel of the library, from
+    the code objects' metadata notes (llvm-objdump --offloading + llvm-readelf --notes)."""
+    import glob
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    shutil.copy(lib_path, os.path.join(workdir, "lib.so"))
+    subprocess.run([llvm + "llvm-objdump", "--offloading", "lib.so"], cwd=workdir, check=True, capture_output=True)
+    table = {}
+    for co in sorted(glob.glob(os.path.join(workdir, "lib.so.*gfx950*"))):
+        notes = subprocess.run([llvm + "llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+        for k in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", k).group(1)
+            priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", k).group(1))
+            vg = int(re.search(r"\.vgpr_count:\s+(\d+)", k).group(1))
+            sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", k)
+            table[name] = (priv, vg, int(sp.group(1)) if sp else 0)
+    names = list(table)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+    short = {}
+    for n, d in zip(names, dem):
+        d = d.replace("(anonymous namespace)::", "").replace("void ", "", 1)
+        m = re.match(r"^(.*?>)\(", d) or re.match(r"^([^(]+)\(", d)
+        key = m.group(1) if m else d
+        if key.startswith("_ZN"):      # c++filt could not demangle (_Float16 template arguments): spell the ef_expand family by hand
+            mm = re.match(r"_ZN12_GLOBAL__N_116ef_expand_kernelIDF16_Li(\d)ELb([01])EEE", key)
+            if mm:
+                key = "ef_expand_kernel<_Float16, %s, %s>" % (mm.group(1), "true" if mm.group(2) == "1" else "false")
+        short[key] = table[n]
+    return short
+
+
+def test_no_kernel_uses_scratch_outside_the_allow_list(tmp_path):
+    """Every kernel of the product library (all are reachable from the default plans since the experiment tiles moved to
+    tools/exp/build_exp_tiles.sh) compiles WITHOUT scratch, except the allow-listed ones, which may not grow."""
+    _ensure_built()
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no llvm-readelf in this image")
+    table = kernel_scratch_table(_lib.LIB_PATH, str(tmp_path))
+    assert len(table) > 300
+    over = {k: v for k, v in table.items() if v[0] > SCRATCH_ALLOWED.get(k, 0)}
+    assert not over, over
+    stale = {k: lim for k, lim in SCRATCH_ALLOWED.items() if k not in table}
+    assert not stale, ("allow-list entries without a kernel (renamed or gone: delete them)", stale)
+    # no 256 x 256 conv tiles in the product (they spill 900-1500 VGPRs and no automatic rule selects them)
+    assert not [k for k in table if k.startswith("conv_gemm_glds_kernel<256, 256")]

@@ -44,8 +44,9 @@ def _smooth(shape, seed):
 
 
 def _close(got, ref, tol=TOL):
-    """fp32 bar, scaled per sample by the magnitude of what is compared: random-weight EfficientNets amplify a few inputs by
-    two orders of magnitude (26 blocks of swish + SE + identity with random BN gains), and fp32 rounding scales with that."""
+    """A RELATIVE fp32 bar: |got - ref| < tol x max(1, max |ref| of the SAMPLE) -- scaled per sample by the magnitude of what is
+    compared, not an absolute 1e-3: random-weight EfficientNets amplify a few inputs by two orders of magnitude (26 blocks of swish +
+    SE + identity with random BN gains), and fp32 rounding scales with that.  Returns (ok, worst relative error)."""
     n = ref.shape[0]
     scale = ref.reshape(n, -1).abs().amax(1).clamp(min=1.0)
     err = (got - ref).reshape(n, -1).abs().amax(1)
@@ -300,7 +301,7 @@ def test_b3_whole_block_kernels_equal_the_four_launch_plan(dev, size, image_size
     depthwise out of the accumulators -> in-block squeeze-and-excite -> gated project) against the four-launch plan, at every
     block boundary behind a fused block and at the pooled features.  Every stored value comes from the same arithmetic with the
     same fp16 roundings; the squeeze adds its pixels in another order, which can move a gated value across an fp16 rounding
-    boundary: agreement to a few fp16 ulps.  144^2 (config 5): blocks 9-17 on 9 x 9 and 19-25 on 5 x 5 maps; the other sizes /
+    boundary: agreement to a few fp16 ulps.  144^2 (config 5): blocks 9-17 on 9 x 9 and 19-24 on 5 x 5 maps (block 25, hid 2304, keeps the four-launch plan); the other sizes /
     padding rules put 3 x 3 ... 8 x 8 maps under the kernel (native padding at 100^2: 6 x 6 and 3 x 3; at 75^2: 9 x 9 for blocks
     6-7 and 4 x 4; dynamic padding at 100^2: 7 x 7 and 4 x 4; at 75^2: 5 x 5 and 3 x 3; at 128^2: 8 x 8 and 4 x 4); n = 5 leaves a
     ragged last image pair where a workgroup owns two images."""
@@ -317,8 +318,7 @@ def test_b3_whole_block_kernels_equal_the_four_launch_plan(dev, size, image_size
         plain = [m.engine().forward_blocks(x4, k).float().clone() for k in cuts] + [m.features_nhwc4(x4).clone()]
     for k, f, p in zip(cuts + ("features",), fused, plain):
         assert f.shape == p.shape
-        if True:
-            assert (f - p).abs().max().item() <= 4e-3 * max(1.0, float(p.abs().max())), (size, k, (f - p).abs().max().item())
+        assert (f - p).abs().max().item() <= 4e-3 * max(1.0, float(p.abs().max())), (size, k, (f - p).abs().max().item())
     m32, _ = _net(dev, "efficientnet-b3", 200, dtype="f32")
     assert m32.engine().whole_blocks(size) == 0          # fp32 storage keeps the four-launch plan
 
@@ -485,4 +485,4 @@ def test_config5_efficientnet_b3_t16_p144_end_to_end(dev, R):
     rell = ((lg16 - rl).pow(2).mean().sqrt() / rl.pow(2).mean().sqrt()).item()
     print("config 5 (EfficientNet-B3, T=16, P=144): fp16 storage rel rms local features %.2e, logits %.2e, max |dlogit| %.2e"
           % (relf, rell, (lg16 - rl).abs().max().item()))
-    assert relf < 3e-2 and rell < 3e-2
+    assert relf < 2e-3 and rell < 2e-3        # measured 1.4e-4 .. 4e-4 (bench.py `also.config5...`): a 10x regression fails

@@ -196,8 +196,8 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 32, 33, 34, 37, 38, 39,
-                                  40, 41, 42, 43, 44, 45, 46, 47, 51, 52, 53, 54, 71, 72, 73, 74])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 31, 32, 33, 34, 38, 39,
+                                  40, 41, 42, 43, 44, 45, 46, 51, 52, 53, 54, 71, 72, 73, 74])
 def test_conv_engine_vs_oracle(dev, ops, O, tile):
     for i, (n, h, w, cin, cout, k, s, pad, act, res, tsm) in enumerate(CONV_CASES):
         got, naive, ref = _conv_case(O, ops, dev, n, h, w, cin, cout, k, s, pad, act, res, tile, tsm, seed=i,
@@ -211,7 +211,7 @@ def test_conv_engine_vs_oracle(dev, ops, O, tile):
 
 def test_conv_tiles_bit_identical(dev, ops, O):
     """Every tile shape walks K in the same order, so results must not depend on the tile."""
-    outs = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 32, 33, 34, 37, 38, 39, 71, 72, 73, 74)]
+    outs = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 31, 32, 33, 34, 38, 39, 71, 72, 73, 74)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 
@@ -365,7 +365,7 @@ def test_resnet50_featmap_unpooled_vs_oracle(dev, O, p, tsm):
     assert fmap.shape == ref.shape and fmap.shape[1] == 2048
     err = (fmap.cpu() - ref).abs().max().item()
     assert err < 3e-4 * max(1.0, ref.abs().max().item()), err
-    assert (fmap.mean(dim=(2, 3)) - pooled.view(n, -1)).abs().max().item() < 1e-5
+    assert (fmap.mean(dim=(2, 3)) - pooled.view(n, -1)).abs().max().item() < 1e-5 * max(1.0, pooled.abs().max().item())    # (torch's mean sums in another order)
 
 
 @pytest.mark.parametrize("p,tsm", [(96, 0), (128, 8), (100, 0)])

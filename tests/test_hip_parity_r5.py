@@ -193,3 +193,69 @@ def test_sth_shipped_glancer_and_focuser_in_one_model_forward(dev, O):
         out = m(input=fo.to(dev), scan=gl.to(dev))
     assert out.shape == (2, 174)
     assert np.abs(out.cpu().numpy() - g["logits"]).max() < TOL
+
+
+def test_shift_place_block_golden_and_oracle(dev, O):
+    """shift_place = 'block' (STH/ops/temporal_shift.py:104-121: TemporalShift around whole Bottlenecks -- conv1, the downsample conv and
+    the identity read the shifted block input) on the HIP trunk (adaf_resnet50_set_shift_place): the reference's own features (G14),
+    and against the oracle at 12 segments / 144^2 where every fused launch form is in play."""
+    from adafocus_amd.tsn import TSN
+    from tests.helpers import rnd
+    g = golden("g14_sth_block_shift")
+    net = TSN(4, base_model="resnet50", is_shift=True, shift_div=8, shift_place="block")
+    net.base_model = torch.nn.Sequential(*list(net.base_model.children())[:-1])         # STH/evaluate.py:83
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 1414).items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().to(dev)
+    with torch.no_grad():
+        got = net(rnd((8, 3, 64, 64), 141).to(dev), no_reshape=True).cpu()
+    assert np.abs(got.numpy() - g["feat"]).max() < 3e-4 * max(1.0, float(np.abs(g["feat"]).max()))
+    # 12 segments, 144^2, 24 patches; the same weights under 'blockres' give a different network
+    csd = O.canonical_resnet_keys({"n." + k: v for k, v in sd.items()}, "n.base_model.")
+    net.num_segments = net.base_model.tsm_segments = TF
+    x = rnd((2 * TF, 3, P, P), 142)
+    with torch.no_grad():
+        got = net(x.to(dev), no_reshape=True).cpu()
+        ref = O.resnet50_trunk(csd, "n.base_model.", x, TF, 8, shift_place="block").flatten(1)
+        net.base_model.tsm_place = "blockres"
+        res = net(x.to(dev), no_reshape=True).cpu()
+        ref_res = O.resnet50_trunk(csd, "n.base_model.", x, TF, 8).flatten(1)
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 3e-4 * scale
+    assert (res - ref_res).abs().max().item() < 3e-4 * scale
+    assert (got - res).abs().max().item() > 1e-2
+
+
+@pytest.mark.parametrize("b,t", [(33, 16), (64, 16), (65, 4), (200, 2)])
+def test_gru_scan_two_slices_bit_identical_to_one(dev, b, t):
+    """The persistent GRU scan cuts a batch of more than one m-tile into two slices, each scanned by its own 128 blocks with its own
+    barrier words (option gru_scan_slices, the default since round 4).  Clips are independent: every logit and every hidden state is
+    torch.equal to the single-slice scan -- with the folded classifier, with an initial state, and through the cooperative launch."""
+    from adafocus_amd import _lib, hip_ops as ops
+    from tests.helpers import rnd
+    gen = {"gru.weight_ih_l0": (3072, 3328), "gru.weight_hh_l0": (3072, 1024), "gru.bias_ih_l0": (3072,), "gru.bias_hh_l0": (3072,),
+           "fc.weight": (200, 1024), "fc.bias": (200,)}
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_state_dict(gen, 606).items()}
+    args = (d["gru.weight_ih_l0"], d["gru.weight_hh_l0"], d["gru.bias_ih_l0"], d["gru.bias_hh_l0"], d["fc.weight"], d["fc.bias"])
+    seq_args = (d["gru.weight_ih_l0"][:, :1024].contiguous(),) + args[1:4]
+    x = rnd((b, t, 3328), 500 + b, 0.5).to(dev)
+    xs = rnd((b, t, 1024), 600 + b, 0.5).to(dev)
+    h0 = rnd((b, 1024), 700 + b, 0.5).to(dev)
+    out = {}
+    try:
+        for mode in (1, 2):
+            ops.set_gru_persistent(mode, dev)
+            for slices in (1, 2):
+                with _lib.option("gru_scan_slices", slices):
+                    lg, last = [v.clone() for v in ops.gru_cls_forward(x, *args)]
+                    hs = ops.gru_seq_forward(xs, *seq_args, h0=h0).clone()
+                out[(mode, slices)] = (lg, last, hs)
+    finally:
+        ops.set_gru_persistent(1, dev)
+    ref = out[(1, 1)]
+    assert torch.isfinite(ref[0]).all() and torch.isfinite(ref[2]).all()
+    for key, val in out.items():
+        for a_, b_ in zip(ref, val):
+            assert torch.equal(a_, b_), key
+    assert ops.gru_scan_timeouts(dev) == 0

@@ -158,3 +158,31 @@ def test_policy_fixtures_carry_their_decision_margins():
             _, hid, gap = O.policy_act_discrete(sd, "focuser.policy.policy_old.", fm[:, s], hid, return_gap=True)
             gaps.append(gap.numpy())
     np.testing.assert_allclose(np.stack(gaps, 1), golden("g7_act_e2e")["policy_argmax_gap"], rtol=0, atol=2e-4)
+
+
+def _block_shift_tsn():
+    from adafocus_amd.tsn import TSN
+    net = TSN(4, base_model="resnet50", is_shift=True, shift_div=8, shift_place="block")
+    full_keys = sorted(net.state_dict())
+    net.base_model = torch.nn.Sequential(*list(net.base_model.children())[:-1])         # STH/evaluate.py:83
+    return net, full_keys
+
+
+def test_g14_shift_place_block():
+    """shift_place = 'block' (STH/ops/temporal_shift.py:104-121): TemporalShift around every whole Bottleneck.  The host mirror carries
+    the reference's state-dict keys for that placement (full and fc-stripped), and the oracle's trunk with the shift in front of the
+    block (identity and downsample included) reproduces the reference's features."""
+    g = golden("g14_sth_block_shift")
+    net, full_keys = _block_shift_tsn()
+    assert full_keys == g["keys_full"].tolist()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert sorted(shapes) == g["keys_stripped"].tolist()
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 1414).items()}
+    net.load_state_dict(sd, strict=True)                                                 # the stripped spelling loads
+    csd = O.canonical_resnet_keys({"n." + k: v for k, v in sd.items()}, "n.base_model.")
+    x = rnd((8, 3, 64, 64), 141)
+    with torch.no_grad():
+        feat = O.resnet50_trunk(csd, "n.base_model.", x, 4, 8, shift_place="block").flatten(1)
+        other = O.resnet50_trunk(csd, "n.base_model.", x, 4, 8, shift_place="blockres").flatten(1)
+    np.testing.assert_allclose(feat.numpy(), g["feat"], rtol=1e-4, atol=1e-4)
+    assert (other - feat).abs().max().item() > 1e-2            # the two placements are different networks

@@ -1,0 +1,16 @@
+#!/bin/sh
+# Experiment build: the product library plus the 256 x 256 block tiles of the conv engine (tile ids 27 / 37 / 47:
+# conv_gemm_glds_kernel<256,256,2,4,...>, eight waves of 128x64).  They reach 140.6 TF on an 8192^2 x 4096 GEMM but spill
+# 900-1500 VGPRs in every other instantiation and no automatic rule ever selects them, so the product Makefile leaves them out
+# (VERDICT r4).  Writes adafocus_amd/csrc/libadafocus_hip_exp.so; point ADAF_LIB at it:  ADAF_LIB=.../libadafocus_hip_exp.so python tools/conv_probe.py
+set -e
+cd "$(dirname "$0")/../../adafocus_amd/csrc"
+mkdir -p exp_build
+for f in api conv_gemm conv_lat crop misc_ops mobilenetv2 mbconv gru_scan stem effnet mbconv_whole; do
+  extra=""
+  case $f in mbconv_whole|effnet) extra="-fno-slp-vectorize";; esac
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-inline-asm -DADAF_EXP_TILES $extra -c $f.hip -o exp_build/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC exp_build/*.o -o libadafocus_hip_exp.so
+echo built libadafocus_hip_exp.so

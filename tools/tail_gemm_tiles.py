@@ -16,7 +16,7 @@ def timeit(fn, iters=10):
 cases = [("b8 expand", 14, 64, 384, False, ops.ACT_RELU6), ("b8 project", 14, 384, 64, True, ops.ACT_NONE), ("b12 expand", 14, 96, 576, False, ops.ACT_RELU6),
          ("b12 project", 14, 576, 96, True, ops.ACT_NONE), ("b15 expand", 7, 160, 960, False, ops.ACT_RELU6), ("b15 project", 7, 960, 160, True, ops.ACT_NONE),
          ("b17 project", 7, 960, 320, False, ops.ACT_NONE), ("head", 7, 320, 1280, False, ops.ACT_RELU6)]
-tiles = [0, 31, 32, 33, 34, 37, 38, 39, 71, 72, 73, 74, 21, 22, 23, 25, 26, 27]
+tiles = [0, 31, 32, 33, 34, 38, 39, 71, 72, 73, 74, 21, 22, 23, 25, 26]      # (27 / 37: tools/exp/build_exp_tiles.sh)
 for name, hw, k, cout, res, act in cases:
     x = torch.randn((n, hw, hw, k), device=dev); w = torch.randn((cout, 1, 1, k), device=dev) * 0.05
     sc, bi = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
