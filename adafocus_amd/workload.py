@@ -123,6 +123,26 @@ def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_bl
     return 4 * elems
 
 
+def mobilenetv2_block_bytes_per_frame(size=224, elem=4):
+    """BLOCK-LEVEL algorithmic bytes per frame of the glancer (the denominator config 5 uses, effnet_block_bytes_per_frame): the frame
+    (3 channels, fp32) read once, every tensor that crosses a block boundary (stem -> b1 -> ... -> b17 -> head) written once and read
+    once in the storage type, the identity re-read where a block has one, the 1280-channel map written (it is the policy's input) and
+    the mean-pooled vector written (fp32); nothing inside a block (expanded map, depthwise output) and no parameters.  9.1 MB for 224^2
+    frames in fp32 storage -- what a perfectly fused network would move (5.2 MB in fp16 storage); the launch plan that runs moves 22.2 MB
+    (mobilenetv2_bytes_per_frame) and the counters see 25.9 MB (profiles/r4_glancer_traffic.json)."""
+    hw = _out(size, 3, 2, 1)
+    b_ = size * size * 3 * 4 + hw * hw * 32 * elem                      # frame in, stem out
+    last = None
+    for b in _mbv2_blocks(size):
+        b_ += (b["hw"] ** 2 * b["inp"] + b["ohw"] ** 2 * b["oup"]) * elem
+        if b["stride"] == 1 and b["inp"] == b["oup"]:
+            b_ += b["ohw"] ** 2 * b["oup"] * elem                          # identity rows
+        last = b
+    ohw = last["ohw"] ** 2
+    b_ += ohw * last["oup"] * elem + ohw * 1280 * 4 + 1280 * 4             # head in, map out (fp32: the policy reads it), pooled vector
+    return b_
+
+
 # ---- EfficientNet (BASELINE config 5; csrc/effnet.hip) -----------------------------------------------------------------
 # efficientnet_pytorch utils.py: (width, depth) per model; blocks_args (repeats, kernel, stride, expand, in, out)
 _EFF_PARAMS = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b1": (1.0, 1.1), "efficientnet-b2": (1.1, 1.2), "efficientnet-b3": (1.2, 1.4),

@@ -313,3 +313,148 @@ def latency_rows(dev, cases=((1, 8), (2, 8), (2, 16)), p=96, iters=200):
                     "(csrc/conv_lat.hip: v_mfma_f32_16x16x4_f32 chains in the engine's k order), batched_tiles_only_ms = the same step "
                     "with that switched off (adaf_resnet50_set_latency_rows(net, 0))" % iters)
     return rows
+
+
+def _events_ms(fn, iters=5, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, out
+
+
+def glancer_f16_row(dev, model, b, t, streams):
+    """Rows a10 / f2: the glancer with fp16 STORAGE of activations and 1x1 weights (adaf_mobilenetv2_set_dtype: MFMA products on the
+    f16 pipe with fp32 accumulation, depthwise taps in fp32 from fp16 maps) -- what the switch buys (ms per B*T frames) and what it
+    costs end to end on BASELINE config 1 / the headline (ActivityNet model: how many of the policy's arg-max choices survive, max |dlogit|)
+    and config 4 (Something-Something: crop origin shift in pixels, max |dlogit|).  Random-init weights amplify a perturbation ~1000x
+    through the 52 layers (tests/test_hip_parity_r2.py::test_mobilenetv2_f16_storage_vs_g5_golden), so the cost shown is a worst case."""
+    from adafocus_amd import synth
+    from adafocus_amd.gfv_net_sth import GFV as GFV_STH
+    from adafocus_amd.transforms import ingest_uint8
+    out = {}
+    eng = model.glancer.net._engine
+    u8 = torch.randint(0, 256, (b, 224, 224, t * 3), device=dev, dtype=torch.uint8)
+    with torch.no_grad():
+        fr4 = ingest_uint8(u8, t)
+        ms32, _ = _events_ms(lambda: model.glancer.net.features_from_nhwc4(fr4), 3)
+        lg32, _, _, idx32 = [v.clone() if torch.is_tensor(v) else v for v in model.offline_forward_nhwc4(fr4, b, t)]
+        full32, _ = _events_ms(lambda: model.offline_forward_nhwc4(fr4, b, t), 3)
+        eng.dtype = "f16"
+        try:
+            ms16, _ = _events_ms(lambda: model.glancer.net.features_from_nhwc4(fr4), 3)
+            lg16, _, _, idx16 = [v.clone() if torch.is_tensor(v) else v for v in model.offline_forward_nhwc4(fr4, b, t)]
+            full16, _ = _events_ms(lambda: model.offline_forward_nhwc4(fr4, b, t), 3)
+        finally:
+            eng.dtype = "f32"
+            model.glancer.net.features_from_nhwc4(fr4[:t])            # re-sync the fp32 plan
+    same = (idx16 == idx32)
+    clip_same = same.view(b, t).all(1)
+    lg32v, lg16v = lg32.view(b, t, -1), lg16.view(b, t, -1)
+    out["act_T%d_P%d" % (t, model.patch_size)] = {
+        "glancer_ms_f32": round(ms32, 3), "glancer_ms_f16_storage": round(ms16, 3), "speedup": round(ms32 / ms16, 3),
+        "full_forward_clips_per_s_f32": round(b / full32 * 1e3, 1), "full_forward_clips_per_s_f16_glancer": round(b / full16 * 1e3, 1),
+        "policy_argmax_agreement": round(float(same.float().mean()), 4), "clips_with_all_actions_equal": int(clip_same.sum()),
+        "max_abs_logit_diff": float((lg16 - lg32).abs().max()),
+        "max_abs_logit_diff_clips_with_equal_actions": float((lg16v[clip_same] - lg32v[clip_same]).abs().max()) if bool(clip_same.any()) else None,
+        "logit_scale": float(lg32.abs().max())}
+    del u8, fr4
+    # config 4: Something-Something (TSM glancer, continuous policy; the glancer's logits are ADDED to the output)
+    a = sth_args(b, 8, 128)
+    m = GFV_STH(a).eval()
+    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])
+    m.load_state_dict(synth_model_state(m, 1007), strict=True)
+    m = m.to(dev)
+    gu = torch.randint(0, 256, (b, 224, 224, 24), dtype=torch.uint8, device=dev)
+    fu = torch.randint(0, 256, (b, 224, 224, 24), dtype=torch.uint8, device=dev)
+
+    def fwd():
+        g4 = ingest_uint8(gu, 8, m.input_mean, m.input_std)
+        f4 = ingest_uint8(fu, 8, m.input_mean, m.input_std)
+        fm4, glog = m.glance_nhwc4(g4, b)
+        act = m.focuser.policy.policy_old.act_nhwc(fm4, b, 8)
+        return m.action_stage2_nhwc4(f4, fm4, glog, 0, a, with_baseline=False)[0], act
+    with torch.no_grad():
+        g4 = ingest_uint8(gu, 8, m.input_mean, m.input_std)
+        s32, _ = _events_ms(lambda: m.glance_nhwc4(g4, b), 3)
+        p32, a32 = [v.clone() for v in fwd()]
+        m.glancer.net._engine.dtype = "f16"
+        s16, _ = _events_ms(lambda: m.glance_nhwc4(g4, b), 3)
+        p16, a16 = [v.clone() for v in fwd()]
+        m.glancer.net._engine.dtype = "f32"
+    px = ((a16 - a32).abs() * (224 - 128))
+    same_origin = (torch.floor(a16 * 96) == torch.floor(a32 * 96)).all(1)
+    out["sth_T8_P128"] = {"glancer_ms_f32": round(s32, 3), "glancer_ms_f16_storage": round(s16, 3), "speedup": round(s32 / s16, 3),
+                          "max_action_shift_px": float(px.max()), "clips_with_equal_crop_origin": int(same_origin.sum()), "clips": b,
+                          "max_abs_logit_diff": float((p16 - p32).abs().max()),
+                          "max_abs_logit_diff_clips_with_equal_origin": float((p16[same_origin] - p32[same_origin]).abs().max()) if bool(same_origin.any()) else None,
+                          "logit_scale": float(p32.abs().max())}
+    out["note"] = ("adaf_mobilenetv2_set_dtype(f16): activations and 1x1 weights stored in fp16 (fp32 accumulation, fp32 depthwise arithmetic); the "
+                   "local CNN, policy and classifier stay fp32.  Random-init weights: a worst case for the cost columns (DESIGN 3.4)")
+    return out
+
+
+def split_bf16_row(dev, model, frames, gvec, actions, b, t, p, streams, steps, step_fn):
+    """`also.split_bf16`: the SAME hot path with the local CNN's convolutions on the bf16 matrix pipe -- every fp32 operand split
+    exactly into three bf16 parts, the six products of magnitude >= 2^-24 |xy| accumulated in fp32 (ADAF_MATH_F32_SPLIT_BF16;
+    include/adafocus.h).  NOT the reported configuration (`value` stays on the exact fp32 pipe).  Roofline: the work priced is what the
+    pipe actually executes -- 6 x the algorithmic FLOP -- against the dense bf16 MFMA peak (2.5 PFLOP/s); pricing the algorithmic FLOP
+    against the fp32 peak would read > 1."""
+    from adafocus_amd import workload
+    from adafocus_amd.utils import get_patch_nhwc4
+    net = model.focuser.net
+    with torch.no_grad():
+        ref_logits = model.hot_path(frames, gvec, actions, b, t)[0].clone()
+        x4 = get_patch_nhwc4(frames, actions, p)
+        feat32 = net.features_nhwc4(x4).clone()
+        net.set_math("split_bf16")
+        try:
+            alt_logits = model.hot_path(frames, gvec, actions, b, t)[0].clone()
+            feat_sp = net.features_nhwc4(x4).clone()
+            for i in range(2 * len(streams)):
+                step_fn(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(steps):
+                step_fn(i)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / steps
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                for i in range(steps):
+                    model.hot_path(frames, gvec, actions, b, t)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / steps
+            trunk = net._sync()
+            trunk.forward(x4)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                trunk.forward(x4)
+            e1.record()
+            torch.cuda.synchronize()
+            trunk_ms = e0.elapsed_time(e1) / 3
+        finally:
+            net.set_math("f32")
+    # error against fp64 of both pipes on a sample of patches (the oracle-free statement: which pipe is closer to exact arithmetic)
+    alg_flop = 2.0 * workload.resnet50_macs_per_patch(p) * b * t
+    stem_flop = 2.0 * (p // 2) ** 2 * 64 * 147 * b * t            # the stem keeps the fp32 pipe
+    pipe_flop = 6.0 * (alg_flop - stem_flop)
+    ach = pipe_flop / (trunk_ms * 1e-3) / 1e12
+    return {"clips_per_s": round(b / dt, 1), "ms_per_step": round(dt * 1e3, 3), "streams": len(streams), "steps": steps,
+            "serial": {"clips_per_s": round(b / dts, 1), "ms_per_step": round(dts * 1e3, 3)},
+            "max_abs_logit_diff_vs_f32": float((alt_logits - ref_logits).abs().max()),
+            "max_abs_feature_diff_vs_f32": float((feat_sp - feat32).abs().max()), "feature_scale": float(feat32.abs().max()),
+            "roofline": {"bound": "mfma", "pipe": "bf16 (v_mfma_f32_32x32x16_bf16), fp32 accumulate", "achieved": round(ach, 1), "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "trunk_ms": round(trunk_ms, 3),
+                         "work_is": "6 bf16 products per algorithmic multiply-add of the non-stem convs (the stem stays on the fp32 pipe)",
+                         "algorithmic_tflops": round(alg_flop / (trunk_ms * 1e-3) / 1e12, 1),
+                         "note": "the algorithmic rate exceeds what the fp32 pipe can do at all (157.3 TF) when it reads > 157"},
+            "note": "ADAF_MATH_F32_SPLIT_BF16 (opt-in; ResNet.set_math('split_bf16')): fp32 in, fp32 out, fp32 accumulate; every GPU parity module "
+                    "also runs in this mode (tests/conftest.py trunk_math)"}
