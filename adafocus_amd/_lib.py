@@ -26,7 +26,7 @@ SYMBOLS = (
     "adaf_fold_bn_f32", "adaf_maxpool3x3s2_f32", "adaf_global_avgpool_f32", "adaf_temporal_shift_f32",
     "adaf_resnet50_create", "adaf_resnet50_destroy", "adaf_resnet50_set_param", "adaf_resnet50_finalize",
     "adaf_resnet50_workspace_bytes", "adaf_resnet50_forward", "adaf_resnet50_map_size", "adaf_resnet50_forward_map", "adaf_resnet50_launch_count",
-    "adaf_resnet50_forward_profiled", "adaf_resnet50_set_tiles", "adaf_resnet50_set_math", "adaf_resnet50_set_fusion", "adaf_resnet50_set_latency_rows", "adaf_resnet50_set_shift_place", "adaf_gru_cls_workspace_bytes",
+    "adaf_resnet50_forward_profiled", "adaf_resnet50_set_tiles", "adaf_resnet50_set_math", "adaf_resnet50_set_fusion", "adaf_resnet50_set_latency_rows", "adaf_resnet50_set_shift_place", "adaf_resnet50_forward_frames", "adaf_gru_cls_workspace_bytes",
     "adaf_gru_cls_forward_f32", "adaf_fc_meanpool_forward_f32", "adaf_copy2d_f32",
     "adaf_pack_dw_weight_f32", "adaf_dwconv3x3_bn_act_f32", "adaf_mobilenetv2_create", "adaf_mobilenetv2_destroy",
     "adaf_mobilenetv2_set_param", "adaf_mobilenetv2_finalize", "adaf_mobilenetv2_workspace_bytes",
@@ -87,6 +87,7 @@ def load_library():
     lib.adaf_resnet50_workspace_bytes.restype = C.c_size_t
     lib.adaf_resnet50_workspace_bytes.argtypes = [vp, ip, ip]
     lib.adaf_resnet50_forward.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, vp, C.c_size_t, vp]
+    lib.adaf_resnet50_forward_frames.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, ip, ip, vp, ip, vp, C.c_size_t, vp]
     lib.adaf_resnet50_map_size.argtypes = [ip]
     lib.adaf_resnet50_forward_map.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, C.c_size_t, vp]
     lib.adaf_resnet50_launch_count.argtypes = [vp]

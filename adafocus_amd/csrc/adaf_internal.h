@@ -41,6 +41,7 @@ struct AdafOptions {
     unsigned effnet_plan = 63u;   // "effnet_plan": ADAF_EF_PLAN_* bits
     unsigned effnet_fused_blocks = 0xffffffffu;   // "effnet_fused_blocks": MBConv blocks (bit = block index) the fused expand + depthwise launch may take
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
+    int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)
     int gru_scan_slices = 2;      // "gru_scan_slices": clip slices a persistent GRU scan may be cut into (1 | 2; gru_scan.hip)
 };
 AdafOptions& adaf_options();
@@ -207,6 +208,10 @@ void adaf_launch_pack_stem_weight(const float* w_oihw, float* wr, hipStream_t s)
 size_t adaf_stem_weight_floats();
 void adaf_launch_stem7x7(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
                          int cus, hipStream_t s);
+bool adaf_stem7x7_rows_ok(int P, int n, int cus);   // the strip-walking stem + pool kernel exists for this patch size and there are enough images to fill the device
+// the same launch gathering its own windows from planar frames [n, 3, H, W] at floor(action * (H - P)) (get_patch folded in); false = not available
+bool adaf_launch_stem7x7_pool_frames(const float* frames, bool pixel_major, int nframes, const float* act, int fpa, int H, int W, int n, int P,
+                                     const float* wr, const float* scale, const float* bias, float* out, int cus, hipStream_t s);
 bool adaf_stem7x7_pool_pays(int P);     // does the fused stem + max-pool launch beat the two separate ones at this patch size
 void adaf_launch_stem7x7_pool(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
                               int cus, hipStream_t s);

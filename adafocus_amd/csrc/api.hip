@@ -80,7 +80,7 @@ struct OptKey { const char* name; int kind; double lo, hi; };      // kind: inde
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
                            {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 63}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
-                           {"effnet_fused_blocks", 12, 0, 4294967295.0}};
+                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
     for (const OptKey& k : kOptKeys)
@@ -163,6 +163,7 @@ int adaf_set_option(adaf_handle* h, const char* key, double value) {
         case 9: o.effnet_plan = (unsigned)value; break;
         case 11: o.gru_scan_slices = (int)value; break;
         case 12: o.effnet_fused_blocks = (unsigned)value; break;
+        case 13: o.stem_rows = (int)value; break;
         default: o.effnet_chunk = (int)value; break;
     }
     return ADAF_OK;
@@ -185,6 +186,7 @@ double adaf_get_option(const char* key) {
         case 9: return o.effnet_plan;
         case 11: return o.gru_scan_slices;
         case 12: return o.effnet_fused_blocks;
+        case 13: return o.stem_rows;
         default: return o.effnet_chunk;
     }
 }
@@ -521,10 +523,21 @@ struct Launch {   // one enqueued kernel of the forward pass, for the profiler
     int tile;
 };
 
+// Where the trunk's patches come from when the stem gathers them itself (adaf_resnet50_forward_frames)
+struct FrameSrc {
+    const float* frames;    // [nframes, 3, H, W] planar or [nframes, H, W, 4] pixel-major
+    bool pixel_major;
+    int nframes, H, W;
+    const float* act;       // [n / fpa, 2] fp32 (y, x)
+    int fpa;
+};
+
 // Walks the trunk; `rec` (optional) gets one hipEvent before each launch plus one at the end.
 int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int tsm_div, float* feat, int ldfeat,
-              void* ws, size_t ws_bytes, hipStream_t st, std::vector<hipEvent_t>* rec, std::vector<Launch>* info, float* featmap = nullptr) {
+              void* ws, size_t ws_bytes, hipStream_t st, std::vector<hipEvent_t>* rec, std::vector<Launch>* info, float* featmap = nullptr,
+              const FrameSrc* src = nullptr) {
     adaf_handle* h = net->h;
+    if (src) x4 = src->frames;
     if (!net->finalized) return fail(h, ADAF_E_STATE, "resnet50: finalize() has not been called");
     if (!x4 || !feat || !ws) return fail(h, ADAF_E_BADARG, "resnet50: null pointer");
     if (n <= 0 || P < 32) return fail(h, ADAF_E_BADARG, "resnet50: need n > 0 and patch >= 32");
@@ -586,8 +599,35 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     };
 
     int hh, ww, rc;
+    bool gathered = false;
+    if (src) {
+        // the patches are windows of resident frames at floor(action * (H - P)) (get_patch, ACT/models/utils.py:37-51).  The strip-walking
+        // stem kernel gathers them itself -- no gather launch, no patch tensor; where it does not apply (other patch sizes, small batches,
+        // fusion off, a stem tile override) the gather runs into a free workspace slab first: same values either way.
+        if (net->tiles[0] == 0 && net->fuse && adaf_stem7x7_rows_ok(P, n, h->cus)) {
+            const ConvLayer& L = net->convs[0];
+            const int oh = conv_out(P, 7, 2, 3), ph = conv_out(oh, 3, 2, 1);
+            mark(2.0 * (double)n * oh * oh * 64 * 147, 4.0 * ((double)n * P * P * 3 + (double)n * ph * ph * 64 + 64.0 * 147), 94);
+            gathered = adaf_launch_stem7x7_pool_frames(src->frames, src->pixel_major, src->nframes, src->act, src->fpa, src->H, src->W, n, P,
+                                                       net->stem_w, L.scale, L.bias, buf[1], h->cus, st);
+            if (gathered) { ++li; hh = ww = ph; }
+            else if (rec) info->pop_back();
+        }
+        if (!gathered) {
+            mark(0.0, 4.0 * 2.0 * (double)n * P * P * 3, 0);
+            for (int g = 0; g * src->nframes < n; ++g) {      // one gather per action set over the same frames
+                const float* act = src->act + (size_t)g * (src->nframes / src->fpa) * 2;
+                float* dst = buf[2] + (size_t)g * src->nframes * P * P * 4;
+                if (src->pixel_major) adaf_launch_crop_nhwc4(src->frames, src->nframes, src->H, src->W, act, src->fpa, P, dst, nullptr, st);
+                else if (adaf_launch_crop(src->frames, src->nframes, 3, src->H, src->W, act, src->fpa, P, dst, ADAF_LAYOUT_NHWC4, nullptr, st) != hipSuccess)
+                    return fail(h, ADAF_E_LAUNCH, "resnet50: gather launch");
+            }
+            x4 = buf[2];
+        }
+    }
     // stem: conv7x7 s2 + BN + ReLU -> maxpool 3x3 s2
-    if (net->tiles[0] == 0 && net->fuse && (adaf_stem7x7_pool_pays(P) || net->fuse_stem_always)) {   // both in one launch: the conv map never reaches HBM
+    if (gathered) {
+    } else if (net->tiles[0] == 0 && net->fuse && (adaf_stem7x7_pool_pays(P) || adaf_stem7x7_rows_ok(P, n, h->cus) || net->fuse_stem_always)) {   // both in one launch: the conv map never reaches HBM
         const ConvLayer& L = net->convs[0];
         hh = ww = conv_out(P, 7, 2, 3);
         const int ph = conv_out(hh, 3, 2, 1);
@@ -846,6 +886,26 @@ int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n,
     if (!net) return ADAF_E_BADARG;
     return run_trunk(net, patches_nhwc4, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream,
                      nullptr, nullptr);
+}
+
+int adaf_resnet50_forward_frames(adaf_resnet50* net, const float* frames, int frames_layout, int n_frames, int height, int width,
+                                 const float* action_yx, int n_actions, int frames_per_action, int patch, int tsm_segments, int tsm_div,
+                                 float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream) {
+    if (!net) return ADAF_E_BADARG;
+    adaf_handle* h = net->h;
+    if (!frames || !action_yx || n_frames <= 0 || n_actions <= 0 || frames_per_action <= 0)
+        return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: null pointer or empty batch");
+    if (frames_layout != ADAF_LAYOUT_NCHW && frames_layout != ADAF_LAYOUT_NHWC4)
+        return fail(h, ADAF_E_LAYOUT, "resnet50 forward_frames: frames must be NCHW (3 planes) or NHWC4");
+    if (n_frames % frames_per_action) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: n_frames %% frames_per_action != 0");
+    const int per_set = n_frames / frames_per_action;
+    if (n_actions % per_set) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: n_actions=%d is not a multiple of n_frames / frames_per_action=%d", n_actions, per_set);
+    if (height != width) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: square frames only (get_patch scales both axes by H - P)");
+    if (patch > height || patch < 32) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: patch %d outside [32, %d]", patch, height);
+    if (!aligned16(frames)) return fail(h, ADAF_E_LAYOUT, "resnet50 forward_frames: frames must be 16-byte aligned");
+    FrameSrc src{frames, frames_layout == ADAF_LAYOUT_NHWC4, n_frames, height, width, action_yx, frames_per_action};
+    const int n = (n_actions / per_set) * n_frames;        // one patch per (action set, frame)
+    return run_trunk(net, frames, n, patch, tsm_segments, tsm_div, feat, ldfeat, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, &src);
 }
 
 int adaf_resnet50_map_size(int patch) {

@@ -38,7 +38,10 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 struct StemArgs {
-    const float* x;      // [n, P, P, 4]
+    const float* x;      // [n, P, P, 4] pixel-major patches -- or, with `act`, the planar frames [n, 3, H, W] the patches are cut from
+    const float* act;    // nullptr, or [n / fpa, 2] fp32 (y, x) actions: the stem gathers its own input windows (get_patch folded in)
+    int fpa, H, W;       // frames per action (1 = ActivityNet, T = Something-Something), frame size
+    int nframes;         // frames behind `x` (patch i is cut from frame i % nframes)
     const float* w;      // Wr [2][74][64]
     const float* scale;  // [64]
     const float* bias;
@@ -181,7 +184,8 @@ struct PoolCfg {
     static constexpr int WIN = RH * RP + 8;
     static constexpr int SIMG = NPIX * SPITCH;
     static constexpr int REGION = WIN > SIMG ? WIN : SIMG;            // the window and the staging image share LDS
-    static constexpr int WPE = (2 * NWV + 3) / 4;                     // waves per SIMD with two blocks resident on a CU
+    static constexpr int WPE = NWV >= 7 ? 3 : (2 * NWV + 3) / 4;      // waves per SIMD with two blocks resident on a CU (seven-wave blocks: 168 VGPRs
+                                                                      // instead of 128 + 6 spilled -- the tile form now only runs where blocks are scarce)
 };
 
 template <int TPH>
@@ -244,7 +248,7 @@ void stem7x7_pool_kernel(const StemArgs a) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        stem_mfma<C::RP, (C::WPE >= 4 ? 4 : 8)>(abase, bbase, h, acc0, acc1);
+        stem_mfma<C::RP, (C::WPE >= 4 ? 2 : 8)>(abase, bbase, h, acc0, acc1);     // (groups of 4 spilled 6 VGPRs under the 128-register cap of 4 waves per SIMD)
         __syncthreads();   // every wave is done reading the window: the staging image may overwrite it
 
 #pragma unroll
@@ -282,6 +286,186 @@ void stem7x7_pool_kernel(const StemArgs a) {
     }
 }
 
+// ---- conv + BN + ReLU + max-pool over whole-width strips walked down the image (round 5) ------------------------------------------
+// The tile form above recomputes a halo row and column per tile (13 x 17 conv outputs for 6 x 8 pooled ones: 1.17x the MFMA work) on
+// seven waves per block (3.5 per SIMD with two blocks resident: 12.5 % of the matrix pipe's time is a missing wave), and its phases run
+// in lockstep: MfmaUtil 0.61.  Here a block owns whole IMAGES: a strip is R conv rows of the full width (no column halo: column -1 is
+// outside the map), strips are walked top to bottom and the one conv row a pooling window shares with the previous strip travels in
+// REGISTERS: the thread that pooled the strip's last pooled row keeps the 3-column maxima of its bottom conv row and becomes the thread
+// of the next strip's first pooled row (pooled-row index rotated by the strip number).  So every conv pixel is computed exactly once
+// (R * OW = 32 * NW pixels: whole waves), the windows of strip s+1 are written to LDS while strip s pools (a separate buffer), the
+// fetch of strip s+2 is in flight behind both, and a wave starts the next strip's MFMAs as soon as ITS pooling is done -- four barriers
+// per strip, none between pooling and the next K walk.  Same k order, same BN / ReLU / max: bit-identical to the kernels above.
+// With `act` the block gathers its windows straight from the planar frames at the crop origin (the reference's get_patch,
+// ACT/models/utils.py:37-51, with crop.hip's exact coordinate arithmetic): no gather launch, no patch tensor.
+template <int OW, int R>
+struct RowsCfg {
+    static constexpr int NPX = R * OW;                 // conv pixels per strip
+    static constexpr int NW = NPX / 32;                // waves
+    static constexpr int NT = 64 * NW;
+    static constexpr int RW = 2 * OW + 5, RH = 2 * R + 5;   // staged input columns / rows
+    static constexpr int RP = RW * 3;
+    static constexpr int WPIX = RH * RW;
+    static constexpr int WPT = (WPIX + NT - 1) / NT;
+    static constexpr int SP = 36;                      // floats per pixel of the 32-channel staging image
+    static constexpr int WIN = (RH * RP + 3) & ~3;
+    static constexpr int SIMG = NPX * SP;
+    static constexpr int LDSF = 2 * KS * 64 + WIN + SIMG;
+    static constexpr int PW = OW / 2, PR = R / 2;      // pooled pixels per row, pooled rows per strip
+    static constexpr int NS = OW / R;                  // strips per image (square maps)
+    static constexpr int BPC = (LDSF * 4 + 1023) / 1024 * 1024 * 2 <= 160 * 1024 ? 2 : 1;
+    static constexpr int WPE = (BPC * NW + 3) / 4;
+    static_assert(NPX % 32 == 0 && OW % 2 == 0 && R % 2 == 0 && OW % R == 0 && PR * PW * 8 == NT, "strip geometry");
+};
+
+template <int OW, int R, int FR, int G = (RowsCfg<OW, R>::WPE >= 3 ? 4 : 8)>
+__global__ __launch_bounds__((RowsCfg<OW, R>::NT)) __attribute__((amdgpu_waves_per_eu((RowsCfg<OW, R>::WPE), (RowsCfg<OW, R>::WPE))))
+void stem7x7_pool_rows_kernel(const StemArgs a) {
+    using C = RowsCfg<OW, R>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;
+    float* reg = smem + 2 * KS * 64;
+    float* S = reg + C::WIN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * KS * 64 / 4; i += C::NT) reinterpret_cast<f32x4*>(Ws)[i] = reinterpret_cast<const f32x4*>(a.w)[i];
+
+    const int h = lane >> 5, li = lane & 31;
+    const int q = 32 * wave + li;                                // this lane's conv pixel of the strip (as an A row)
+    const float* abase = reg + ((2 * (q / OW)) * C::RW + 2 * (q % OW)) * 3;
+    const float* bbase = Ws + h * KS * 64 + li;
+    const float sc0 = a.scale[li], sc1 = a.scale[32 + li], bi0 = a.bias[li], bi1 = a.bias[32 + li];
+    // pooling role: (pooled row j, pooled column px, channel quad c4)
+    const int c4 = tid & 7, px = (tid >> 3) % C::PW, j = (tid >> 3) / C::PW;
+    const int xl = (2 * px > 0 ? 2 * px - 1 : 0) * C::SP + 4 * c4, xm = 2 * px * C::SP + 4 * c4, xr = (2 * px + 1) * C::SP + 4 * c4;
+
+    const int P = 2 * OW;
+    const int nimg = (a.n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // images of this block
+    const int nsteps = nimg * C::NS;
+    f32x4 win[C::WPT];
+    auto fetch = [&](int step) {
+        const int img = blockIdx.x + (step / C::NS) * gridDim.x, st = step % C::NS;
+        const int iy0 = 2 * R * st - 3;
+        const float* src;
+        if (FR) {
+            // the window origin of this patch: floor(action * (H - P)) for both axes (utils.py:40-42), clamped like crop_kernel; patch `img`
+            // is cut from frame img % nframes with action img / fpa (a second action set over the same frames: the reward baseline)
+            const int ai = img / a.fpa, fr = img % a.nframes;
+            const float span = (float)(a.H - P);
+            int y0 = (int)floorf(__fmul_rn(a.act[2 * ai], span)), x0 = (int)floorf(__fmul_rn(a.act[2 * ai + 1], span));
+            y0 = min(max(y0, 0), a.H - P); x0 = min(max(x0, 0), a.W - P);
+            src = FR == 1 ? a.x + ((size_t)fr * 3 * a.H + y0) * a.W + x0 : a.x + (((size_t)fr * a.H + y0) * a.W + x0) * 4;
+        } else {
+            src = a.x + (size_t)img * P * P * 4;
+        }
+#pragma unroll
+        for (int u = 0; u < C::WPT; ++u) {
+            const int idx = tid + C::NT * u;
+            const int r = idx / C::RW, c = idx - r * C::RW;
+            const int iy = iy0 + r, ix = c - 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < C::WPIX && (unsigned)iy < (unsigned)P && (unsigned)ix < (unsigned)P) {
+                if (FR == 1) {
+                    const float* p0 = src + (size_t)iy * a.W + ix;
+                    const size_t plane = (size_t)a.H * a.W;
+                    v.x = p0[0]; v.y = p0[plane]; v.z = p0[2 * plane];
+                } else if (FR == 2) {
+                    v = *reinterpret_cast<const f32x4*>(src + ((size_t)iy * a.W + ix) * 4);
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(src + ((size_t)iy * P + ix) * 4);
+                }
+            }
+            win[u] = v;
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int u = 0; u < C::WPT; ++u) {
+            const int idx = tid + C::NT * u;
+            if (idx < C::WPIX) {
+                float* d = reg + idx * 3;
+                d[0] = win[u].x; d[1] = win[u].y; d[2] = win[u].z;
+            }
+        }
+    };
+    if (nsteps <= 0) return;
+    fetch(0);
+    put();
+    if (nsteps > 1) fetch(1);
+    __syncthreads();
+
+    f32x4 carry[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int step = 0; step < nsteps; ++step) {
+        const int img = blockIdx.x + (step / C::NS) * gridDim.x, st = step % C::NS;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        stem_mfma<C::RP, G>(abase, bbase, h, acc0, acc1);
+        __syncthreads();   // every wave is done with this strip's window; last strip's pooling reads of S are done
+
+        const int je = (j + st) % C::PR;                            // this strip's pooled row of the thread (rotated: see above)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // BN + ReLU of 32 channels into S[pixel][channel]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                S[p * C::SP + li] = half ? fmaxf(fmaf(acc1[r], sc1, bi1), 0.f) : fmaxf(fmaf(acc0[r], sc0, bi0), 0.f);
+            }
+            if (half == 0 && step + 1 < nsteps) {   // the next strip's window (fetched during the previous strip) -> LDS; the one after -> registers
+                put();
+                if (step + 2 < nsteps) fetch(step + 2);
+            }
+            __syncthreads();
+            {
+                auto hmax = [&](int row) {
+                    const float* s0 = S + row * OW * C::SP;
+                    const f32x4 l = *reinterpret_cast<const f32x4*>(s0 + xl), m = *reinterpret_cast<const f32x4*>(s0 + xm),
+                                r_ = *reinterpret_cast<const f32x4*>(s0 + xr);
+                    f32x4 o;
+                    o.x = fmaxf(fmaxf(l.x, m.x), r_.x); o.y = fmaxf(fmaxf(l.y, m.y), r_.y);
+                    o.z = fmaxf(fmaxf(l.z, m.z), r_.z); o.w = fmaxf(fmaxf(l.w, m.w), r_.w);
+                    return o;
+                };
+                f32x4 top = carry[half];
+                if (st == 0 && je == 0) top = f32x4{0.f, 0.f, 0.f, 0.f};     // first pooled row of an image: conv row -1 is outside
+                if (je > 0) top = hmax(2 * je - 1);
+                const f32x4 mid = hmax(2 * je), bot = hmax(2 * je + 1);
+                f32x4 m;
+                m.x = fmaxf(fmaxf(top.x, mid.x), bot.x); m.y = fmaxf(fmaxf(top.y, mid.y), bot.y);
+                m.z = fmaxf(fmaxf(top.z, mid.z), bot.z); m.w = fmaxf(fmaxf(top.w, mid.w), bot.w);
+                if (je == C::PR - 1) carry[half] = bot;
+                const int py = st * C::PR + je;
+                *reinterpret_cast<f32x4*>(a.out + (((size_t)img * C::PW + py) * C::PW + px) * 64 + 32 * half + 4 * c4) = m;
+            }
+            if (half == 0) __syncthreads();   // the second half overwrites the staging image
+        }
+    }
+}
+
+template <int OW, int R, int FR, int G = (RowsCfg<OW, R>::WPE >= 3 ? 4 : 8)>
+void launch_rows(StemArgs a, int cus, hipStream_t s) {
+    using C = RowsCfg<OW, R>;
+    const int grid = a.n < cus * C::BPC ? a.n : cus * C::BPC;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_pool_rows_kernel<OW, R, FR, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDSF * 4);
+    hipLaunchKernelGGL((stem7x7_pool_rows_kernel<OW, R, FR, G>), dim3(grid), dim3(C::NT), C::LDSF * 4, s, a);
+}
+
+// Strip height R and operand-group size G per patch size, from tools/stem_probe.py sweeps on 1024 patches (ms per launch, tile form first):
+//   96^2: 0.519 -> R = 4 (two 6-wave blocks per CU) 0.509, R = 6 0.478, R = 8 (one 12-wave block per CU) 0.371 (G = 2 / 4 alike, G = 8 spills: 0.432)
+//   128^2: 1.53 (0.98 as two launches) -> R = 2 (two 4-wave blocks) 0.69, R = 4 / 8 0.70-0.73;  144^2: 1.27 -> R = 4 (one 9-wave block) 1.07;
+//   64^2: 0.39 -> 0.18.  Taller strips amortise the four barriers of a strip; a 16-wave block is the limit (R * OW <= 512).
+template <int FR>
+bool launch_rows_for(const StemArgs& a, int cus, hipStream_t s) {
+    switch (a.P) {
+        case 64: launch_rows<32, 4, FR, 8>(a, cus, s); return true;
+        case 96: launch_rows<48, 8, FR, 2>(a, cus, s); return true;
+        case 128: launch_rows<64, 2, FR, 8>(a, cus, s); return true;
+        case 144: launch_rows<72, 4, FR, 2>(a, cus, s); return true;
+        default: return false;
+    }
+}
+
 template <int TPH>
 void launch_pool(StemArgs a, int cus, hipStream_t s) {
     using C = PoolCfg<TPH>;
@@ -302,7 +486,7 @@ size_t adaf_stem_weight_floats() { return (size_t)2 * KS * 64; }
 void adaf_launch_stem7x7(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
                          int cus, hipStream_t s) {
     StemArgs a;
-    a.x = x4; a.w = wr; a.scale = scale; a.bias = bias; a.out = out;
+    a.x = x4; a.w = wr; a.scale = scale; a.bias = bias; a.out = out; a.act = nullptr; a.fpa = 1; a.H = a.W = 0; a.nframes = n;
     a.n = n; a.P = P; a.OH = (P + 6 - 7) / 2 + 1; a.OW = a.OH; a.PH = a.PW = 0;
     a.tiles_y = (a.OH + TH - 1) / TH; a.tiles_x = (a.OW + TW - 1) / TW;
     a.ntiles = n * a.tiles_y * a.tiles_x;
@@ -317,12 +501,29 @@ bool adaf_stem7x7_pool_pays(int P) {
     return ((ph + 5) / 6) * PoolCfg<6>::NWV < ((ph + 3) / 4) * PoolCfg<4>::NWV;
 }
 
+// the strip-walking form: instantiated patch sizes, and a block owns whole images -- below one image per CU the tile form spreads better
+bool adaf_stem7x7_rows_ok(int P, int n, int cus) {
+    const int mode = adaf_options().stem_rows;      // 0 = off, 1 = default, 2 = at every image count (tests)
+    if (!mode) return false;
+    return (P == 64 || P == 96 || P == 128 || P == 144) && (n >= cus || mode == 2);
+}
+
+bool adaf_launch_stem7x7_pool_frames(const float* frames, bool pixel_major, int nframes, const float* act, int fpa, int H, int W, int n, int P,
+                                     const float* wr, const float* scale, const float* bias, float* out, int cus, hipStream_t s) {
+    if (!adaf_stem7x7_rows_ok(P, n, cus) || !act || fpa < 1 || nframes < 1 || H < P || W < P) return false;
+    StemArgs a;
+    a.x = frames; a.act = act; a.fpa = fpa; a.H = H; a.W = W; a.nframes = nframes; a.w = wr; a.scale = scale; a.bias = bias; a.out = out;
+    a.n = n; a.P = P; a.OH = P / 2; a.OW = a.OH; a.PH = a.OH / 2; a.PW = a.PH; a.tiles_y = a.tiles_x = a.ntiles = 0;
+    return pixel_major ? launch_rows_for<2>(a, cus, s) : launch_rows_for<1>(a, cus, s);
+}
+
 // conv 7x7/2 + BN + ReLU + max-pool 3x3/2/1 in one launch: out [n, PH, PW, 64] with PH = (OH - 1) / 2 + 1
 void adaf_launch_stem7x7_pool(const float* x4, int n, int P, const float* wr, const float* scale, const float* bias, float* out,
                               int cus, hipStream_t s) {
     StemArgs a;
-    a.x = x4; a.w = wr; a.scale = scale; a.bias = bias; a.out = out;
+    a.x = x4; a.w = wr; a.scale = scale; a.bias = bias; a.out = out; a.act = nullptr; a.fpa = 1; a.H = a.W = 0; a.nframes = n;
     a.n = n; a.P = P; a.OH = (P + 6 - 7) / 2 + 1; a.OW = a.OH; a.PH = (a.OH - 1) / 2 + 1; a.PW = a.PH;
+    if (adaf_stem7x7_rows_ok(P, n, cus) && launch_rows_for<0>(a, cus, s)) return;
     // rows of pooled pixels per tile: 4 (5 waves) or 6 (7 waves), whichever computes fewer conv pixels for this map
     const int cost4 = ((a.PH + 3) / 4) * PoolCfg<4>::NWV, cost6 = ((a.PH + 5) / 6) * PoolCfg<6>::NWV;
     if (cost6 < cost4) launch_pool<6>(a, cus, s);

@@ -194,11 +194,16 @@ class GFV(nn.Module):
         gdim = global_feat.shape[2] if global_feat is not None else 0
         feature = torch.empty((b, t, gdim + self.focuser.feature_dim), device=frames.device, dtype=torch.float32)
         flat = feature.view(b * t, -1)
-        if frames.shape[-1] == 4 and frames.shape[1] != 3:
-            patches = hip_ops.crop_gather_nhwc4(frames, actions, self.patch_size)
+        net = self.focuser.net
+        if hasattr(net, "features_from_frames"):
+            # the gather rides in the trunk's first launch (adaf_resnet50_forward_frames): no patch tensor between get_patch and the local CNN
+            net.features_from_frames(frames, actions, self.patch_size, out=flat[:, gdim:])
         else:
-            patches = get_patch_nhwc4(frames, actions, self.patch_size)
-        self.focuser.net.features_nhwc4(patches, out=flat[:, gdim:])
+            if frames.shape[-1] == 4 and frames.shape[1] != 3:
+                patches = hip_ops.crop_gather_nhwc4(frames, actions, self.patch_size)
+            else:
+                patches = get_patch_nhwc4(frames, actions, self.patch_size)
+            net.features_nhwc4(patches, out=flat[:, gdim:])
         if gdim:
             hip_ops.copy2d(global_feat.reshape(b * t, gdim), flat[:, :gdim])
         logits, last = self.classifier(feature)

@@ -279,6 +279,25 @@ class ResNet50Trunk:
                                                 out.stride(0), L.ptr(ws), need, L.stream_ptr()), self._h)
         return out
 
+    def forward_frames(self, frames, actions, patch, frames_per_action=1, tsm_segments=0, tsm_div=8, out=None):
+        """get_patch + trunk in one call (adaf_resnet50_forward_frames): frames (N,3,H,W) planar or (N,H,W,4) pixel-major, actions
+        (k * N / frames_per_action, 2) fp32 (y, x) -> (k * N, 2048); the stem gathers its own windows where its strip kernel applies."""
+        L.need_gpu_f32(frames, actions, out)
+        L.on_current_device(frames, actions, out)
+        x = frames.contiguous()
+        pixel_major = x.shape[-1] == 4 and x.shape[1] != 3
+        nf = x.shape[0]
+        hh, ww = (x.shape[1], x.shape[2]) if pixel_major else (x.shape[2], x.shape[3])
+        act = actions.contiguous()
+        n = act.shape[0] // (nf // frames_per_action) * nf
+        if out is None:
+            out = torch.empty((n, 2048), device=x.device, dtype=torch.float32)
+        ws, need = self._workspace(n, patch)
+        L.check(self._lib.adaf_resnet50_forward_frames(self._net, L.ptr(x), LAYOUT_NHWC4 if pixel_major else LAYOUT_NCHW, nf, hh, ww, L.ptr(act),
+                                                       act.shape[0], int(frames_per_action), int(patch), int(tsm_segments), int(tsm_div),
+                                                       L.ptr(out), out.stride(0), L.ptr(ws), need, L.stream_ptr()), self._h)
+        return out
+
     def forward_map(self, patches_nhwc4, tsm_segments=0, tsm_div=8):
         """patches (N,P,P,4) -> (featmap (N,s,s,2048) NHWC, pooled feature (N,2048)): ResNet.get_featmap(x, pooled=False)."""
         L.need_gpu_f32(patches_nhwc4)

@@ -97,6 +97,9 @@ class TSN(nn.Module):
     def features_nhwc4(self, patches_nhwc4, out=None):
         return self.base_model.features_nhwc4(patches_nhwc4, out=out)
 
+    def features_from_frames(self, frames, actions, patch_size, frames_per_action=1, out=None):
+        return self.base_model.features_from_frames(frames, actions, patch_size, frames_per_action, out=out)
+
     def partialBN(self, enable):
         self._enable_pbn = enable
 

@@ -246,6 +246,19 @@ size_t adaf_resnet50_workspace_bytes(const adaf_resnet50* net, int n, int patch)
  * tsm_segments = 0 for the ActivityNet model. */
 int adaf_resnet50_forward(adaf_resnet50* net, const float* patches_nhwc4, int n, int patch, int tsm_segments,
                           int tsm_div, float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream);
+/* The same forward with the patch gather folded in: the trunk's patches are the P x P windows of resident frames at
+ * floor(action * (H - P)) -- get_patch(images, action_sequence, patch_size), ACT/models/utils.py:37-51 (= STH/models/utils.py:44-58),
+ * adaf_crop_gather_f32's coordinate arithmetic -- and the stem gathers them itself (csrc/stem.hip stem7x7_pool_rows_kernel): no gather
+ * launch and no patch tensor between Focuser.forward's two calls (ACT/models/gfv_net.py:325-331).  frames: [n_frames, 3, H, W]
+ * (ADAF_LAYOUT_NCHW, the loader's layout) or [n_frames, H, W, 4] (ADAF_LAYOUT_NHWC4, adaf_ingest_u8's output), square.  action_yx:
+ * [n_actions, 2] fp32; n_actions = k * n_frames / frames_per_action: action set j (k > 1: the Something-Something reward baseline rides
+ * in the same pass) cuts patch j * n_frames + f from frame f with action j * n_frames / fpa + f / fpa.  feat: [k * n_frames, 2048].
+ * Where the gathering stem does not apply (patch sizes other than 64 / 96 / 128 / 144, fewer images than CUs, fusion off) the gather
+ * runs into a workspace slab first: the same values either way (tests/test_hip_parity_r5.py).  Workspace: adaf_resnet50_workspace_bytes
+ * for k * n_frames patches. */
+int adaf_resnet50_forward_frames(adaf_resnet50* net, const float* frames, int frames_layout, int n_frames, int height, int width,
+                                 const float* action_yx, int n_actions, int frames_per_action, int patch, int tsm_segments, int tsm_div,
+                                 float* feat, int ldfeat, void* ws, size_t ws_bytes, void* stream);
 /* ResNet.get_featmap(x, pooled=False) (ACT/models/resnet.py:211-225, the branch `return x` before avgpool): the same pass, with the last
  * block's map written to featmap_nhwc [n][s][s][2048] (s = adaf_resnet50_map_size(patch): 3 at 96^2, 4 at 128^2) and the pooled feature to
  * `feat` as in adaf_resnet50_forward (the pool runs as its own launch here: same values). */

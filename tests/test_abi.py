@@ -100,7 +100,7 @@ SCRATCH_ALLOWED = {
     "ef_expand_kernel<float, 8, false>": 104, "ef_expand_kernel<float, 8, true>": 84, "ef_expand_kernel<float, 7, false>": 48,
     "ef_expand_kernel<float, 7, true>": 40, "ef_expand_kernel<_Float16, 8, true>": 76, "ef_expand_kernel<_Float16, 8, false>": 44,
     "ef_expand_kernel<_Float16, 7, true>": 28,
-    "stem7x7_pool_kernel<6>": 28, "mb_block_w_kernel<32>": 8,
+    "mb_block_w_kernel<32>": 8,
 }
 
 

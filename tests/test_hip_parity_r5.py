@@ -259,3 +259,60 @@ def test_gru_scan_two_slices_bit_identical_to_one(dev, b, t):
         for a_, b_ in zip(ref, val):
             assert torch.equal(a_, b_), key
     assert ops.gru_scan_timeouts(dev) == 0
+
+
+@pytest.mark.parametrize("p,n", [(96, 3), (96, 300), (64, 5), (128, 7), (144, 24), (128, 260)])
+def test_stem_pool_strip_kernel_bit_identical_to_tile_kernel(dev, p, n):
+    """csrc/stem.hip stem7x7_pool_rows_kernel (whole-width strips walked down the image, the shared conv row carried in registers, no halo
+    recompute) against the tile kernel and against the unfused conv + max-pool launches: the same k order in every product, the same
+    BN / ReLU / max -> torch.equal trunk features; image counts below, at and above one image per resident block."""
+    from adafocus_amd import _lib
+    from adafocus_amd.resnet import resnet50
+    from tests.helpers import rnd
+    net = resnet50(num_classes=200).eval()
+    net.load_state_dict(synth_sd("ACT", 1007 + p, "focuser.net.", keep_prefix=False), strict=True)
+    net = net.to(dev)
+    x = rnd((n, p, p, 4), 900 + p).to(dev)
+    x[..., 3] = 0
+    out = {}
+    with torch.no_grad():
+        for mode, fusion in ((2, 2), (0, 2), (0, 0)):
+            with _lib.option("stem_rows", mode):
+                net._sync().set_fusion(fusion)
+                out[(mode, fusion)] = net.features_nhwc4(x).clone()
+        net._sync().set_fusion(1)
+    assert torch.isfinite(out[(2, 2)]).all() and out[(2, 2)].abs().max().item() > 0.1
+    assert torch.equal(out[(2, 2)], out[(0, 2)]) and torch.equal(out[(2, 2)], out[(0, 0)])
+
+
+@pytest.mark.parametrize("p,nf,fpa,sets,layout", [(96, 300, 1, 1, "nchw"), (96, 8, 1, 1, "nchw"), (96, 288, 12, 2, "nhwc4"), (128, 264, 8, 1, "nchw"),
+                                                  (144, 264, 12, 2, "nchw"), (100, 260, 1, 1, "nhwc4"), (64, 520, 1, 1, "nhwc4")])
+def test_trunk_from_frames_equals_gather_then_trunk(dev, p, nf, fpa, sets, layout):
+    """adaf_resnet50_forward_frames -- get_patch (ACT/models/utils.py:37-51) folded into the trunk's first launch: the stem gathers its
+    own windows from the planar or pixel-major frames at floor(action * (H - P)) -- gives torch.equal features to the gather launch
+    followed by the trunk, with per-frame actions (ActivityNet), one action per clip (Something-Something), two action sets over the
+    same frames (the reward baseline in one pass), and where the gathering stem does not apply (P = 100; fewer images than CUs)."""
+    from adafocus_amd import hip_ops as ops
+    from adafocus_amd.resnet import resnet50
+    from adafocus_amd.utils import get_patch_nhwc4
+    from tests.helpers import rnd
+    net = resnet50(num_classes=200).eval()
+    net.load_state_dict(synth_sd("ACT", 1007 + p, "focuser.net.", keep_prefix=False), strict=True)
+    net = net.to(dev)
+    net.tsm_segments = fpa if fpa > 1 else 0
+    frames = rnd((nf, 3, 224, 224), 1300 + p).to(dev)
+    gen = np.random.Generator(np.random.PCG64([p, nf]))
+    act = gen.random((sets * nf // fpa, 2), dtype=np.float32)
+    act[0], act[-1] = (0.0, 1.0), (1.0, 0.0)                    # the corners: origins 0 and H - P
+    act = torch.from_numpy(act).to(dev)
+    src = frames if layout == "nchw" else torch.cat([frames, torch.zeros_like(frames[:, :1])], 1).permute(0, 2, 3, 1).contiguous()
+    with torch.no_grad():
+        got = net.features_from_frames(src, act, p, frames_per_action=fpa).clone()
+        per = nf // fpa
+        patches = torch.cat([get_patch_nhwc4(frames, act[g * per:(g + 1) * per], p, fpa) for g in range(sets)])
+        ref = net.features_nhwc4(patches)
+    assert got.shape == (sets * nf, 2048) and torch.isfinite(got).all()
+    assert torch.equal(got, ref)
+    if layout == "nhwc4":          # the same through the pixel-major gather
+        p4 = torch.cat([ops.crop_gather_nhwc4(src, act[g * per:(g + 1) * per], p, fpa) for g in range(sets)])
+        assert torch.equal(p4, patches)
