@@ -42,6 +42,7 @@ struct AdafOptions {
     unsigned effnet_fused_blocks = 0xffffffffu;   // "effnet_fused_blocks": MBConv blocks (bit = block index) the fused expand + depthwise launch may take
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
     int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)
+    int split_stage1_f32 = 1;     // "split_stage1_f32": the split-bf16 trunk takes the fp32 pipe's fused stage-1 launches (api.hip run_trunk)
     int gru_scan_slices = 2;      // "gru_scan_slices": clip slices a persistent GRU scan may be cut into (1 | 2; gru_scan.hip)
 };
 AdafOptions& adaf_options();

@@ -80,7 +80,7 @@ struct OptKey { const char* name; int kind; double lo, hi; };      // kind: inde
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
                            {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 63}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
-                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}};
+                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
     for (const OptKey& k : kOptKeys)
@@ -164,6 +164,7 @@ int adaf_set_option(adaf_handle* h, const char* key, double value) {
         case 11: o.gru_scan_slices = (int)value; break;
         case 12: o.effnet_fused_blocks = (unsigned)value; break;
         case 13: o.stem_rows = (int)value; break;
+        case 14: o.split_stage1_f32 = (int)value; break;
         default: o.effnet_chunk = (int)value; break;
     }
     return ADAF_OK;
@@ -187,6 +188,7 @@ double adaf_get_option(const char* key) {
         case 11: return o.gru_scan_slices;
         case 12: return o.effnet_fused_blocks;
         case 13: return o.stem_rows;
+        case 14: return o.split_stage1_f32;
         default: return o.effnet_chunk;
     }
 }
@@ -558,6 +560,11 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
     // conv AND the identity see the shifted block input.  The shifted map is materialised in a sixth slab in front of every block and
     // the block then runs exactly as a block without a shift (every fused form applies, except the next block's conv1 riding in a
     // fused tail: it needs the SHIFTED output).  'blockres' (every shipped configuration) keeps the shift inside conv1's operand load.
+    // The 64-plane stage is HBM-bound layer by layer, whatever the matrix pipe: its fused launches (conv1 + downsample of layer1.0;
+    // conv2 -> conv3 -> next conv1 per block) exist on the fp32 pipe only, and the opt-in split-bf16 arithmetic takes them too --
+    // 2.30 ms against 2.41 ms for the ten split launches they replace (option "split_stage1_f32" = 0: A/B).  Every product of such a
+    // plan is either an exact fp32 FMA chain or the 6-product bf16 form: fp32-level accuracy throughout.
+    const bool stage1_f32 = net->math == ADAF_MATH_F32 || (net->math == ADAF_MATH_F32_SPLIT_BF16 && adaf_options().split_stage1_f32);
     const bool tsm_block = net->tsm_block && tsm_T > 0;
     const int tsm_c1 = tsm_block ? 0 : tsm_T;     // the temporal shift conv1's operand load carries
     const int nslab = net->tsm_block ? 6 : 5;
@@ -666,7 +673,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             const int i_next = li + 3 + (b == 0 ? 1 : 0);          // the next block's conv1 (or convs.size())
             // conv1 (1x1, optional fused temporal shift) -> conv2 (3x3, stride) -> conv3 (1x1) + identity
             bool ds_done = false;
-            if (s == 0 && b == 0 && !c1_done && fuse && net->l10_w && tsm_c1 == 0 && net->math == ADAF_MATH_F32 &&
+            if (s == 0 && b == 0 && !c1_done && fuse && net->l10_w && tsm_c1 == 0 && stage1_f32 &&
                 !net->tiles[li] && !net->tiles[i_ds]) {
                 // layer1.0: conv1 and the downsample conv in ONE launch (same input, same 1x1 geometry; N = 64 + 256): the
                 // pooled map is read once instead of twice and a 0.07 ms launch disappears.  128x64 tiles: column tile 0 is conv1.
@@ -702,7 +709,7 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             }
             li = i_c2;
             const ConvLayer& L2 = net->convs[i_c2];
-            const bool fusable = fuse && net->math == ADAF_MATH_F32 && L2.cin == 64 && L2.cout == 64 && L2.stride == 1 &&
+            const bool fusable = fuse && stage1_f32 && L2.cin == 64 && L2.cout == 64 && L2.stride == 1 &&
                                  !net->tiles[i_c2] && !net->tiles[i_c3];
             if (fusable) {
                 const ConvLayer& L3 = net->convs[i_c3];

@@ -565,7 +565,7 @@ template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, 
 __global__ __launch_bounds__(64 * WGM * WGN, (BM == 128 && BN == 128 && WGM * WGN == 4) ? 2 : 1)   // 128x128: two blocks per CU
 void conv_gemm_glds_kernel(const ConvArgs a) {
     static_assert(!POOL || (LEAN && DENSE && DT == 0), "pooled epilogue: the lean dense fp32 kernel");
-    static_assert(!PM || (!DENSE && EMU == 0 && !BSP && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe");
+    static_assert(!PM || (!DENSE && (EMU == 0 || BSP) && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe, or split tiles with pre-split weights");
     static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && EMU == 0 && !BSP && PIPE == 1), "lean K loop: plain fp32-pipe launches");
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -760,7 +760,7 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
             const float* srcb = pb[q];
             if (!BSP && SPECIAL && nx_tail && nx_kt * 32 + qb[q] >= a.K) srcb = a.zeros;
             if (PM) {
-                if (step_b[q]) srcb += nx_koff;         // (rows past N point at the zero block and stay there)
+                if (step_b[q]) srcb += BSP ? (nx_koff >> 1) : nx_koff;         // (rows past N point at the zero block and stay there; bf16 planes: two k per float)
             } else
                 pb[q] += step_b[q];
             __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(Bs + q * NW * 8 * 32), 16, 0, 0);
@@ -889,7 +889,8 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         if (nk > 1) { body(k, std::true_type{}, std::false_type{}); ++k; }
         body(k, std::false_type{}, std::false_type{});
         __syncthreads();
-        conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
+        if (PM) conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave, a.OH * a.OW, pm_p, a.pm_images);
+        else conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
         return;
     }
 
@@ -1651,6 +1652,20 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
             else
                 hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 0, false, 0, true>), dim3(a.nblocks),
                                    dim3(64 * WGM * WGN), 0, s, a);
+            return;
+        }
+    }
+    if constexpr (PIPE == 1 && EMU == 6 && BSP) {
+        // the same position-major tiles on the split-bf16 pipe (round 5): a skipped tap is whole MFMA steps of exact zeros, so the result
+        // is bit-identical to the row-major split tile; the activation split (VALU) of the skipped slices disappears with their MFMAs
+        const int ohw = a.OH * a.OW;
+        const int images = ohw > 0 ? a.M / ohw : 0;
+        if (!dense && a.pm_allow == 1 && a.wsp && a.KH * a.KW > 1 && a.KH * a.KW <= 32 && images * ohw == a.M && images >= BM && ohw <= 4096 &&
+            (a.cin & 31) == 0 && conv_tap_fill(a) < conv_pm_fill_threshold()) {
+            a.pm_images = images;
+            a.pm_groups = (images + BM - 1) / BM;
+            a.nblocks = ohw * a.pm_groups * a.tiles_n;
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 6, true, 0, true>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
             return;
         }
     }

@@ -364,6 +364,19 @@ def glancer_f16_row(dev, model, b, t, streams):
         "max_abs_logit_diff_clips_with_equal_actions": float((lg16v[clip_same] - lg32v[clip_same]).abs().max()) if bool(clip_same.any()) else None,
         "logit_scale": float(lg32.abs().max())}
     del u8, fr4
+    out["note"] = ("adaf_mobilenetv2_set_dtype(f16): activations and 1x1 weights stored in fp16 (fp32 accumulation, fp32 depthwise arithmetic); the "
+                   "local CNN, policy and classifier stay fp32.  Random-init weights: a worst case for the cost columns (DESIGN 3.4)")
+    try:
+        out["sth_T8_P128"] = _glancer_f16_sth(dev, b)
+    except Exception as exc:      # the fp16 plan has no temporal shift (csrc/mobilenetv2.hip): say so instead of losing the ActivityNet row
+        out["sth_T8_P128"] = {"unsupported": repr(exc)[:200]}
+    return out
+
+
+def _glancer_f16_sth(dev, b):
+    from adafocus_amd.gfv_net_sth import GFV as GFV_STH
+    from adafocus_amd.transforms import ingest_uint8
+    out = {}
     # config 4: Something-Something (TSM glancer, continuous policy; the glancer's logits are ADDED to the output)
     a = sth_args(b, 8, 128)
     m = GFV_STH(a).eval()
@@ -394,9 +407,7 @@ def glancer_f16_row(dev, model, b, t, streams):
                           "max_abs_logit_diff": float((p16 - p32).abs().max()),
                           "max_abs_logit_diff_clips_with_equal_origin": float((p16[same_origin] - p32[same_origin]).abs().max()) if bool(same_origin.any()) else None,
                           "logit_scale": float(p32.abs().max())}
-    out["note"] = ("adaf_mobilenetv2_set_dtype(f16): activations and 1x1 weights stored in fp16 (fp32 accumulation, fp32 depthwise arithmetic); the "
-                   "local CNN, policy and classifier stay fp32.  Random-init weights: a worst case for the cost columns (DESIGN 3.4)")
-    return out
+    return out["sth_T8_P128"]
 
 
 def split_bf16_row(dev, model, frames, gvec, actions, b, t, p, streams, steps, step_fn):

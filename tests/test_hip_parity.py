@@ -219,7 +219,7 @@ def test_conv_tiles_bit_identical(dev, ops, O):
 def test_conv_split_tiles_bit_identical_and_close_to_fp32(dev, ops, O):
     """The split tiles (fp32 operands as three exact bf16 parts on the bf16 matrix pipe) share one k / term order, so
     they agree bit for bit among themselves; against the fp32-MFMA tiles they differ only by accumulation rounding."""
-    six = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (41, 42, 43, 44, 45, 46, 47)]
+    six = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (41, 42, 43, 44, 45, 46)]
     nine = [_conv_case(O, ops, dev, 4, 12, 12, 128, 128, 3, 1, 1, 1, True, t, seed=99)[0] for t in (51, 52, 53, 54)]
     for o in six[1:]:
         assert torch.equal(o, six[0])
@@ -388,18 +388,25 @@ def test_resnet50_trunk_split_math_vs_oracle(dev, O, p, tsm):
 
 def test_resnet50_split_math_presplit_weights_bit_identical(dev):
     """Tiles 6x read the weights pre-split at load time; tiles 4x split them on the fly: same parts, same order."""
+    from adafocus_amd import _lib
     net, _ = _trunk(dev, 1007)
     net.set_math("split_bf16")
     x = rnd((8, 3, 96, 96), 77).to(dev)
     trunk = net._sync()
     outs = []
-    with torch.no_grad():
+    with torch.no_grad(), _lib.option("split_stage1_f32", 0):       # every conv on split tiles (the default plan keeps stage 1's fused fp32 launches)
         for t in (0, 41, 42, 43, 61, 62, 63, 64, 65):
             trunk.set_tiles([0] + [t] * 52)
             outs.append(net.get_featvec(x).clone())
     trunk.set_tiles([0] * 53)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+    # the default split plan (round 5): stage 1 on the fp32 pipe's fused launches, the rest on split tiles -- two fp32-accurate
+    # arithmetics, so it agrees with the all-split plan to rounding noise but not bit for bit
+    with torch.no_grad():
+        hybrid = net.get_featvec(x).clone()
+    assert not torch.equal(hybrid, outs[0])
+    assert (hybrid - outs[0]).abs().max().item() < 2e-5 * max(1.0, outs[0].abs().max().item())
 
 
 def test_resnet50_trunk_error_vs_fp64_split_same_order(dev, O):

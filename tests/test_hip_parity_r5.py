@@ -272,6 +272,7 @@ def test_stem_pool_strip_kernel_bit_identical_to_tile_kernel(dev, p, n):
     net = resnet50(num_classes=200).eval()
     net.load_state_dict(synth_sd("ACT", 1007 + p, "focuser.net.", keep_prefix=False), strict=True)
     net = net.to(dev)
+    net.set_math("f32")          # (the stem is on the fp32 pipe in either arithmetic; fusion on / off changes the split plan's stage 1)
     x = rnd((n, p, p, 4), 900 + p).to(dev)
     x[..., 3] = 0
     out = {}
@@ -316,3 +317,29 @@ def test_trunk_from_frames_equals_gather_then_trunk(dev, p, nf, fpa, sets, layou
     if layout == "nhwc4":          # the same through the pixel-major gather
         p4 = torch.cat([ops.crop_gather_nhwc4(src, act[g * per:(g + 1) * per], p, fpa) for g in range(sets)])
         assert torch.equal(p4, patches)
+
+
+@pytest.mark.parametrize("p,n", [(96, 256), (96, 140), (128, 130)])
+def test_split_bf16_position_major_tap_skipping_bit_identical(dev, p, n):
+    """Round 5: the split-bf16 tiles (pre-split weights) take position-major tiles with padding-tap skipping like the fp32 pipe's do.  A
+    skipped tap is whole MFMA steps whose activation operand is zero in all three bf16 parts -- exact zeros into the fp32 accumulator --
+    so the trunk's features must be torch.equal with the skipping on and off."""
+    from adafocus_amd import hip_ops as ops
+    from adafocus_amd.resnet import resnet50
+    from tests.helpers import rnd
+    net = resnet50(num_classes=200).eval()
+    net.load_state_dict(synth_sd("ACT", 1007 + p, "focuser.net.", keep_prefix=False), strict=True)
+    net = net.to(dev)
+    net.set_math("split_bf16")
+    x = rnd((n, p, p, 4), 1500 + p).to(dev)
+    x[..., 3] = 0
+    try:
+        with torch.no_grad():
+            ops.set_conv_pos_major(False, dev)
+            ref = net.features_nhwc4(x).clone()
+            ops.set_conv_pos_major(True, dev)
+            got = net.features_nhwc4(x).clone()
+    finally:
+        ops.set_conv_pos_major(True, dev)
+    assert torch.isfinite(got).all() and got.abs().max().item() > 0.1
+    assert torch.equal(got, ref)

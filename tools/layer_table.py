@@ -20,6 +20,8 @@ net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(s
 net = net.to(dev)
 x = torch.randn((n, p, p, 4), device=dev)
 x[..., 3] = 0
+if os.environ.get("MATH"):          # MATH=split_bf16: the opt-in arithmetic
+    net.set_math(os.environ["MATH"])
 trunk = net._sync()
 for _ in range(3):
     trunk.forward(x, tsm_segments=tsm) if tsm else trunk.forward(x)
