@@ -43,6 +43,7 @@ struct GruScanArgs {
     int C, cpb;          // classes, classes per block
     unsigned* timeouts;  // device counter bumped by a block whose barrier wait ran out (or nullptr)
     int groups, bg;      // the batch in `groups` independent slices of `bg` clips, each with its own H / JB blocks and barrier words
+    int bpad;            // 0: one counter per step (flat barrier); > 0: XCD-hierarchical barrier, 17 words per step at a pitch of `bpad` words
 };
 
 template <int H, int JB>
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int T = a.T;
     const int bbeg = grp * a.bg;
     const int B = min(a.B, bbeg + a.bg);               // this slice's clips: [bbeg, B)
-    unsigned* bar = a.bar + grp * (T + 1);
+    unsigned* bar = a.bar + (size_t)grp * (T + 1) * (a.bpad > 0 ? 17 * a.bpad : 1);
     if (tid == 0) timed_out = 0;
 
     f32x4 wreg[NKK];
@@ -153,13 +154,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 // keeps the arrive behind the write-back (the compiler may drop the fence's own wait when its scoreboard looks empty).
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(bar + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned spins = 0;
-                while (__hip_atomic_load(bar + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NBLK) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) { timed_out = 1; break; }
+                if (a.bpad > 0) {
+                    // XCD-hierarchical form (round 5; MI355X_MICROARCH.md barrier-xcd: 4.1 us against 7.4 for one counter at 256 workgroups):
+                    // 128 arrivals on one word serialise (~12 ns each) and 128 pollers hammer its line.  Blocks are dispatched round-robin
+                    // over the 8 XCDs, so block jb arrives on the counter of group jb & 7 (16 arrivals); the group's LAST arriver is its
+                    // leader for this step: release fence -> top counter (8 arrivals) -> poll it -> acquire fence -> the group's flag; the
+                    // other 15 poll that flag.  Correct for any block -> XCD mapping (the groups are by block index); the mapping only
+                    // decides whether a group's words stay within one XCD's reach.  17 words per step: [top | 8 counters | 8 flags].
+                    unsigned* rec = bar + (size_t)t * 17 * a.bpad;
+                    const int g8 = jb & 7;
+                    const unsigned members = (unsigned)((NBLK + 7 - g8) >> 3);
+                    const unsigned old = __hip_atomic_fetch_add(rec + (1 + g8) * a.bpad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == members - 1u) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        __hip_atomic_fetch_add(rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while (__hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(NBLK < 8 ? NBLK : 8)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 24)) { timed_out = 1; break; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        __hip_atomic_store(rec + (9 + g8) * a.bpad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        while (__hip_atomic_load(rec + (9 + g8) * a.bpad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 24)) { timed_out = 1; break; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                } else {
+                    __hip_atomic_fetch_add(bar + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (__hip_atomic_load(bar + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NBLK) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 24)) { timed_out = 1; break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             if (timed_out) {   // never observed; refuses to hang the device if the grid cannot become co-resident
@@ -221,14 +251,20 @@ hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, co
     // `bar` lends groups * (steps + 1) words to the grid barriers: the launcher checks the capacity itself (it used to trust the caller)
     if (groups > 1 && (size_t)groups * (steps + 1) > bar_words) groups = 1;
     if ((size_t)(steps + 1) > bar_words) return hipErrorInvalidValue;
+    // XCD-hierarchical barrier records (17 words per step) at a pitch of 16 words (64 bytes) when the buffer has the room, packed
+    // otherwise, the single counter per step when even that does not fit (option "gru_barrier" = 0: always the single counter)
+    const size_t recs = (size_t)(groups < 1 ? 1 : groups) * (steps + 1) * 17;
+    const int bpad = !adaf_options().gru_barrier ? 0 : recs * 16 <= bar_words ? 16 : recs <= bar_words ? 1 : 0;
+    const size_t nzero = bpad ? recs * bpad : (size_t)(groups < 1 ? 1 : groups) * (steps + 1);
     GruScanArgs a;
+    a.bpad = bpad;
     a.timeouts = timeouts;
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;
     a.fcw = fcw; a.fcb = fcb; a.logits = logits; a.last = last; a.C = fcw ? classes : 0;
     a.cpb = fcw ? (classes + kGrid - 1) / kGrid : 0;
     a.groups = groups < 1 ? 1 : groups;
     a.bg = a.groups == 1 ? batch : ((batch + a.groups - 1) / a.groups + 31) / 32 * 32;      // whole m-tiles per slice
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, bar, a.groups * (steps + 1));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(nzero > 256 ? 1024 : 64), 0, s, bar, (int)nzero);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (cooperative) {

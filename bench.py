@@ -184,7 +184,7 @@ def load_glancer_traffic(frames):
 def load_traffic(t, p, b):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r<N>_traffic.json, tools/profile_bench.sh +
     tools/publish_profiles.py; newest round first); only reported when it was collected on this very workload."""
-    for tag in ("r4", "r3", "r2"):
+    for tag in ("r5", "r4", "r3", "r2"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)))
             w = d["workload"]

@@ -58,8 +58,14 @@ EXTRA_R4 = {   # round 4 (tools/profile_r4.sh)
     "effnet_f16_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB; x2 for wide coalesced reads on gfx950)",
     "effnet_f16_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB)",
 }
+EXTRA_R5 = {   # round 5 (tools/profile_r5.sh)
+    "split_trace": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 4 --skip-extras --streams 1 --cpu-baseline 0 --math split_bf16   (the opt-in arithmetic: also.split_bf16)",
+    "split_mfma": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0 --math split_bf16",
+}
 if tag >= "r4":
     EXTRA = EXTRA_R4
+if tag >= "r5":
+    EXTRA = EXTRA_R5
 
 
 def all_kernels_sum(path, counter, once_per_forward):
