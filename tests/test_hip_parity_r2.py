@@ -380,7 +380,9 @@ def test_sth_stage3_classifier_training_forward(dev, O):
 # ------------------------------------------------------------------------------------ fused trunk launches
 @pytest.mark.parametrize("p,n,tsm", [(96, 8, 0), (128, 4, 0), (100, 3, 0), (72, 4, 4), (96, 16, 8), (64, 1, 0), (33, 5, 0),
                                      # >= 128 patches: the fused tails run position-major tiles (full groups, a ragged last group, no next conv1)
-                                     (32, 128, 0), (40, 250, 0), (32, 256, 8)])
+                                     (32, 128, 0), (40, 250, 0), (32, 256, 8),
+                                     # round 5: at >= 256 patches of an instantiated size the fused stem is the strip-walking kernel
+                                     (64, 257, 0), (96, 264, 12), (128, 256, 0)])
 def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
     """Stage-1 conv2 -> conv3 -> next conv1 in one launch and stem + max-pool in one launch (adaf_resnet50_set_fusion):
     same k order in every product, hence torch.equal with the one-launch-per-layer plan -- full tiles, ragged last tiles
