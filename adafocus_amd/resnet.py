@@ -114,7 +114,8 @@ class ResNet(nn.Module):
         (N,H,W,4), actions (k * N / frames_per_action, 2) -> (k * N, 2048); the stem gathers its own windows (no patch tensor)."""
         if self.training:
             raise RuntimeError("adafocus_amd.ResNet implements the eval-mode (offline inference) path only")
-        return self._sync().forward_frames(frames, actions.to(dtype=torch.float32), patch_size, frames_per_action, self.tsm_segments, self.tsm_div, out=out)
+        return self._sync().forward_frames(frames, actions.to(device=frames.device, dtype=torch.float32), patch_size, frames_per_action, self.tsm_segments,
+                                           self.tsm_div, out=out)
 
     def get_featmap(self, x, pooled=True):
         """ACT/models/resnet.py:211-225: the trunk up to layer4, then the global average pool (pooled=True: (N,2048,1,1), the call the
