@@ -733,7 +733,10 @@ def main():
         crop_bytes = float(workload.crop_bytes_per_patch(p)) * b * t
         res["gather"] = {"bound": "hbm", "achieved": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(crop_bytes / (crop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "ms": round(crop_ms, 4), "bytes_per_patch": workload.crop_bytes_per_patch(p)}
+                         "ms": round(crop_ms, 4), "bytes_per_patch": workload.crop_bytes_per_patch(p),
+                         "note": "adaf_crop_gather_f32 as its own launch (get_patch for callers that want the patch tensor); in the timed step "
+                                 "the gather rides in the trunk's first launch (adaf_resnet50_forward_frames: the stem fetches its windows "
+                                 "from the frames), so this launch and the patch tensor do not exist there"}
         def extra(group, key, fn):      # an `also` / `next_rows` entry must never fail the bench
             try:
                 res.setdefault(group, {})[key] = fn()
