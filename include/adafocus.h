@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ADAF_VERSION 301
+#define ADAF_VERSION 302
 
 enum {
     ADAF_OK = 0,
