@@ -489,7 +489,7 @@ struct adaf_resnet50 {
     float* l10_bias = nullptr;
     int math = ADAF_MATH_F32;      // ADAF_MATH_*: which matrix pipe the (non-stem) convs use
     bool fuse = true;              // stage 1: conv2 -> conv3 (-> next conv1) in one launch; stem + max-pool in one launch
-    bool fuse_stem_always = false; // (tests) take the fused stem launch at every patch size, not only where it is faster
+    bool fuse_stem_always = false; // (tests, set_fusion(2)) take every fused launch at every size, not only where it is the faster plan
     bool tsm_block = false;        // temporal shift in front of the WHOLE Bottleneck (shift_place = 'block') instead of its conv1 ('blockres')
     int lat_rows = -1;             // convs with at most this many GEMM rows take the small-batch form (-1 = the "latency_rows" option, 1536)
     float* stem_w = nullptr;       // filter bank in the stem kernel's layout (stem.hip)
@@ -711,8 +711,11 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
             }
             li = i_c2;
             const ConvLayer& L2 = net->convs[i_c2];
+            // (below ~1.5 row tiles of 128 pixels per CU the fused launch is a few dozen blocks that each run conv2, eight conv3 passes and
+            //  the next conv1 one after the other -- 48-55 us at 8 patches against ~30 us for the three launches it replaces, each spread over
+            //  more CUs; measured crossover between 64 and 96 patches of 96^2, tools/lat_plan_probe.py.  Bit-identical either way.)
             const bool fusable = fuse && stage1_f32 && L2.cin == 64 && L2.cout == 64 && L2.stride == 1 &&
-                                 !net->tiles[i_c2] && !net->tiles[i_c3];
+                                 !net->tiles[i_c2] && !net->tiles[i_c3] && (net->fuse_stem_always || (long long)n * h1 * w1 * 2 >= 3ll * 128 * h->cus);
             if (fusable) {
                 const ConvLayer& L3 = net->convs[i_c3];
                 adaf_conv_params p;

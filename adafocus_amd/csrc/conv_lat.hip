@@ -18,6 +18,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "adaf_internal.h"
 
@@ -58,13 +59,21 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const ConvArgs a) {
     const int cslices = a.cin / KC;               // slices per tap
     const int nslices = a.KH * a.KW * cslices;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // The slices of one block are a dependent chain (one accumulator): DEPTH slices are kept in flight in registers (set d holds
-    // slice s with s % DEPTH == d).  Measured on stage 4's 3x3 (K = 4608, 36 slices, 54 us): 1, 2 and 4 deep run the same; with
-    // the products replaced by a trivial sum 44 us, without the LDS hand-over + barrier 37 us, with neither 28 us -- per slice
-    // ~0.3 us of chain, ~0.3 us of hand-over and ~0.6 us of issue + latency that one wave per SIMD has nothing to hide behind.
-    constexpr int DEPTH = 2;
-    f32x4 pa[DEPTH][PPT], pb[DEPTH][PPT];
-    auto gload = [&](int s, f32x4 (&ra)[PPT], f32x4 (&rb)[PPT]) {
+    // The slices of one block are a dependent chain (one accumulator).  Round 3's loop measured 1.4-1.5 us per 128-k slice against
+    // ~0.5 us of chain, and 1, 2 or 4 slices of prefetch all the same; round 5 read the ISA and found why: (i) every load was written
+    // `ok ? *p : zero` -- its own exec-masked branch behind a v_mov of zeros into its destination -- and (ii) the prefetch sets were
+    // an array indexed by `s % DEPTH` inside a loop with a break, which hipcc compiled as ONE loop body that loads into scratch
+    // registers, waits s_waitcnt vmcnt(0) and MOVES them into the set: every slice drained the loads it had just issued, i.e. paid a
+    // full memory round trip.  Now: NSET explicit register sets (slice j lives in set j % NSET; the loop body is NSET steps with
+    // compile-time sets, no moves), UNCONDITIONAL loads from a selected address (the handle's block of zeros for padding taps, rows
+    // past M, filters past N; past the last slice the last slice again), so a slice's loads have NSET - 1 steps to land and the only
+    // wait is the counted one in front of the LDS hand-over; and the hand-over of slice s+1 is issued BEFORE the products of slice s
+    // (its buffer was released by the previous barrier), so the chain of 2 KC / 8 dependent MFMAs runs while the writes complete.
+    // Same products in the same order: bit-identical (tests/test_hip_parity_r3.py).
+    constexpr int NSET = 4;
+    f32x4 pa[NSET][PPT], pb[NSET][PPT];
+    auto gload = [&](int s_req, f32x4 (&ra)[PPT], f32x4 (&rb)[PPT]) {
+        const int s = s_req < nslices ? s_req : nslices - 1;
         const int tap = s / cslices, c0 = (s - tap * cslices) * KC;
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
         const bool ok = (tapmask >> tap) & 1u;
@@ -73,8 +82,10 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int p = sp + 8 * j;
-            ra[j] = ok ? *reinterpret_cast<const f32x4*>(src + 4 * p) : zero4;
-            rb[j] = n_ok ? *reinterpret_cast<const f32x4*>(wsrc + 4 * p) : zero4;
+            const float* pa_ = ok ? src + 4 * p : a.zeros;
+            const float* pb_ = n_ok ? wsrc + 4 * p : a.zeros;
+            ra[j] = *reinterpret_cast<const f32x4*>(pa_);
+            rb[j] = *reinterpret_cast<const f32x4*>(pb_);
         }
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[PPT], const f32x4 (&rb)[PPT]) {
@@ -91,8 +102,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const ConvArgs a) {
         }
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (d < nslices) gload(d, pa[d], pb[d]);
+    for (int d = 0; d < NSET; ++d) gload(d, pa[d], pb[d]);
     // the epilogue's operands travel under the K loop too
     const int n = n0 + wn * 16 + r16;
     const bool col_ok = n < a.N;
@@ -109,31 +119,46 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const ConvArgs a) {
     const float* Ar = smem[0][0] + (wm * 16 + r16) * PITCH + 2 * kg;
     const float* Br = smem[0][1] + (wn * 16 + r16) * PITCH + 2 * kg;
     constexpr int BUFSTRIDE = 2 * 32 * PITCH;     // floats between the two buffers
-    for (int s0 = 0; s0 < nslices; s0 += DEPTH) {
+    // one step: slice s (in LDS buffer BUF = s & 1).  LOAD: set `rs` (which held slice s, handed to LDS one step ago) is refilled
+    // with slice s + NSET; the hand-over of slice s + 1 (set `ns`) goes out before the products.
+    auto step = [&](int s, auto buf_tag, auto load_tag, f32x4 (&rsa)[PPT], f32x4 (&rsb)[PPT], const f32x4 (&nsa)[PPT], const f32x4 (&nsb)[PPT]) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool LOAD = decltype(load_tag)::value;
+        if (LOAD) gload(s + NSET, rsa, rsb);
+        // every fragment of the slice is requested before the first product
+        f32x2 av[KC / 8], bv[KC / 8];
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int s = s0 + d;
-            if (s >= nslices) break;
-            const int buf = s & 1;
-            if (s + DEPTH < nslices) gload(s + DEPTH, pa[d], pb[d]);       // set d was written to LDS before the previous barrier
-            // every fragment of the slice is requested before the first product (left to itself the compiler read two groups,
-            // waited for them, multiplied, read the next two: an LDS round trip exposed every 160 cycles of a 40-cycle-per-step chain)
-            f32x2 av[KC / 8], bv[KC / 8];
-#pragma unroll
-            for (int g = 0; g < KC / 8; ++g) {
-                av[g] = *reinterpret_cast<const f32x2*>(Ar + buf * BUFSTRIDE + 8 * g);
-                bv[g] = *reinterpret_cast<const f32x2*>(Br + buf * BUFSTRIDE + 8 * g);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < KC / 8; ++g) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bv[g].x, acc, 0, 0, 0);     // k offsets {0, 4, 1, 5} of the group
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, bv[g].y, acc, 0, 0, 0);     // k offsets {2, 6, 3, 7}
-            }
-            if (s + 1 < nslices) lstore(buf ^ 1, pa[(d + 1) % DEPTH], pb[(d + 1) % DEPTH]);   // (that buffer was last read before the previous barrier)
-            __syncthreads();
+        for (int g = 0; g < KC / 8; ++g) {
+            av[g] = *reinterpret_cast<const f32x2*>(Ar + BUF * BUFSTRIDE + 8 * g);
+            bv[g] = *reinterpret_cast<const f32x2*>(Br + BUF * BUFSTRIDE + 8 * g);
         }
+        if (s + 1 < nslices) lstore(BUF ^ 1, nsa, nsb);       // (that buffer was last read before the previous barrier)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < KC / 8; ++g) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bv[g].x, acc, 0, 0, 0);     // k offsets {0, 4, 1, 5} of the group
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, bv[g].y, acc, 0, 0, 0);     // k offsets {2, 6, 3, 7}
+        }
+        __syncthreads();
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int s0 = 0;
+    for (; s0 + NSET <= nslices; s0 += NSET) {      // NSET is even: the buffer of a step is a compile-time constant
+        step(s0, B0{}, std::true_type{}, pa[0], pb[0], pa[1], pb[1]);
+        step(s0 + 1, B1{}, std::true_type{}, pa[1], pb[1], pa[2], pb[2]);
+        step(s0 + 2, B0{}, std::true_type{}, pa[2], pb[2], pa[3], pb[3]);
+        step(s0 + 3, B1{}, std::true_type{}, pa[3], pb[3], pa[0], pb[0]);
     }
+    // tail (nslices % NSET steps): everything they need is already in the sets
+    if (s0 < nslices) step(s0, B0{}, std::false_type{}, pa[0], pb[0], pa[1], pb[1]);
+    if (s0 + 1 < nslices) step(s0 + 1, B1{}, std::false_type{}, pa[1], pb[1], pa[2], pb[2]);
+    if (s0 + 2 < nslices) step(s0 + 2, B0{}, std::false_type{}, pa[2], pb[2], pa[3], pb[3]);
+    // (Tried on top of this and not kept, round 5: a three-buffer LDS ring with the next slice's fragments read and the slice after it
+    // handed over INSIDE the chain, one piece of each behind every pair of products, pinned with sched_barrier -- the ISA was exactly the
+    // weave intended: stage 4's 3x3 43.5 -> 38.2 us, but the short-K launches 8.6 -> 11-12 us (a longer prologue), B = 1 the same 0.89 ms,
+    // and 32-64 patches 8-10 % SLOWER (101 KB of LDS: one block per CU instead of two).  Six sets of prefetch instead of four: no gain
+    // either -- a 128-k slice stays at ~1.05 us, so what is left is the chain itself plus the barrier, not memory latency.)
     // ---- epilogue: C[row = 4 kg + i][col = r16] of the wave's 16 x 16 sub-tile
     if (!col_ok) return;
     const float lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;

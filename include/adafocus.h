@@ -279,7 +279,8 @@ int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
  *   - stage 1 (64 planes): conv2 3x3 -> conv3 1x1 + identity + ReLU -> the NEXT block's conv1 1x1 in one launch per
  *     128-pixel tile (csrc/conv_gemm.hip conv_fused_tail_kernel); the next conv1 is left out when it carries a temporal shift;
  *   - stem conv 7x7/2 + BN + ReLU + max-pool 3x3/2 in one launch (csrc/stem.hip) at the patch sizes where that is the
- *     faster plan (on = 2: at every size, for tests);
+ *     faster plan (on = 2: at every size, for tests); the stage-1 launches likewise only from ~1.5 row tiles of 128 pixels per CU
+ *     upwards (below that the three separate launches are faster: small batches; on = 2: always);
  *   - the global average pool (ACT/models/resnet.py:222-223) in the epilogue of the last conv3 when whole images fill its
  *     128-row tiles (3x3 / 4x4 / 5x5 final maps): the 2048-channel map is never written (conv_gemm.hip conv_epilogue_pool).
  * Results are bit-identical to the unfused launches (same k order in every product).  ADAF_MATH_F32 only. */
