@@ -493,16 +493,26 @@ __global__ __launch_bounds__(256, 4) void mb_stem_b1_w_kernel(const MbStemArgs a
     const int half = lane >> 5, nl = lane & 31;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // input window -> LDS (pixels outside the frame are the stem conv's zero padding)
+    // input window -> LDS (pixels outside the frame are the stem conv's zero padding).  All five pieces of a lane are requested
+    // before the first is written: as `Xw[..] = ok ? *p : zero` per piece hipcc emitted load -> s_waitcnt vmcnt(0) -> ds_write five
+    // times in a row -- five dependent memory round trips at the head of every tile (round 5, found in the ISA after the same pattern
+    // had cost the small-batch conv form its prefetch).  Unconditional loads from a clamped address, zeroed afterwards.
+    {
+        constexpr int NP = (XPIX + 63) / 64;
+        f32x4 wv[NP];
+        bool wok[NP];
 #pragma unroll
-    for (int u = 0; u < (XPIX + 63) / 64; ++u) {
-        const int idx = lane + 64 * u;
-        if (idx < XPIX) {
+        for (int u = 0; u < NP; ++u) {
+            const int idx = lane + 64 * u;
             const int r = idx / XW, c = idx - r * XW;
             const int iy = iy0 + r, ix = ix0 + c;
-            const bool ok = (unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S;
-            *reinterpret_cast<f32x4*>(&Xw[idx * 4]) =
-                ok ? *reinterpret_cast<const f32x4*>(a.x + (((size_t)img * a.S + iy) * a.S + ix) * 4) : zero4;
+            wok[u] = idx < XPIX && (unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S;
+            wv[u] = *reinterpret_cast<const f32x4*>(a.x + (wok[u] ? (((size_t)img * a.S + iy) * a.S + ix) * 4 : (size_t)0));
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < XPIX) *reinterpret_cast<f32x4*>(&Xw[idx * 4]) = wok[u] ? wv[u] : zero4;
         }
     }
     if (lane < 4) Xw[XPIX * 4 + lane] = 0.f;

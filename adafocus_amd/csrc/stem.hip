@@ -341,6 +341,22 @@ void stem7x7_pool_rows_kernel(const StemArgs a) {
     const int P = 2 * OW;
     const int nimg = (a.n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // images of this block
     const int nsteps = nimg * C::NS;
+    // gathering form: the window origins of this block's images, computed once (a dependent action load -> address -> frame load chain
+    // in front of every strip's fetch would sit right before a barrier)
+    constexpr int MAXO = 32;
+    __shared__ int origin[2 * MAXO];
+    if (FR != 0) {
+        for (int i = tid; i < nimg && i < MAXO; i += C::NT) {
+            const int img = blockIdx.x + i * gridDim.x;
+            const int ai = img / a.fpa;
+            // floor(action * (H - P)) for both axes (utils.py:40-42), clamped like crop_kernel
+            const float span = (float)(a.H - P);
+            const int y0 = (int)floorf(__fmul_rn(a.act[2 * ai], span)), x0 = (int)floorf(__fmul_rn(a.act[2 * ai + 1], span));
+            origin[2 * i] = min(max(y0, 0), a.H - P);
+            origin[2 * i + 1] = min(max(x0, 0), a.W - P);
+        }
+        __syncthreads();
+    }
     f32x4 win[C::WPT];
     auto fetch = [&](int step) {
         const int img = blockIdx.x + (step / C::NS) * gridDim.x, st = step % C::NS;
@@ -349,10 +365,15 @@ void stem7x7_pool_rows_kernel(const StemArgs a) {
         if (FR) {
             // the window origin of this patch: floor(action * (H - P)) for both axes (utils.py:40-42), clamped like crop_kernel; patch `img`
             // is cut from frame img % nframes with action img / fpa (a second action set over the same frames: the reward baseline)
-            const int ai = img / a.fpa, fr = img % a.nframes;
-            const float span = (float)(a.H - P);
-            int y0 = (int)floorf(__fmul_rn(a.act[2 * ai], span)), x0 = (int)floorf(__fmul_rn(a.act[2 * ai + 1], span));
-            y0 = min(max(y0, 0), a.H - P); x0 = min(max(x0, 0), a.W - P);
+            const int ii = step / C::NS, fr = img % a.nframes;
+            int y0, x0;
+            if (ii < MAXO) { y0 = origin[2 * ii]; x0 = origin[2 * ii + 1]; }
+            else {
+                const int ai = img / a.fpa;
+                const float span = (float)(a.H - P);
+                y0 = (int)floorf(__fmul_rn(a.act[2 * ai], span)); x0 = (int)floorf(__fmul_rn(a.act[2 * ai + 1], span));
+                y0 = min(max(y0, 0), a.H - P); x0 = min(max(x0, 0), a.W - P);
+            }
             src = FR == 1 ? a.x + ((size_t)fr * 3 * a.H + y0) * a.W + x0 : a.x + (((size_t)fr * a.H + y0) * a.W + x0) * 4;
         } else {
             src = a.x + (size_t)img * P * P * 4;
