@@ -589,11 +589,15 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
         memset(&p, 0, sizeof(p));
         p.n = n; p.h = hh; p.w = ww; p.cin = L.cin_pad; p.cout = L.cout; p.kh = p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
         p.act = act; p.tsm_segments = tsm ? tsm_T : 0; p.tsm_div = tsm_div; p.ldo = ldo;
-        p.tile = net->tiles[li] ? net->tiles[li] : (net->math == ADAF_MATH_F32_SPLIT_BF16 ? 40 : 0);
+        // the split plan's stage 1 is on the fp32 pipe BY LAYER (convs 1..11: layer1.* and layer2.0.conv1, the launches the fused forms
+        // cover), whether or not the fused launches are taken for this batch size / shift / fusion setting: a patch's features must not
+        // depend on the batch it came in
+        const bool split_here = net->math == ADAF_MATH_F32_SPLIT_BF16 && !(stage1_f32 && li >= 1 && li <= 11);
+        p.tile = net->tiles[li] ? net->tiles[li] : (split_here ? 40 : 0);
         ConvArgs a;
         int rc = make_conv_args(h, &p, in, L.w, L.scale, L.bias, res, out, &a);
         if (rc) return rc;
-        a.wsp = net->math == ADAF_MATH_F32_SPLIT_BF16 ? L.wsp : nullptr;
+        a.wsp = split_here ? L.wsp : nullptr;
         const double macs = (double)a.M * L.cout * L.k * L.k * L.cin;   // algorithmic: un-padded cin
         const double bytes = 4.0 * ((double)n * hh * ww * L.cin + (double)a.M * L.cout * (res ? 2 : 1) + (double)L.cout * L.k * L.k * L.cin);
         mark(2.0 * macs, bytes, 0);
