@@ -141,9 +141,11 @@ void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s);
 // mbconv_whole.hip: whole-image MBConv blocks (EfficientNet, fp16 storage)
 size_t adaf_mbw_bfrag_halfs(int n, int k, bool even_tiles);
 void adaf_launch_pack_bfrag_f16(const float* w, int n, int k, bool even_tiles, void* o, hipStream_t s);
+int adaf_mbw_tap_row(int k);       // floats per channel in the depthwise operand rows: k*k taps + BN scale + BN bias, padded to 16 bytes
+void adaf_launch_pack_dw_rows(const float* wd, const float* sd, const float* bd, int hid, int k, float* o, hipStream_t s);
 bool adaf_mbw_eligible(int hw, int k, int stride, int cin, int hid, int cout, int sq);
 bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
-                              const float* be, const float* wd, const float* sd, const float* bd, const float* se_wr, const float* se_br,
+                              const float* be, const float* wdl, const float* se_wr, const float* se_br,
                               const float* se_wet, const float* se_be, const void* wpf, const float* sp, const float* bp, bool skip, void* out,
                               hipStream_t s);
 

@@ -1581,6 +1581,7 @@ struct EfBlock {
     float* se_be = nullptr;         // [hid]
     void* wef = nullptr;            // fp16 storage: expand / project filters in MFMA B-fragment order for the whole-block kernel
     void* wpf = nullptr;            //  (mbconv_whole.hip)
+    float* wdl = nullptr;           //  ... and the depthwise taps + folded BN as one row per channel
 };
 
 struct adaf_effnet {
@@ -1595,6 +1596,26 @@ struct adaf_effnet {
     // stride 1, maps up to 9 x 9).  On by default; adaf_effnet_set_fusion(net, 0) restores the four-launch plan (tests, A/B).
     bool fuse = true;
     bool finalized = false;
+    // Every derived weight buffer (packed filters, folded BN, SE matrices, B fragments) is carved out of a few large slabs: a
+    // launch of the whole-block kernel reads ~14 of them, and as separate small hipMalloc()s each sat in pages of its own.
+    std::vector<void*> slabs;
+    char* slab_cur = nullptr;
+    size_t slab_left = 0;
+    void* carve(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > slab_left) {
+            const size_t sz = bytes > ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
+            void* p = nullptr;
+            if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
+            slabs.push_back(p);
+            slab_cur = static_cast<char*>(p);
+            slab_left = sz;
+        }
+        void* r = slab_cur;
+        slab_cur += bytes;
+        slab_left -= bytes;
+        return r;
+    }
 };
 
 namespace {
@@ -1739,20 +1760,7 @@ int adaf_effnet_create(adaf_handle* h, float width_coefficient, float depth_coef
 
 int adaf_effnet_destroy(adaf_effnet* net) {
     if (!net) return ADAF_OK;
-    for (auto& L : net->convs) {
-        if (L.w) (void)hipFree(L.w);
-        if (L.w16) (void)hipFree(L.w16);
-        if (L.scale) (void)hipFree(L.scale);
-        if (L.bias) (void)hipFree(L.bias);
-    }
-    for (auto& b : net->blocks) {
-        if (b.se_wr) (void)hipFree(b.se_wr);
-        if (b.se_br) (void)hipFree(b.se_br);
-        if (b.se_wet) (void)hipFree(b.se_wet);
-        if (b.se_be) (void)hipFree(b.se_be);
-        if (b.wef) (void)hipFree(b.wef);
-        if (b.wpf) (void)hipFree(b.wpf);
-    }
+    for (void* p : net->slabs) (void)hipFree(p);
     delete net;
     return ADAF_OK;
 }
@@ -1842,7 +1850,7 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
         return ADAF_OK;
     };
     auto alloc = [&](float** p, size_t count) -> int {
-        if (!*p && hipMalloc(reinterpret_cast<void**>(p), count * sizeof(float)) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+        if (!*p && !(*p = static_cast<float*>(net->carve(count * sizeof(float))))) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
         return ADAF_OK;
     };
     for (auto& L : net->convs) {
@@ -1859,7 +1867,7 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
         if (L.dw) adaf_launch_pack_dw_kxk(w, L.cout, L.k, L.w, st);
         else adaf_launch_pack_weight(w, L.cout, L.cin, L.k, L.k, L.cin_pad, L.w, st);
         if (!L.dw && L.k == 1 && net->dtype == ADAF_DTYPE_F16) {
-            if (!L.w16 && hipMalloc(&L.w16, wn * sizeof(unsigned short)) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            if (!L.w16 && !(L.w16 = net->carve(wn * sizeof(unsigned short)))) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
             adaf_launch_pack_weight_f16(w, L.cout, L.cin, 1, 1, L.cin_pad, L.w16, st);
         }
         adaf_launch_fold_bn(g, b, m, v, 1e-3f, L.cout, L.scale, L.bias, st);     // utils.py: batch_norm_epsilon = 1e-3
@@ -1886,10 +1894,13 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
             if ((rc = get(net->convs[b.expand].name + ".weight", (size_t)b.hid * b.cin, &wexp)) ||
                 (rc = get(net->convs[b.project].name + ".weight", (size_t)b.cout * b.hid, &wproj)))
                 return rc;
-            if (!b.wef && hipMalloc(&b.wef, adaf_mbw_bfrag_halfs(b.hid, b.cin, true) * 2) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
-            if (!b.wpf && hipMalloc(&b.wpf, adaf_mbw_bfrag_halfs(b.cout, b.hid, false) * 2) != hipSuccess) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            if (!b.wef && !(b.wef = net->carve(adaf_mbw_bfrag_halfs(b.hid, b.cin, true) * 2))) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            if (!b.wpf && !(b.wpf = net->carve(adaf_mbw_bfrag_halfs(b.cout, b.hid, false) * 2))) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
             adaf_launch_pack_bfrag_f16(wexp, b.hid, b.cin, true, b.wef, st);
             adaf_launch_pack_bfrag_f16(wproj, b.cout, b.hid, false, b.wpf, st);
+            if (!b.wdl && !(b.wdl = static_cast<float*>(net->carve((size_t)b.hid * adaf_mbw_tap_row(b.k) * 4)))) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            const EfConv& D = net->convs[b.dwc];
+            adaf_launch_pack_dw_rows(D.w, D.scale, D.bias, b.hid, b.k, b.wdl, st);
         }
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -1962,7 +1973,7 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             if (f16 && net->fuse && (plan & ADAF_EF_PLAN_WHOLE_BLOCK) && b.expand >= 0 && b.wef && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1) {
                 // maps small enough for a workgroup to own whole images: the block as ONE launch (mbconv_whole.hip)
                 const EfConv& E = net->convs[b.expand];
-                if (adaf_launch_mbconv_whole(cur, nc, hw, b.cin, b.hid, b.cout, b.sq, b.k, b.wef, E.scale, E.bias, D.w, D.scale, D.bias, b.se_wr,
+                if (adaf_launch_mbconv_whole(cur, nc, hw, b.cin, b.hid, b.cout, b.sq, b.k, b.wef, E.scale, E.bias, b.wdl, b.se_wr,
                                              b.se_br, b.se_wet, b.se_be, b.wpf, P.scale, P.bias, skip, nxt, st)) {
                     char* t = cur; cur = nxt; nxt = t;
                     out_elems = (size_t)hw * hw * b.cout;

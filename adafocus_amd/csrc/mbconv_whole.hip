@@ -58,9 +58,7 @@ struct MbwArgs {
     const u32x4* wef;        // expand filter in B-fragment order [NT2][KS][64] x 16 B (NT2 = tiles rounded up to even; zero padded)
     const float* se;         // expand BN [hid]
     const float* be;
-    const float* wd;         // depthwise taps [K*K][hid]
-    const float* sd;         // depthwise BN [hid]
-    const float* bd;
+    const float* wdl;        // depthwise operands, one row per channel [hid][TP]: K*K taps, BN scale, BN bias, zeros (TP = 12 / 28)
     const float* se_wr;      // [sq][hid]
     const float* se_br;      // [sq]
     const float* se_wet;     // [sq][hid] (transposed _se_expand.weight)
@@ -72,7 +70,17 @@ struct MbwArgs {
     int KS, KSP, NTP, NPAIR; // expand k steps (of 16), project k steps, project column tiles, channel pairs (of 64)
     int xpitch, dpitch;      // LDS row pitches in bytes
     int d_off;               // byte offset of D in the dynamic LDS (X and, later, mean / gate / squeezed vector come first)
+#ifdef MBW_TRACE
+    unsigned long long* trace;   // [blocks][waves][16] s_memtime stamps (tools/mbw_trace.py; never compiled into the shipped library)
+#endif
 };
+
+// Trace build (tools/exp/build_mbw_trace.sh, -DMBW_TRACE): lane 0 of every wave stamps s_memtime at the phase boundaries.
+#ifdef MBW_TRACE
+#define MBW_STAMP(slot_) do { if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * kMbwWaves + wave) * 16 + (slot_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MBW_STAMP(slot_) do { } while (0)
+#endif
 
 template <int HW, int K, int G>
 __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs a) {
@@ -90,6 +98,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     char* xl = dsm;
     char* dl = dsm + a.d_off;
     const int hid = a.hid;
+    MBW_STAMP(0);
 
     // ---- phase 0: X -> LDS ----
     // (all global loads of this kernel are UNCONDITIONAL loads from clamped addresses, in straight-line batches: hipcc puts an
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         }
     }
     __syncthreads();
+    MBW_STAMP(1);
 
     // row of band b this lane feeds the MFMAs with (rows past the last pixel repeat the last row: their results are never used)
     int xoff[NB], doff[NB];
@@ -136,14 +146,12 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         for (int g = 0; g < G; ++g) psr[q][g] = 0.f;
     {
         const int KS = a.KS;
+        // (KS is a whole number of chunks: plan_mbw pads it, the packed filter and the LDS rows carry zeros there)
         auto load_b = [&](u32x4 (&dst)[2][KC], int jp, int k0) {
             const u32x4* p0 = a.wef + ((size_t)(2 * jp) * KS + k0) * 64 + lane;
             const u32x4* p1 = p0 + (size_t)KS * 64;
 #pragma unroll
-            for (int u = 0; u < KC; ++u) {
-                const int uu = k0 + u < KS ? u : 0;          // (a partial last chunk repeats its first step; the products are skipped)
-                dst[0][u] = p0[uu * 64]; dst[1][u] = p1[uu * 64];
-            }
+            for (int u = 0; u < KC; ++u) { dst[0][u] = p0[u * 64]; dst[1][u] = p1[u * 64]; }
         };
         // Every workgroup of the launch streams the same filters; they start together, so without a stagger all CUs would ask the L2
         // for the same lines at the same time.  Workgroup b walks the channel pairs starting at pair `rot`.
@@ -157,11 +165,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             const int c = 64 * jp + lane;            // the channel this lane owns in the depthwise part
             const bool cok = c < hid;
             const int cc = cok ? c : 0;
-            // operands of the vector part: requested now, needed after the products
-            float w[K * K];
-#pragma unroll
-            for (int t = 0; t < K * K; ++t) w[t] = a.wd[(size_t)t * hid + cc];
-            const float sdl = a.sd[cc], bdl = a.bd[cc];
+            // BN of the expanded channels: requested now, needed right after the products
             const int ce0 = 64 * jp + nl, ce1 = ce0 + 32;      // the channels of this lane's accumulator columns
             const float sce0 = ce0 < hid ? a.se[ce0] : 0.f, bie0 = ce0 < hid ? a.be[ce0] : 0.f;
             const float sce1 = ce1 < hid ? a.se[ce1] : 0.f, bie1 = ce1 < hid ? a.be[ce1] : 0.f;
@@ -190,17 +194,31 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                         acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[1][u]), acc[1][b], 0, 0, 0);
                     }
             };
-            const int nfull = KS / KC, krem = KS - nfull * KC;
-            for (int c = 0; c < nfull; ++c) {
-                if ((c + 1) * KC < KS) load_b(bn, jp, (c + 1) * KC);
+            const int nchunk = KS / KC;
+            for (int c = 0; c < nchunk; ++c) {
+                if (c + 1 < nchunk) load_b(bn, jp, (c + 1) * KC);
                 mma_chunk(c * KC, std::integral_constant<int, KC>());
 #pragma unroll
                 for (int u = 0; u < KC; ++u) { bc[0][u] = bn[0][u]; bc[1][u] = bn[1][u]; }
             }
-            if (krem == 1) mma_chunk(nfull * KC, std::integral_constant<int, 1>());
-            else if (krem == 2) mma_chunk(nfull * KC, std::integral_constant<int, 2>());
             // the next pair's first fragments travel under the vector part
             if (li + kMbwWaves < a.NPAIR) load_b(bc, pair_of(li + kMbwWaves), 0);
+            // operands of the depthwise part (the channel's row: taps, BN scale, BN bias in TP / 4 16-byte loads): requested now,
+            // under the swish of the expanded map -- not before the products: 27 registers that are live across the K loop are
+            // the difference between spilling and not spilling, and a spill to scratch is an HBM write that every later
+            // s_waitcnt vmcnt of the wave waits for
+            constexpr int TP = (K * K + 2 + 3) / 4 * 4;
+            float w[TP];
+            {
+                const f32x4* wrow = reinterpret_cast<const f32x4*>(a.wdl + (size_t)cc * TP);
+#pragma unroll
+                for (int q = 0; q < TP / 4; ++q) {
+                    const f32x4 v = wrow[q];
+                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                }
+            }
+            const float sdl = w[K * K], bdl = w[K * K + 1];
+            if (rd < 2) MBW_STAMP(2 + 3 * rd);
 
             // BN + swish on the accumulators, rounded to the storage type (what the expand launch would have written)
 #pragma unroll
@@ -222,6 +240,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                     acc[0][b][i] = __uint_as_float(r[0]);
                     acc[1][b][i] = __uint_as_float(r[1]);
                 }
+            if (rd < 2) MBW_STAMP(3 + 3 * rd);
             // depthwise k x k + BN + swish out of registers: the map value of pixel p of image g
 #define MBW_M(g_, p_) acc[(((p_) & 31) >> 2) & 1][(g_) * RB + ((p_) >> 5)][((p_) & 3) + 4 * (((p_) & 31) >> 3)]
             if constexpr (G == 2) {
@@ -296,8 +315,10 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 for (int q = 0; q < kMbwMaxRounds; ++q) psr[q][0] = q == rd ? pst : psr[q][0];
             }
 #undef MBW_M
+            if (rd < 2) MBW_STAMP(4 + 3 * rd);
         }
     }
+    MBW_STAMP(8);
     // ---- phase 2: squeeze-and-excite (the arithmetic of se_gate_kernel) ----
     // The filter rows come from L2 and do not depend on this block's data, and every workgroup of the launch streams all of them:
     // the phase is bound by how many bytes a CU keeps in flight.  A batch is SEB rows per wave with every 16-byte piece requested
@@ -324,6 +345,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         };
         se_load(wave);
         __syncthreads();           // X is dead, D is complete
+        MBW_STAMP(9);
         {
             const float inv_hw = 1.f / (float)PX;
             const int rot = (int)((blockIdx.x * 5u) % (unsigned)a.NPAIR);
@@ -388,6 +410,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             for (int u = 0; u < GJB; ++u) wj[u] = *reinterpret_cast<const f32x4*>(wp + (size_t)(j0 + u < SQ ? j0 + u : SQ - 1) * hid);
         };
         gate_load(0);
+        MBW_STAMP(10);
         __syncthreads();
         {
             f32x4 sg[G];
@@ -416,7 +439,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             }
         }
     }
+    MBW_STAMP(11);
     __syncthreads();
+    MBW_STAMP(12);
 
     // ---- phase 3: D *= gate (fp32 product, rounded to fp16) ----
     {
@@ -439,7 +464,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             if (cq >= cpr) { cq -= cpr; ++row; }
         }
     }
+    MBW_STAMP(13);
     __syncthreads();
+    MBW_STAMP(14);
 
     // ---- phase 4: project 1x1 + BN (+ identity), one 32-column tile per wave iteration ----
     {
@@ -522,6 +549,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             }
         }
     }
+    MBW_STAMP(15);
 }
 
 // [N][K] fp32 (a 1x1 conv's OIHW filter) -> the B operand of v_mfma_f32_32x32x16_f16 in fragment order, fp16:
@@ -536,6 +564,9 @@ __global__ void pack_bfrag_f16_kernel(const float* __restrict__ w, int n, int k,
     o[idx] = (row < n && col < k) ? (_Float16)w[(size_t)row * k + col] : (_Float16)0.f;
 }
 
+// k steps of the expand GEMM: whole chunks of 3 (the K loop has no tail; the padding is zeros on both operands)
+int mbw_expand_ksteps(int cin) { return ((cin + 15) / 16 + 2) / 3 * 3; }
+
 struct MbwPlan { int G, KS, KSP, NTP, NPAIR, xpitch, dpitch, d_off; size_t lds; };
 
 constexpr size_t kLdsMax = 160 * 1024;
@@ -544,7 +575,7 @@ constexpr size_t kLdsMax = 160 * 1024;
 bool plan_mbw(int hw, int cin, int hid, int cout, int sq, int gmax, MbwPlan* p) {
     if (cin % 8 || hid % 16 || hid > 64 * kMbwWaves * kMbwMaxRounds) return false;
     const int px = hw * hw;
-    p->KS = (cin + 15) / 16;
+    p->KS = mbw_expand_ksteps(cin);
     p->KSP = hid / 16;
     p->NTP = (cout + 31) / 32;
     p->NPAIR = (hid + 63) / 64;
@@ -587,16 +618,39 @@ void launch_mbw_hw(const MbwArgs& a, int k, int g, size_t lds, hipStream_t s) {
 
 }  // namespace
 
+#ifdef MBW_TRACE
+static unsigned long long* adaf_mbw_trace_buf = nullptr;
+static int adaf_mbw_trace_hid = 0, adaf_mbw_trace_k = 0;
+extern "C" void adaf_mbw_set_trace(unsigned long long* p, int hid, int k) { adaf_mbw_trace_buf = p; adaf_mbw_trace_hid = hid; adaf_mbw_trace_k = k; }
+#endif
+
+// even_tiles: the expand filter (tiles in pairs, k steps in whole chunks); otherwise the project filter
 size_t adaf_mbw_bfrag_halfs(int n, int k, bool even_tiles) {
     int tiles = (n + 31) / 32;
     if (even_tiles) tiles = (tiles + 1) & ~1;
-    return (size_t)tiles * ((k + 15) / 16) * 512;
+    return (size_t)tiles * (even_tiles ? mbw_expand_ksteps(k) : (k + 15) / 16) * 512;
+}
+
+int adaf_mbw_tap_row(int k) { return (k * k + 2 + 3) / 4 * 4; }
+
+// depthwise taps [K*K][hid] + folded BN -> one row per channel [hid][TP]: taps, scale, bias, zeros
+__global__ void pack_dw_rows_kernel(const float* __restrict__ wd, const float* __restrict__ sd, const float* __restrict__ bd, int hid, int kk, int tp,
+                                    float* __restrict__ o) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= hid * tp) return;
+    const int c = idx / tp, t = idx - c * tp;
+    o[idx] = t < kk ? wd[(size_t)t * hid + c] : t == kk ? sd[c] : t == kk + 1 ? bd[c] : 0.f;
+}
+
+void adaf_launch_pack_dw_rows(const float* wd, const float* sd, const float* bd, int hid, int k, float* o, hipStream_t s) {
+    const int tp = adaf_mbw_tap_row(k);
+    hipLaunchKernelGGL(pack_dw_rows_kernel, dim3((unsigned)((hid * tp + 255) / 256)), dim3(256), 0, s, wd, sd, bd, hid, k * k, tp, o);
 }
 
 void adaf_launch_pack_bfrag_f16(const float* w, int n, int k, bool even_tiles, void* o, hipStream_t s) {
     int tiles = (n + 31) / 32;
     if (even_tiles) tiles = (tiles + 1) & ~1;
-    const int ks = (k + 15) / 16;
+    const int ks = even_tiles ? mbw_expand_ksteps(k) : (k + 15) / 16;
     const long long total = (long long)tiles * ks * 512;
     hipLaunchKernelGGL(pack_bfrag_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, n, k, tiles, ks, static_cast<_Float16*>(o));
 }
@@ -609,7 +663,7 @@ bool adaf_mbw_eligible(int hw, int k, int stride, int cin, int hid, int cout, in
 
 // one launch for a whole MBConv block (fp16 storage, stride 1, map hw x hw); false = not eligible, nothing launched
 bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
-                              const float* be, const float* wd, const float* sd, const float* bd, const float* se_wr, const float* se_br,
+                              const float* be, const float* wdl, const float* se_wr, const float* se_br,
                               const float* se_wet, const float* se_be, const void* wpf, const float* sp, const float* bp, bool skip, void* out,
                               hipStream_t s) {
     if (!adaf_mbw_eligible(hw, k, 1, cin, hid, cout, sq) || n <= 0) return false;
@@ -618,10 +672,13 @@ bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, in
     MbwArgs a;
     memset(&a, 0, sizeof(a));
     a.x = static_cast<const _Float16*>(x); a.res = skip ? a.x : nullptr; a.out = static_cast<_Float16*>(out);
-    a.wef = static_cast<const u32x4*>(wef); a.se = se; a.be = be; a.wd = wd; a.sd = sd; a.bd = bd;
+    a.wef = static_cast<const u32x4*>(wef); a.se = se; a.be = be; a.wdl = wdl;
     a.se_wr = se_wr; a.se_br = se_br; a.se_wet = se_wet; a.se_be = se_be;
     a.wpf = static_cast<const u32x4*>(wpf); a.sp = sp; a.bp = bp;
     a.n = n; a.cin = cin; a.hid = hid; a.cout = cout; a.sq = sq;
+#ifdef MBW_TRACE
+    a.trace = (adaf_mbw_trace_hid == 0 || adaf_mbw_trace_hid == hid) && adaf_mbw_trace_k == k ? adaf_mbw_trace_buf : nullptr;
+#endif
     a.KS = p.KS; a.KSP = p.KSP; a.NTP = p.NTP; a.NPAIR = p.NPAIR; a.xpitch = p.xpitch; a.dpitch = p.dpitch; a.d_off = p.d_off;
     switch (hw) {
         case 3: launch_mbw_hw<3>(a, k, p.G, p.lds, s); break;
