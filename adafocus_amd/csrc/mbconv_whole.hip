@@ -68,6 +68,7 @@ struct MbwArgs {
     const float* bp;
     int n, cin, hid, cout, sq;
     int KS, KSP, NTP, NPAIR; // expand k steps (of 16), project k steps, project column tiles, channel pairs (of 64)
+    int KSPP;                // project k steps padded to whole chunks of 6 (the packed filter carries zero fragments there)
     int xpitch, dpitch;      // LDS row pitches in bytes
     int d_off;               // byte offset of D in the dynamic LDS (X and, later, mean / gate / squeezed vector come first)
 #ifdef MBW_TRACE
@@ -89,7 +90,6 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     constexpr int NB = G * RB;
     constexpr int P = (K - 1) / 2;             // SAME padding at stride 1 is symmetric
     constexpr int KC = 3;                      // k steps per prefetched chunk of B fragments (expand)
-    constexpr int KCP = 4;                     // ... (project)
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, half = lane >> 5;
@@ -157,8 +157,13 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         // for the same lines at the same time.  Workgroup b walks the channel pairs starting at pair `rot`.
         const int rot = (int)((blockIdx.x * 5u) % (unsigned)a.NPAIR);
         auto pair_of = [&](int li) { const int j = li + rot; return j >= a.NPAIR ? j - a.NPAIR : j; };
-        u32x4 bc[2][KC], bn[2][KC];
-        if (wave < a.NPAIR) load_b(bc, pair_of(wave), 0);
+        // Three sets of B fragments with FIXED roles per unrolled step (no hand-over copies: a copy out of the set that was loaded last
+        // is a wait for the newest load, i.e. one chunk of cover however many sets there are): a pair starts with its chunks 0 and 1 in
+        // sets 0 and 1, chunk c + 2 is requested before the products of chunk c.
+        const int nchunk = KS / KC;
+        u32x4 bs[3][2][KC];
+        auto load_pair_head = [&](int jp) { load_b(bs[0], jp, 0); if (nchunk > 1) load_b(bs[1], jp, KC); };
+        if (wave < a.NPAIR) load_pair_head(pair_of(wave));
         int rd = 0;
         for (int li = wave; li < a.NPAIR; li += kMbwWaves, ++rd) {
             const int jp = pair_of(li);
@@ -179,30 +184,37 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                     for (int i = 0; i < 16; ++i) acc[t][b][i] = 0.f;
             // K loop in chunks of KC steps, branch-free inside a chunk: every A fragment of the chunk is requested from LDS before its
             // first product (a read -> wait -> product sequence per step leaves the matrix pipe idle for an LDS round trip each time)
-            auto mma_chunk = [&](int k0, auto ns_tag) {
-                constexpr int NS = decltype(ns_tag)::value;
-                f16x8 af[NS][NB];
+            auto mma_chunk = [&](int k0, const u32x4 (&bb)[2][KC]) {
+                f16x8 af[KC][NB];
 #pragma unroll
-                for (int u = 0; u < NS; ++u)
+                for (int u = 0; u < KC; ++u)
 #pragma unroll
                     for (int b = 0; b < NB; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(xl + xoff[b] + (k0 + u) * 32);
 #pragma unroll
-                for (int u = 0; u < NS; ++u)
+                for (int u = 0; u < KC; ++u)
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[0][u]), acc[0][b], 0, 0, 0);
-                        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[1][u]), acc[1][b], 0, 0, 0);
+                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bb[0][u]), acc[0][b], 0, 0, 0);
+                        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bb[1][u]), acc[1][b], 0, 0, 0);
                     }
             };
-            const int nchunk = KS / KC;
-            for (int c = 0; c < nchunk; ++c) {
-                if (c + 1 < nchunk) load_b(bn, jp, (c + 1) * KC);
-                mma_chunk(c * KC, std::integral_constant<int, KC>());
-#pragma unroll
-                for (int u = 0; u < KC; ++u) { bc[0][u] = bn[0][u]; bc[1][u] = bn[1][u]; }
+            {
+                int c = 0;
+                for (; c + 3 <= nchunk; c += 3) {
+                    load_b(bs[2], jp, (c + 2) * KC);
+                    mma_chunk(c * KC, bs[0]);
+                    if (c + 3 < nchunk) load_b(bs[0], jp, (c + 3) * KC);
+                    mma_chunk((c + 1) * KC, bs[1]);
+                    if (c + 4 < nchunk) load_b(bs[1], jp, (c + 4) * KC);
+                    mma_chunk((c + 2) * KC, bs[2]);
+                }
+                if (c < nchunk) {
+                    mma_chunk(c * KC, bs[0]);
+                    if (c + 1 < nchunk) mma_chunk((c + 1) * KC, bs[1]);
+                }
             }
-            // the next pair's first fragments travel under the vector part
-            if (li + kMbwWaves < a.NPAIR) load_b(bc, pair_of(li + kMbwWaves), 0);
+            // the next pair's first two chunks travel under the vector part
+            if (li + kMbwWaves < a.NPAIR) load_pair_head(pair_of(li + kMbwWaves));
             // operands of the depthwise part (the channel's row: taps, BN scale, BN bias in TP / 4 16-byte loads): requested now,
             // under the swish of the expanded map -- not before the products: 27 registers that are live across the K loop are
             // the difference between spilling and not spilling, and a spill to scratch is an HBM write that every later
@@ -225,6 +237,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
+                    // (registers i, i + 1 of band b hold rows 32 (b % RB) + (i & 3) + 8 (i >> 2) [+ 1] (+ 4 in the upper half-wave):
+                    // a pair whose first row is past the image is never read by the depthwise part)
+                    if ((b % RB) * 32 + (i & 3) + 8 * (i >> 2) >= PX) continue;
                     const f32x2 t0 = w_swish2(w_fma2(f32x2{acc[0][b][i], acc[0][b][i + 1]}, sce0, bie0));
                     const f32x2 t1 = w_swish2(w_fma2(f32x2{acc[1][b][i], acc[1][b][i + 1]}, sce1, bie1));
                     acc[0][b][i] = (float)adaf_f16_of(t0.x); acc[0][b][i + 1] = (float)adaf_f16_of(t0.y);
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
+                    if ((b % RB) * 32 + (i & 3) + 8 * (i >> 2) >= PX) continue;
                     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][b][i]), __float_as_uint(acc[1][b][i]), false, false);
                     acc[0][b][i] = __uint_as_float(r[0]);
                     acc[1][b][i] = __uint_as_float(r[1]);
@@ -443,6 +459,27 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     __syncthreads();
     MBW_STAMP(12);
 
+    // ---- the first two chunks of filter fragments of this wave's first column tile of phase 4 are requested HERE, ahead of phase 3:
+    // they do not depend on the gate, and phase 3 + its barrier is longer than their round trip ----
+    constexpr int KCP = 6;                     // k steps per chunk of B fragments (project); three chunks deep
+    const int KSP = a.KSP, KSPP = a.KSPP;      // real k steps / padded to whole chunks (zero fragments in the packed filter)
+    const _Float16* __restrict__ resb = a.res ? a.res + (size_t)img0 * PX * a.cout : nullptr;
+    _Float16* __restrict__ outb = a.out + (size_t)img0 * PX * a.cout;
+    const int rotp = (int)((blockIdx.x * 3u) % (unsigned)a.NTP);
+    u32x4 pb[3][KCP];                          // three sets with fixed roles per unrolled step, like the expand loop
+    auto tile_of = [&](int lt) { return lt + rotp >= a.NTP ? lt + rotp - a.NTP : lt + rotp; };
+    auto load_p = [&](u32x4 (&dst)[KCP], int nt, int k0) {
+        const u32x4* bp0 = a.wpf + (size_t)nt * KSPP * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < KCP; ++u) dst[u] = bp0[(k0 + u < KSPP ? k0 + u : KSPP - 1) * 64];
+    };
+    auto issue_tile = [&](int lt) {
+        const int nt = tile_of(lt);
+        load_p(pb[0], nt, 0);
+        load_p(pb[1], nt, KCP);
+    };
+    if (wave < a.NTP) issue_tile(wave);
+
     // ---- phase 3: D *= gate (fp32 product, rounded to fp16) ----
     {
         const int cpr = hid >> 3;                     // 16-byte chunks per row
@@ -469,85 +506,83 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     MBW_STAMP(14);
 
     // ---- phase 4: project 1x1 + BN (+ identity), one 32-column tile per wave iteration ----
-    {
-        const int KSP = a.KSP;
-        const _Float16* __restrict__ resb = a.res ? a.res + (size_t)img0 * PX * a.cout : nullptr;
-        _Float16* __restrict__ outb = a.out + (size_t)img0 * PX * a.cout;
-        const int rotp = (int)((blockIdx.x * 3u) % (unsigned)a.NTP);
-        for (int lt = wave; lt < a.NTP; lt += kMbwWaves) {
-            const int nt = lt + rotp >= a.NTP ? lt + rotp - a.NTP : lt + rotp;
-            const u32x4* bp0 = a.wpf + (size_t)nt * KSP * 64 + lane;
-            // B fragments three chunks of KCP steps deep (this phase is bound by the matrix pipe and by how many bytes a wave keeps in flight)
-            u32x4 bc[KCP], bn[KCP], bnn[KCP];
-            auto load_p = [&](u32x4 (&dst)[KCP], int k0) {
-#pragma unroll
-                for (int u = 0; u < KCP; ++u) dst[u] = bp0[(k0 + u < KSP ? k0 + u : KSP - 1) * 64];
-            };
-            load_p(bc, 0);
-            load_p(bn, KCP);
-            // the identity rows of this tile travel under the products (one 2-byte load per output of the lane)
-            const int ncol = nt * 32 + nl;
-            const bool nok = ncol < a.cout;
-            const int obase = 4 * half * a.cout + (nok ? ncol : 0);
-            // (unconditional loads from clamped addresses -- a load inside a per-lane branch is followed by its own s_waitcnt, and 41 of
-            // those in a row were most of this phase's time; values of pixels that do not exist are never stored)
-            _Float16 rv[NB][16];
-            if (resb) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);          // pixel of the h = 0 lanes; h = 1: + 4
-                        const bool ok = b / RB < nimg && pr + 4 * half < PX;
-                        rv[b][i] = resb[ok ? obase + ((b / RB) * PX + pr) * a.cout : 0];
-                    }
-            } else {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) rv[b][i] = (_Float16)0.f;
-            }
-            f32x16 acc[NB];
+    // K loop in chunks of KCP steps, three chunks of B fragments in flight (a chunk's 18 products are shorter than an L2 round trip);
+    // the padding steps multiply real (finite) D columns by zero fragments
+    for (int lt = wave; lt < a.NTP; lt += kMbwWaves) {
+        const int nt = tile_of(lt);
+        const int ncol = nt * 32 + nl;
+        const bool nok = ncol < a.cout;
+        const int obase = 4 * half * a.cout + (nok ? ncol : 0);
+        // the identity rows of this tile travel under the products (one 2-byte load per output of the lane; unconditional loads from
+        // clamped addresses -- a load inside a per-lane branch is followed by its own s_waitcnt, and 41 of those in a row were most of
+        // this phase's time; values of pixels that do not exist are never stored)
+        _Float16 rv[NB][16];
+        if (resb) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-            auto mma_chunk = [&](int k0, auto ns_tag) {
-                constexpr int NS = decltype(ns_tag)::value;
-                f16x8 af[NS][NB];
+                for (int i = 0; i < 16; ++i) {
+                    const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);          // pixel of the h = 0 lanes; h = 1: + 4
+                    const bool ok = b / RB < nimg && pr + 4 * half < PX;
+                    rv[b][i] = resb[ok ? obase + ((b / RB) * PX + pr) * a.cout : 0];
+                }
+        } else {
 #pragma unroll
-                for (int u = 0; u < NS; ++u)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(dl + doff[b] + (k0 + u) * 32);
+                for (int i = 0; i < 16; ++i) rv[b][i] = (_Float16)0.f;
+        }
+        f32x16 acc[NB];
 #pragma unroll
-                for (int u = 0; u < NS; ++u)
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        const int npc = KSPP / KCP;
+        auto mma_p = [&](int k0, const u32x4 (&bb)[KCP]) {
+#pragma unroll
+            for (int h = 0; h < KCP; h += 3) {
+                f16x8 af[3][NB];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int kk = k0 + h + u < KSP ? k0 + h + u : KSP - 1;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(dl + doff[b] + kk * 32);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bc[u]), acc[b], 0, 0, 0);
-            };
-            const int nfull = KSP / KCP, krem = KSP - nfull * KCP;
-            for (int c = 0; c < nfull; ++c) {
-                load_p(bnn, (c + 2) * KCP);
-                mma_chunk(c * KCP, std::integral_constant<int, KCP>());
-#pragma unroll
-                for (int u = 0; u < KCP; ++u) { bc[u] = bn[u]; bn[u] = bnn[u]; }
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bb[h + u]), acc[b], 0, 0, 0);
             }
-            if (krem == 1) mma_chunk(nfull * KCP, std::integral_constant<int, 1>());
-            else if (krem == 2) mma_chunk(nfull * KCP, std::integral_constant<int, 2>());
-            else if (krem == 3) mma_chunk(nfull * KCP, std::integral_constant<int, 3>());
-            if (nok) {
-                const float sc = a.sp[ncol], bi = a.bp[ncol];
+        };
+        {
+            int c = 0;
+            for (; c + 3 <= npc; c += 3) {
+                load_p(pb[2], nt, (c + 2) * KCP);
+                mma_p(c * KCP, pb[0]);
+                if (c + 3 < npc) load_p(pb[0], nt, (c + 3) * KCP);
+                mma_p((c + 1) * KCP, pb[1]);
+                if (c + 4 < npc) load_p(pb[1], nt, (c + 4) * KCP);
+                mma_p((c + 2) * KCP, pb[2]);
+            }
+            if (c < npc) {
+                mma_p(c * KCP, pb[0]);
+                if (c + 1 < npc) mma_p((c + 1) * KCP, pb[1]);
+            }
+        }
+        if (nok) {
+            const float sc = a.sp[ncol], bi = a.bp[ncol];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if (b / RB >= nimg) continue;
+            for (int b = 0; b < NB; ++b) {
+                if (b / RB >= nimg) continue;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);
-                        if (pr + 4 * half < PX) outb[obase + ((b / RB) * PX + pr) * a.cout] = adaf_f16_of(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);
+                    if (pr + 4 * half < PX) outb[obase + ((b / RB) * PX + pr) * a.cout] = adaf_f16_of(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
                 }
             }
         }
+        if (lt + kMbwWaves < a.NTP) issue_tile(lt + kMbwWaves);
     }
     MBW_STAMP(15);
 }
@@ -566,6 +601,8 @@ __global__ void pack_bfrag_f16_kernel(const float* __restrict__ w, int n, int k,
 
 // k steps of the expand GEMM: whole chunks of 3 (the K loop has no tail; the padding is zeros on both operands)
 int mbw_expand_ksteps(int cin) { return ((cin + 15) / 16 + 2) / 3 * 3; }
+// ... of the project GEMM's packed filter: whole chunks of 6
+int mbw_project_ksteps(int hid) { return ((hid + 15) / 16 + 5) / 6 * 6; }
 
 struct MbwPlan { int G, KS, KSP, NTP, NPAIR, xpitch, dpitch, d_off; size_t lds; };
 
@@ -628,7 +665,7 @@ extern "C" void adaf_mbw_set_trace(unsigned long long* p, int hid, int k) { adaf
 size_t adaf_mbw_bfrag_halfs(int n, int k, bool even_tiles) {
     int tiles = (n + 31) / 32;
     if (even_tiles) tiles = (tiles + 1) & ~1;
-    return (size_t)tiles * (even_tiles ? mbw_expand_ksteps(k) : (k + 15) / 16) * 512;
+    return (size_t)tiles * (even_tiles ? mbw_expand_ksteps(k) : mbw_project_ksteps(k)) * 512;
 }
 
 int adaf_mbw_tap_row(int k) { return (k * k + 2 + 3) / 4 * 4; }
@@ -650,7 +687,7 @@ void adaf_launch_pack_dw_rows(const float* wd, const float* sd, const float* bd,
 void adaf_launch_pack_bfrag_f16(const float* w, int n, int k, bool even_tiles, void* o, hipStream_t s) {
     int tiles = (n + 31) / 32;
     if (even_tiles) tiles = (tiles + 1) & ~1;
-    const int ks = even_tiles ? mbw_expand_ksteps(k) : (k + 15) / 16;
+    const int ks = even_tiles ? mbw_expand_ksteps(k) : mbw_project_ksteps(k);
     const long long total = (long long)tiles * ks * 512;
     hipLaunchKernelGGL(pack_bfrag_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, n, k, tiles, ks, static_cast<_Float16*>(o));
 }
@@ -679,7 +716,7 @@ bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, in
 #ifdef MBW_TRACE
     a.trace = (adaf_mbw_trace_hid == 0 || adaf_mbw_trace_hid == hid) && adaf_mbw_trace_k == k ? adaf_mbw_trace_buf : nullptr;
 #endif
-    a.KS = p.KS; a.KSP = p.KSP; a.NTP = p.NTP; a.NPAIR = p.NPAIR; a.xpitch = p.xpitch; a.dpitch = p.dpitch; a.d_off = p.d_off;
+    a.KS = p.KS; a.KSP = p.KSP; a.KSPP = mbw_project_ksteps(hid); a.NTP = p.NTP; a.NPAIR = p.NPAIR; a.xpitch = p.xpitch; a.dpitch = p.dpitch; a.d_off = p.d_off;
     switch (hw) {
         case 3: launch_mbw_hw<3>(a, k, p.G, p.lds, s); break;
         case 4: launch_mbw_hw<4>(a, k, p.G, p.lds, s); break;
