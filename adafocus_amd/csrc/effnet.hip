@@ -137,7 +137,21 @@ struct DwArgs {
     const float* xscale; // the expand BN [C]
     const float* xbias;
     int cin;
+#ifdef EF_TRACE
+    unsigned long long* trace;   // [blocks][4 waves][8] s_memtime stamps (tools/dw_trace.py; never compiled into the shipped library)
+#endif
 };
+
+// Trace build (tools/exp/build_mbw_trace.sh with EF_TRACE): lane 0 of every wave stamps s_memtime at the phase boundaries.
+#ifdef EF_TRACE
+#define EF_STAMP(slot_) do { if (a.trace && (threadIdx.x & 63) == 0) a.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EF_STAMP(slot_) do { } while (0)
+#endif
+#ifdef EF_TRACE
+static unsigned long long* ef_trace_buf = nullptr;
+static int ef_trace_c = 0, ef_trace_k = 0, ef_trace_s = 0;
+#endif
 
 //
 // XN > 0 (fp16 storage): the EXPAND conv of the MBConv block runs inside the staging step -- the 6x-expanded map never exists in HBM (it
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
+    EF_STAMP(0);
     {
         // XCD-aware, bijective remap (the hardware places block b on XCD b % 8): every XCD gets a contiguous range of work
         // items, so the channel slices of one tile -- which read interleaved 16 LPP-byte pieces of the same pixels -- and
@@ -180,11 +195,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     char* xin = dsm;                                                         // [IMB][ihmax][WP][pitch16 * 16 B]
     float* wl = reinterpret_cast<float*>(dsm + (size_t)a.IMB * img_lds);     // [K*K][CS] taps
     float* sbl = wl + K * K * a.CS;                                          // [2][CS] BN scale, bias
-    for (int i = tid; i < K * K * a.CS; i += 256) {
-        const int tap = i / a.CS;
-        wl[i] = a.wt[(size_t)tap * a.C + c0 + (i - tap * a.CS)];
+    // Prologue: EVERY global load that does not depend on another one is requested before the first is used (taps, BN, and below the
+    // expand filter rows and the first batch of window pixels).  As a sequence of load -> LDS-store loops this was four to five L2
+    // round trips in a row, 5-9 k cycles of a 21-35 k cycle workgroup (tools/dw_trace.py).  (CS <= 64: at most NTW values per thread)
+    constexpr int NTW = (K * K * 64 + 255) / 256;
+    float tw[NTW];
+    {
+        const FastDiv dcs(a.CS);
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            const int i = tid + 256 * u;
+            const int ic = i < K * K * a.CS ? i : 0;
+            const int tap = dcs.div(ic);
+            tw[u] = a.wt[(size_t)tap * a.C + c0 + (ic - tap * a.CS)];
+        }
     }
-    for (int i = tid; i < 2 * a.CS; i += 256) sbl[i] = i < a.CS ? a.scale[c0 + i] : a.bias[c0 + i - a.CS];
+    const float sbv = tid < a.CS ? a.scale[c0 + tid] : a.bias[c0 + (tid < 2 * a.CS ? tid - a.CS : 0)];      // (2 CS <= 128 threads carry one)
+    auto store_taps = [&]() {
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+            if (tid + 256 * u < K * K * a.CS) wl[tid + 256 * u] = tw[u];
+        if (tid < 2 * a.CS) sbl[tid] = sbv;
+    };
+    if constexpr (XN == 0) store_taps();
     if constexpr (XN > 0) {
         static_assert(sizeof(T) == 2, "the fused expand is an fp16-storage path");
         const int lane = tid & 63, wave = tid >> 6;
@@ -194,11 +227,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         // the part of the window that lies inside the image: only those pixels are expanded; the SAME padding around them is zeros
         const int vr0 = max(0, -iy0), vr1 = min(ihn, a.H - iy0), vc0 = max(0, -ix0), vc1 = min(a.WP, a.W - ix0);
         const int vw = vc1 - vc0, nv = (vr1 - vr0) * vw;
-        if (nv < ihn * a.WP) {                                             // (block-uniform: tiles on the image border)
-            const int chunks = nimg * (img_lds >> 4);
-            for (int i = tid; i < chunks; i += 256) *reinterpret_cast<u32x4*>(xin + 16 * i) = u32x4{0u, 0u, 0u, 0u};
-            __syncthreads();
-        }
         u32x4 af[XN][KSX];
         f32x4 xs[XN], xb[XN];
 #pragma unroll
@@ -207,7 +235,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             for (int ks = 0; ks < KSX; ++ks) {
                 const int k0 = 32 * ks + 8 * kq;
                 af[rt][ks] = *reinterpret_cast<const u32x4*>(wx + (size_t)(16 * rt + px) * cin + (k0 < cin ? k0 : 0));
-                if (k0 >= cin) af[rt][ks] = u32x4{0u, 0u, 0u, 0u};
             }
             xs[rt] = *reinterpret_cast<const f32x4*>(a.xscale + c0 + 16 * rt + 4 * kq);
             xb[rt] = *reinterpret_cast<const f32x4*>(a.xbias + c0 + 16 * rt + 4 * kq);
@@ -266,6 +293,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         int dstA[GB], dstB[GB];
         constexpr int GSTEP = 4 * GB;
         if (wave < ngr) xload(wave, bfA, dstA);
+        // (everything above is in flight; now the LDS side of the prologue)
+        if (nv < ihn * a.WP) {                                             // (block-uniform: tiles on the image border)
+            const int chunks = nimg * (img_lds >> 4);
+            for (int i = tid; i < chunks; i += 256) *reinterpret_cast<u32x4*>(xin + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+        }
+        store_taps();
+        if (nv < ihn * a.WP) __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < XN; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks)
+                if (32 * ks + 8 * kq >= cin) af[rt][ks] = u32x4{0u, 0u, 0u, 0u};
+        EF_STAMP(1);
         for (int g0 = wave; g0 < ngr; g0 += 2 * GSTEP) {
             if (g0 + GSTEP < ngr) xload(g0 + GSTEP, bfB, dstB);
             xcompute(g0, bfA, dstA);
@@ -298,10 +338,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int iy = iy0 + row, ix = ix0 + col;
-                        v[u] = u32x4{0u, 0u, 0u, 0u};
                         off[u] = row < ihn ? loff : -1;
-                        if (row < ihn && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                            v[u] = *reinterpret_cast<const u32x4*>(xb + goff);
+                        // (an unconditional load from a clamped address: a load inside a per-lane branch gets its own s_waitcnt)
+                        const bool inb = row < ihn && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        v[u] = *reinterpret_cast<const u32x4*>(xb + (inb ? goff : 0));
+                        if (!inb) v[u] = u32x4{0u, 0u, 0u, 0u};
                         col += dcol; row += drow; loff += lstep; goff += gstep;
                         if (col >= a.WP) { col -= a.WP; ++row; goff += gwrap; }
                     }
@@ -312,7 +353,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             }
         }
     }
+    EF_STAMP(2);
     __syncthreads();
+    EF_STAMP(3);
     const int TPI = a.LPP * a.PG;            // threads per image
     const int im = tid / TPI, rem = tid - im * TPI;
     const int cg = rem % a.LPP, pg = rem / a.LPP;
@@ -389,6 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             if (xg >= nxg) { xg -= nxg; ++r; }
         }
     }
+    EF_STAMP(4);
     if (a.pool_part) {
         // squeeze: sum over the block's pixels per (image, channel), in a fixed order
         __syncthreads();
@@ -404,6 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
             a.pool_part[((size_t)(img0 + ri) * a.tiles + tile) * a.C + c0 + c] = s;
         }
     }
+    EF_STAMP(5);
 }
 
 // ---- depthwise k x k on TINY maps (H = W = HW <= 5: the last stages of the network; 5 x 5 at B3's 144^2 patches) -----------------
@@ -1341,6 +1386,10 @@ static bool launch_dw_small_t(const DsArgs& a, int K, int HW, hipStream_t s) {
 
 }  // namespace
 
+#ifdef EF_TRACE
+extern "C" void adaf_ef_set_trace(unsigned long long* p, int c, int k, int s) { ef_trace_buf = p; ef_trace_c = c; ef_trace_k = k; ef_trace_s = s; }
+#endif
+
 // Depthwise k x k (k = 3 | 5, stride 1 | 2), padding pad_t / pad_l before the first row / column and whatever the output
 // extent needs after the last; returns the number of partial-sum tiles per image (> 0) or < 0.
 // pool_part: [n][tiles][c] floats (adaf_effnet_dw_tiles() says how many) or nullptr.
@@ -1370,6 +1419,10 @@ int adaf_launch_dw_expand(const void* x, int n, int hh, int ww, int cin, const v
     memset(&a, 0, sizeof(a));
     a.x = x; a.out = out; a.wt = wt; a.scale = scale; a.bias = bias; a.pool_part = pool_part;
     a.xw = xw; a.xscale = xscale; a.xbias = xbias; a.cin = cin;
+#ifdef EF_TRACE
+    a.trace = (ef_trace_c == c && ef_trace_k == k && ef_trace_s == stride) ? ef_trace_buf : nullptr;
+    if (a.trace) fprintf(stderr, "dw trace: C %d k %d s %d  TH %d TWG %d tiles %d IMB %d PG %d LPP %d CS %d slices %d WP %d OXT %d lds %zu blocks %d\n", c, k, stride, p.TH, p.TWG, p.tiles, p.IMB, p.PG, p.LPP, p.CS, p.slices, p.WP, p.OXT, p.lds, ((n + p.IMB - 1) / p.IMB) * p.tiles * p.slices);
+#endif
     a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
     a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
     a.pitch16 = p.pitch16; a.WP = p.WP;
@@ -1395,6 +1448,10 @@ int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, 
     DwArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.out = out; a.wt = wt; a.scale = scale; a.bias = bias; a.pool_part = pool_part;
+#ifdef EF_TRACE
+    a.trace = (ef_trace_c == c && ef_trace_k == k && ef_trace_s == stride) ? ef_trace_buf : nullptr;
+    if (a.trace) fprintf(stderr, "dw trace: C %d k %d s %d  TH %d TWG %d tiles %d IMB %d PG %d LPP %d CS %d slices %d WP %d OXT %d lds %zu blocks %d\n", c, k, stride, p.TH, p.TWG, p.tiles, p.IMB, p.PG, p.LPP, p.CS, p.slices, p.WP, p.OXT, p.lds, ((n + p.IMB - 1) / p.IMB) * p.tiles * p.slices);
+#endif
     a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
     a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
     a.pitch16 = p.pitch16; a.WP = p.WP;

@@ -157,12 +157,20 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         // for the same lines at the same time.  Workgroup b walks the channel pairs starting at pair `rot`.
         const int rot = (int)((blockIdx.x * 5u) % (unsigned)a.NPAIR);
         auto pair_of = [&](int li) { const int j = li + rot; return j >= a.NPAIR ? j - a.NPAIR : j; };
-        // Three sets of B fragments with FIXED roles per unrolled step (no hand-over copies: a copy out of the set that was loaded last
-        // is a wait for the newest load, i.e. one chunk of cover however many sets there are): a pair starts with its chunks 0 and 1 in
-        // sets 0 and 1, chunk c + 2 is requested before the products of chunk c.
+        // B fragments: ONE set feeds the MFMAs (bcur); global loads land in two other sets (bl0 / bl1, alternating) and a chunk reaches
+        // bcur through a VALU copy after the products of the chunk before it.  So a chunk is requested two chunks ahead of its use
+        // (a chunk's products are shorter than an L2 round trip), and NO LOAD EVER TARGETS A REGISTER THAT AN MFMA READS.  The
+        // obvious form -- three sets with rotating roles, loads straight into the set the previous chunk's MFMAs have just read --
+        // gave results that differed from run to run on gfx950 (tools/exp/effnet_determinism.py; the compiler's waits were correct on
+        // every path): with several independent accumulator chains a wave's MFMAs are still queued when a load issued behind them
+        // returns.  VALU writes to MFMA operands are interlocked; returning loads, measurably, are not.
         const int nchunk = KS / KC;
-        u32x4 bs[3][2][KC];
-        auto load_pair_head = [&](int jp) { load_b(bs[0], jp, 0); if (nchunk > 1) load_b(bs[1], jp, KC); };
+        u32x4 bcur[2][KC], bl0[2][KC], bl1[2][KC];
+        auto load_pair_head = [&](int jp) { load_b(bl0, jp, 0); if (nchunk > 1) load_b(bl1, jp, KC); };
+        auto take = [&](const u32x4 (&src)[2][KC]) {
+#pragma unroll
+            for (int u = 0; u < KC; ++u) { bcur[0][u] = src[0][u]; bcur[1][u] = src[1][u]; }
+        };
         if (wave < a.NPAIR) load_pair_head(pair_of(wave));
         int rd = 0;
         for (int li = wave; li < a.NPAIR; li += kMbwWaves, ++rd) {
@@ -198,43 +206,31 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                         acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bb[1][u]), acc[1][b], 0, 0, 0);
                     }
             };
-            {
-                int c = 0;
-                for (; c + 3 <= nchunk; c += 3) {
-                    load_b(bs[2], jp, (c + 2) * KC);
-                    mma_chunk(c * KC, bs[0]);
-                    if (c + 3 < nchunk) load_b(bs[0], jp, (c + 3) * KC);
-                    mma_chunk((c + 1) * KC, bs[1]);
-                    if (c + 4 < nchunk) load_b(bs[1], jp, (c + 4) * KC);
-                    mma_chunk((c + 2) * KC, bs[2]);
-                }
-                if (c < nchunk) {
-                    mma_chunk(c * KC, bs[0]);
-                    if (c + 1 < nchunk) mma_chunk((c + 1) * KC, bs[1]);
+            take(bl0);
+            for (int c = 0; c < nchunk; c += 2) {
+                if (c + 2 < nchunk) load_b(bl0, jp, (c + 2) * KC);
+                mma_chunk(c * KC, bcur);
+                if (c + 1 < nchunk) {
+                    take(bl1);
+                    if (c + 3 < nchunk) load_b(bl1, jp, (c + 3) * KC);
+                    mma_chunk((c + 1) * KC, bcur);
+                    if (c + 2 < nchunk) take(bl0);
                 }
             }
-            // the next pair's first two chunks travel under the vector part
-            if (li + kMbwWaves < a.NPAIR) load_pair_head(pair_of(li + kMbwWaves));
-            // operands of the depthwise part (the channel's row: taps, BN scale, BN bias in TP / 4 16-byte loads): requested now,
-            // under the swish of the expanded map -- not before the products: 27 registers that are live across the K loop are
-            // the difference between spilling and not spilling, and a spill to scratch is an HBM write that every later
-            // s_waitcnt vmcnt of the wave waits for
+            if (rd < 2) MBW_STAMP(2 + 3 * rd);
+            // BN + swish on the accumulators, rounded to the storage type (what the expand launch would have written) -- LAST band
+            // first: its first swish reads the result of the last MFMA issued, and MFMAs complete in order, so every load requested
+            // behind that point finds no MFMA in flight.  Requested there, pinned by scheduling barriers (hipcc hoists loads as far
+            // up as it can, and hands them the registers the products have just freed):
+            //  * the next pair's first two chunks of B fragments, which travel under the vector part;
+            //  * the operands of the depthwise part (the channel's row: taps, BN scale, BN bias in TP / 4 16-byte loads) -- not
+            //    before the products: 27 registers that are live across the K loop are the difference between spilling and not
+            //    spilling, and a spill to scratch is an HBM write that every later s_waitcnt vmcnt of the wave waits for.
             constexpr int TP = (K * K + 2 + 3) / 4 * 4;
             float w[TP];
-            {
-                const f32x4* wrow = reinterpret_cast<const f32x4*>(a.wdl + (size_t)cc * TP);
 #pragma unroll
-                for (int q = 0; q < TP / 4; ++q) {
-                    const f32x4 v = wrow[q];
-                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-                }
-            }
-            const float sdl = w[K * K], bdl = w[K * K + 1];
-            if (rd < 2) MBW_STAMP(2 + 3 * rd);
-
-            // BN + swish on the accumulators, rounded to the storage type (what the expand launch would have written)
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int bb = 0; bb < NB; ++bb) {
+                const int b = NB - 1 - bb;
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
                     // (registers i, i + 1 of band b hold rows 32 (b % RB) + (i & 3) + 8 (i >> 2) [+ 1] (+ 4 in the upper half-wave):
@@ -245,6 +241,19 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                     acc[0][b][i] = (float)adaf_f16_of(t0.x); acc[0][b][i + 1] = (float)adaf_f16_of(t0.y);
                     acc[1][b][i] = (float)adaf_f16_of(t1.x); acc[1][b][i + 1] = (float)adaf_f16_of(t1.y);
                 }
+                if (bb == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (li + kMbwWaves < a.NPAIR) load_pair_head(pair_of(li + kMbwWaves));
+                    const f32x4* wrow = reinterpret_cast<const f32x4*>(a.wdl + (size_t)cc * TP);
+#pragma unroll
+                    for (int q = 0; q < TP / 4; ++q) {
+                        const f32x4 v = wrow[q];
+                        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const float sdl = w[K * K], bdl = w[K * K + 1];
             // lanes 0-31 take tile 0's other half-rows, lanes 32-63 give them and take tile 1's: afterwards acc[h][b][i] of lane l is
             // row 32 b + (i & 3) + 8 (i >> 2) + 4 h of channel 64 jp + l
 #pragma unroll
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     const _Float16* __restrict__ resb = a.res ? a.res + (size_t)img0 * PX * a.cout : nullptr;
     _Float16* __restrict__ outb = a.out + (size_t)img0 * PX * a.cout;
     const int rotp = (int)((blockIdx.x * 3u) % (unsigned)a.NTP);
-    u32x4 pb[3][KCP];                          // three sets with fixed roles per unrolled step, like the expand loop
+    u32x4 pcur[KCP], pl0[KCP], pl1[KCP];       // the MFMAs' set and two landing sets, like the expand loop
     auto tile_of = [&](int lt) { return lt + rotp >= a.NTP ? lt + rotp - a.NTP : lt + rotp; };
     auto load_p = [&](u32x4 (&dst)[KCP], int nt, int k0) {
         const u32x4* bp0 = a.wpf + (size_t)nt * KSPP * 64 + lane;
@@ -475,8 +484,8 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     };
     auto issue_tile = [&](int lt) {
         const int nt = tile_of(lt);
-        load_p(pb[0], nt, 0);
-        load_p(pb[1], nt, KCP);
+        load_p(pl0, nt, 0);
+        load_p(pl1, nt, KCP);
     };
     if (wave < a.NTP) issue_tile(wave);
 
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     MBW_STAMP(14);
 
     // ---- phase 4: project 1x1 + BN (+ identity), one 32-column tile per wave iteration ----
-    // K loop in chunks of KCP steps, three chunks of B fragments in flight (a chunk's 18 products are shorter than an L2 round trip);
+    // K loop in chunks of KCP steps, a chunk requested two chunks ahead of its products (they are shorter than an L2 round trip);
     // the padding steps multiply real (finite) D columns by zero fragments
     for (int lt = wave; lt < a.NTP; lt += kMbwWaves) {
         const int nt = tile_of(lt);
@@ -555,19 +564,19 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bb[h + u]), acc[b], 0, 0, 0);
             }
         };
-        {
-            int c = 0;
-            for (; c + 3 <= npc; c += 3) {
-                load_p(pb[2], nt, (c + 2) * KCP);
-                mma_p(c * KCP, pb[0]);
-                if (c + 3 < npc) load_p(pb[0], nt, (c + 3) * KCP);
-                mma_p((c + 1) * KCP, pb[1]);
-                if (c + 4 < npc) load_p(pb[1], nt, (c + 4) * KCP);
-                mma_p((c + 2) * KCP, pb[2]);
-            }
-            if (c < npc) {
-                mma_p(c * KCP, pb[0]);
-                if (c + 1 < npc) mma_p((c + 1) * KCP, pb[1]);
+        auto ptake = [&](const u32x4 (&src)[KCP]) {
+#pragma unroll
+            for (int u = 0; u < KCP; ++u) pcur[u] = src[u];
+        };
+        ptake(pl0);
+        for (int c = 0; c < npc; c += 2) {
+            if (c + 2 < npc) load_p(pl0, nt, (c + 2) * KCP);
+            mma_p(c * KCP, pcur);
+            if (c + 1 < npc) {
+                ptake(pl1);
+                if (c + 3 < npc) load_p(pl1, nt, (c + 3) * KCP);
+                mma_p((c + 1) * KCP, pcur);
+                if (c + 2 < npc) ptake(pl0);
             }
         }
         if (nok) {

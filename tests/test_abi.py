@@ -95,8 +95,6 @@ def test_product_package_never_imports_oracle():
 # only shrink or disappear.  Everything else must compile to ZERO scratch (a spill in an MFMA loop is a 10-30 % loss that no test notices).
 # Keys: the demangled name up to the argument list, anonymous namespace stripped.
 SCRATCH_ALLOWED = {
-    "mbconv_whole_kernel<9, 5, 1>": 184, "mbconv_whole_kernel<9, 3, 1>": 120, "mbconv_whole_kernel<5, 5, 2>": 80,
-    "mbconv_whole_kernel<4, 5, 2>": 80, "mbconv_whole_kernel<3, 5, 2>": 80,
     "ef_expand_kernel<float, 8, false>": 104, "ef_expand_kernel<float, 8, true>": 84, "ef_expand_kernel<float, 7, false>": 48,
     "ef_expand_kernel<float, 7, true>": 40, "ef_expand_kernel<_Float16, 8, true>": 76, "ef_expand_kernel<_Float16, 8, false>": 44,
     "ef_expand_kernel<_Float16, 7, true>": 28,

@@ -486,3 +486,23 @@ def test_config5_efficientnet_b3_t16_p144_end_to_end(dev, R):
     print("config 5 (EfficientNet-B3, T=16, P=144): fp16 storage rel rms local features %.2e, logits %.2e, max |dlogit| %.2e"
           % (relf, rell, (lg16 - rl).abs().max().item()))
     assert relf < 2e-3 and rell < 2e-3        # measured 1.4e-4 .. 4e-4 (bench.py `also.config5...`): a 10x regression fails
+
+
+@pytest.mark.parametrize("size,image_size", [(100, "native"), (75, None), (144, "native")])
+def test_b3_fp16_forward_is_the_same_from_run_to_run(dev, size, image_size):
+    """The same batch through the network repeatedly, at every block boundary from block 9 on (whole-block kernels on 3 x 3 ... 9 x 9
+    maps): bit-identical every time.  A version of csrc/mbconv_whole.hip whose filter loads landed in registers that MFMAs issued just
+    before them still read (or whose tap loads landed in accumulator registers the compiler knew to be dead) differed from run to run
+    in a few hundred values per forward -- inside every tolerance of the other tests, on most runs (tools/exp/effnet_determinism.py)."""
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, "efficientnet-b3", 200, dtype="f16", image_size=image_size)
+    g = torch.Generator().manual_seed(4200 + size)
+    x4 = nchw_to_nhwc4((torch.randn((5, 3, size, size), generator=g) * 0.5).to(dev))
+    with torch.no_grad():
+        for k in (10, 14, 18, 20, 22, 24, 25, 26):
+            ref = m.engine().forward_blocks(x4, k).clone()
+            for _ in range(5):
+                assert torch.equal(m.engine().forward_blocks(x4, k), ref), (size, k)
+        ref = m.features_nhwc4(x4).clone()
+        for _ in range(5):
+            assert torch.equal(m.features_nhwc4(x4), ref), size
