@@ -106,6 +106,14 @@ struct FastDiv {
     __device__ __forceinline__ int div(int a) const { return (int)fmaf((float)a, inv, half_inv); }
 };
 
+// a * b + c on the full-rate 24-bit multiplier (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate; hipcc turns __mul24 of a value it
+// cannot bound back into them).  b is wave-uniform (an SGPR operand); |a|, |b| < 2^23.
+__device__ __forceinline__ int mad24s(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 // ---- depthwise k x k, SAME padding, + BN affine + activation + squeeze partial sums -----------------------------------
 // A block owns IMB images x one channel slice (CS = LPP 16-byte chunks) x TH output rows.  Its input rows (with the padding
 // columns, zero-filled) are staged once in LDS; then thread (image, channel chunk cg, pixel-group lane pg) walks the
@@ -129,6 +137,8 @@ struct DwArgs {
     int LPP, CS, slices; // lanes (16-byte chunks) per pixel in a block's channel slice, channels per slice, slices per pixel
     int pitch16;         // LDS pixel pitch in 16-byte units (>= LPP; chosen so neighbouring thread groups hit different banks)
     int WP;              // staged columns: (TWG * OXT - 1) * S + K
+    int img_lds;         // bytes of one image's staged tile: ((TH - 1) * S + K) * WP * pitch16 * 16 (a kernel argument: a product of
+                         // three runtime values in the index arithmetic of every pixel group is two quarter-rate multiplies)
     int IMB, PG;         // images per block, pixel-group lanes per (image, channel chunk): IMB * PG * LPP <= 256
     int igroups;         // ceil(n / IMB)
     int total;           // work items (= blocks): igroups * tiles * slices
@@ -188,34 +198,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     const int th = min(a.TH, a.OH - oy0);
     const int xg0 = tx * a.TWG;              // first x group of this tile
     const int ihn = (th - 1) * S + K;        // staged input rows
-    const int ihmax = (a.TH - 1) * S + K;
     const int iy0 = oy0 * S - a.pad_t, ix0 = xg0 * OXT * S - a.pad_l;
     const int pitchB = a.pitch16 * 16;
-    const int img_lds = ihmax * a.WP * pitchB;                               // bytes of one image's staged tile
+    const int img_lds = a.img_lds;                                           // bytes of one image's staged tile (ihmax * WP * pitchB)
     char* xin = dsm;                                                         // [IMB][ihmax][WP][pitch16 * 16 B]
     float* wl = reinterpret_cast<float*>(dsm + (size_t)a.IMB * img_lds);     // [K*K][CS] taps
     float* sbl = wl + K * K * a.CS;                                          // [2][CS] BN scale, bias
     // Prologue: EVERY global load that does not depend on another one is requested before the first is used (taps, BN, and below the
-    // expand filter rows and the first batch of window pixels).  As a sequence of load -> LDS-store loops this was four to five L2
-    // round trips in a row, 5-9 k cycles of a 21-35 k cycle workgroup (tools/dw_trace.py).  (CS <= 64: at most NTW values per thread)
-    constexpr int NTW = (K * K * 64 + 255) / 256;
-    float tw[NTW];
-    {
-        const FastDiv dcs(a.CS);
+    // expand filter rows and the first batch of window pixels), and its integer arithmetic is kept off the slow paths: the launch is
+    // VALU-issue bound, the prologue was 250 VALU instructions of a wave's ~1200, and a fifth of those were 32 / 64-bit integer
+    // multiplies (quarter rate) of address and index computations (tools/dw_trace.py).  Taps: wave w fetches the filter rows w, w + 4,
+    // ... (scalar row base + lane: no per-thread index arithmetic), BN: wave 0 the scales, wave 1 the biases.
+    const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NTR = (K * K + 3) / 4;
+    const int lcs = lane_ < a.CS ? lane_ : 0;
+    float tw[NTR];
 #pragma unroll
-        for (int u = 0; u < NTW; ++u) {
-            const int i = tid + 256 * u;
-            const int ic = i < K * K * a.CS ? i : 0;
-            const int tap = dcs.div(ic);
-            tw[u] = a.wt[(size_t)tap * a.C + c0 + (ic - tap * a.CS)];
-        }
+    for (int u = 0; u < NTR; ++u) {
+        const int t = wave_ + 4 * u;
+        tw[u] = (a.wt + (t < K * K ? t : 0) * a.C + c0)[lcs];
     }
-    const float sbv = tid < a.CS ? a.scale[c0 + tid] : a.bias[c0 + (tid < 2 * a.CS ? tid - a.CS : 0)];      // (2 CS <= 128 threads carry one)
+    const float sbv = ((wave_ == 0 ? a.scale : a.bias) + c0)[lcs];
     auto store_taps = [&]() {
+        if (lane_ < a.CS) {
 #pragma unroll
-        for (int u = 0; u < NTW; ++u)
-            if (tid + 256 * u < K * K * a.CS) wl[tid + 256 * u] = tw[u];
-        if (tid < 2 * a.CS) sbl[tid] = sbv;
+            for (int u = 0; u < NTR; ++u)
+                if (wave_ + 4 * u < K * K) (wl + (wave_ + 4 * u) * a.CS)[lane_] = tw[u];
+            if (wave_ < 2) (sbl + wave_ * a.CS)[lane_] = sbv;
+        }
     };
     if constexpr (XN == 0) store_taps();
     if constexpr (XN > 0) {
@@ -229,19 +239,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         const int vw = vc1 - vc0, nv = (vr1 - vr0) * vw;
         u32x4 af[XN][KSX];
         f32x4 xs[XN], xb[XN];
+        const int pxcin = px * cin;
 #pragma unroll
         for (int rt = 0; rt < XN; ++rt) {
 #pragma unroll
             for (int ks = 0; ks < KSX; ++ks) {
                 const int k0 = 32 * ks + 8 * kq;
-                af[rt][ks] = *reinterpret_cast<const u32x4*>(wx + (size_t)(16 * rt + px) * cin + (k0 < cin ? k0 : 0));
+                af[rt][ks] = *reinterpret_cast<const u32x4*>(wx + (pxcin + 16 * rt * cin + (k0 < cin ? k0 : 0)));
             }
             xs[rt] = *reinterpret_cast<const f32x4*>(a.xscale + c0 + 16 * rt + 4 * kq);
             xb[rt] = *reinterpret_cast<const f32x4*>(a.xbias + c0 + 16 * rt + 4 * kq);
         }
         const int ntot = nimg * nv, ngr = (ntot + 15) >> 4;
         const FastDiv dnv(nv > 0 ? nv : 1), dvw(vw > 0 ? vw : 1);
-        const _Float16* xg = static_cast<const _Float16*>(a.x);
+        const _Float16* xg = static_cast<const _Float16*>(a.x) + (size_t)img0 * a.H * a.W * cin;      // (the block's first image: scalar)
         // the wave's pixel groups g = wave, wave + 4, ... in batches of GB, two batches deep: the B fragments of batch i + 1 are in flight
         // (unconditional loads, 16 bytes per lane) while batch i goes through the MFMAs and the swish
         constexpr int GB = 4 / KSX;
@@ -252,15 +263,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
                 const int p = 16 * (g0 + 4 * u) + px;
                 const bool valid = p < ntot;
                 const int pc = valid ? p : 0;
-                const int im = dnv.div(pc), q = pc - im * nv;
-                const int vr = dvw.div(q), vc = q - vr * vw;
+                // (24-bit multiplies: full rate, where v_mul_lo_u32 / v_mad_u64_u32 are quarter rate -- every operand here is far below 2^23)
+                const int im = dnv.div(pc), q = pc - __mul24(im, nv);
+                const int vr = dvw.div(q), vc = q - __mul24(vr, vw);
                 const int row = vr0 + vr, col = vc0 + vc;
-                dst[u] = valid ? im * img_lds + (row * a.WP + col) * pitchB + 8 * kq : -1;
-                const _Float16* src = xg + (((size_t)(img0 + im) * a.H + (iy0 + row)) * a.W + (ix0 + col)) * cin;
+                dst[u] = valid ? __mul24(im, img_lds) + __mul24(__mul24(row, a.WP) + col, pitchB) + 8 * kq : -1;
+                // (a 32-bit byte offset from the block's first image: scalar base + vector offset, no 64-bit arithmetic per pixel)
+                const unsigned src = 2u * (unsigned)mad24s(mad24s(mad24s(im, a.H, iy0 + row), a.W, ix0 + col), cin, 0);
 #pragma unroll
                 for (int ks = 0; ks < KSX; ++ks) {
                     const int k0 = 32 * ks + 8 * kq;
-                    bf[u][ks] = *reinterpret_cast<const u32x4*>(src + (k0 < cin ? k0 : 0));
+                    bf[u][ks] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xg) + (src + 2u * (unsigned)(k0 < cin ? k0 : 0)));
                 }
             }
         };
@@ -316,11 +329,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
         }
     } else {
         // staging: lane (pixel slot, chunk) walks the tile's pixels slot, slot + PP, ...
-        const int PP = 256 / a.LPP;
-        const int cgl = tid % a.LPP, slot = tid / a.LPP;
+        const FastDiv dlp(a.LPP), dwp(a.WP);
+        const int PP = dlp.div(256);
+        const int slot = dlp.div(tid), cgl = tid - __mul24(slot, a.LPP);
         if (slot < PP) {
-            const int col0 = slot % a.WP, row0 = slot / a.WP;
-            const int dcol = PP % a.WP, drow = PP / a.WP;
+            const int row0 = dwp.div(slot), col0 = slot - __mul24(row0, a.WP);
+            const int drow = dwp.div(PP), dcol = PP - drow * a.WP;
             // all offsets advance by precomputed steps (no multiplies in the loop): pixel slot -> slot + PP
             const int lstep = (drow * a.WP + dcol) * pitchB;                  // LDS bytes per step
             const int gstep = (drow * a.W + dcol) * a.C;                      // source elements per step
@@ -357,22 +371,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K == 5 ? 3 
     __syncthreads();
     EF_STAMP(3);
     const int TPI = a.LPP * a.PG;            // threads per image
-    const int im = tid / TPI, rem = tid - im * TPI;
-    const int cg = rem % a.LPP, pg = rem / a.LPP;
+    const FastDiv dlpp(a.LPP);
+    const int im = FastDiv(TPI).div(tid), rem = tid - __mul24(im, TPI);
+    const int pg = dlpp.div(rem), cg = rem - __mul24(pg, a.LPP);
     float psum[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) psum[e] = 0.f;
     if (im < nimg) {
         const int nxg = min(a.TWG, (a.OW + OXT - 1) / OXT - xg0);     // x groups in this tile
-        const int dxg = a.PG % nxg, dr = a.PG / nxg;
-        int xg = pg % nxg, r = pg / nxg;
+        const FastDiv dnxg(nxg);
+        const int dr = dnxg.div(a.PG), dxg = a.PG - dr * nxg;
+        int r = dnxg.div(pg), xg = pg - __mul24(r, nxg);
         T* ob = static_cast<T*>(a.out) + ((size_t)(img0 + im) * a.OH + oy0) * a.OW * a.C + c0 + cg * V;
-        const char* xim = xin + im * img_lds + cg * 16;
+        const char* xim = xin + __mul24(im, img_lds) + cg * 16;
         const int rowstride = a.WP * pitchB;                  // LDS bytes per staged row
         while (r < th) {
             const int ox0 = (xg0 + xg) * OXT;
-            const char* rowp = xim + (r * S * a.WP + xg * OXT * S) * pitchB;
-            T* op = ob + (r * a.OW + ox0) * a.C;
+            const char* rowp = xim + __mul24(__mul24(r * S, a.WP) + xg * (OXT * S), pitchB);
+            T* op = ob + __mul24(__mul24(r, a.OW) + ox0, a.C);
             float acc[OXT][V];
 #pragma unroll
             for (int o = 0; o < OXT; ++o)
@@ -1426,6 +1442,7 @@ int adaf_launch_dw_expand(const void* x, int n, int hh, int ww, int cin, const v
     a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
     a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
     a.pitch16 = p.pitch16; a.WP = p.WP;
+    a.img_lds = ((p.TH - 1) * stride + k) * p.WP * p.pitch16 * 16;
     a.IMB = p.IMB; a.PG = p.PG; a.igroups = (n + p.IMB - 1) / p.IMB;
     a.total = a.igroups * a.tiles * a.slices;
     const bool k2 = cin > 32;                                // k steps of 32
@@ -1455,6 +1472,7 @@ int adaf_launch_dw_same(const void* x, int dtype, int n, int hh, int ww, int c, 
     a.n = n; a.H = hh; a.W = ww; a.C = c; a.OH = oh; a.OW = ow; a.pad_t = pad_t; a.pad_l = pad_l; a.act = act;
     a.TH = p.TH; a.tiles = p.tiles; a.TWG = p.TWG; a.tiles_x = p.tiles_x; a.LPP = p.LPP; a.CS = p.CS; a.slices = p.slices;
     a.pitch16 = p.pitch16; a.WP = p.WP;
+    a.img_lds = ((p.TH - 1) * stride + k) * p.WP * p.pitch16 * 16;
     a.IMB = p.IMB; a.PG = p.PG; a.igroups = (n + p.IMB - 1) / p.IMB;
     a.total = a.igroups * a.tiles * a.slices;
     const bool ok = dtype == ADAF_DTYPE_F16 ? launch_dw_t<_Float16>(a, k, stride, p.OXT, p.lds, s)

@@ -349,8 +349,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     // the phase is bound by how many bytes a CU keeps in flight.  A batch is SEB rows per wave with every 16-byte piece requested
     // before the first is used, the first batch is requested BEFORE the barrier that closes phase 1 (a wave that ran out of channel
     // pairs waits there anyway), and the expand FC's first rows are requested before the barrier that closes the reduce FC.
-    constexpr int SEB = 4;                                          // rows per wave per batch of the reduce FC
-    constexpr int GJB = 32;                                         // rows per batch of the expand FC
+    // (rows per wave per batch of the reduce FC and rows per batch of the expand FC are chosen with the piece count, below: B3's
+    //  squeeze widths -- 24 / 34 / 58 rows -- then take ONE batch of the reduce FC, and 34 rows one batch of the expand FC; a
+    //  second batch of two rows is a whole extra round trip)
     const int C4 = hid >> 2;
     const int SQ = a.sq;
     float* mean = reinterpret_cast<float*>(xl);            // [G][hid], later the gate
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     // reduce FC for NP 16-byte pieces of a filter row per lane (NP = ceil(hid / 256): a compile-time count keeps the batch straight-line)
     auto se_reduce = [&](auto np_tag) {
         constexpr int NP = decltype(np_tag)::value;
+        constexpr int SEB = NP == 4 ? 5 : NP == 6 ? 8 : 4;          // rows per wave per batch: SEB * NP 16-byte pieces in flight per lane
         f32x4 wv[SEB][NP];
         auto se_load = [&](int j0) {
 #pragma unroll
@@ -425,8 +427,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         else if (np <= 6) se_reduce(std::integral_constant<int, 6>());
         else se_reduce(std::integral_constant<int, 8>());
     }
-    {
+    auto se_expand = [&](auto gjb_tag) {
         // expand FC: a thread owns 4 consecutive channels; rows in batches of GJB with every load of a batch in flight at once
+        constexpr int GJB = decltype(gjb_tag)::value;
         const int c4 = tid < C4 ? tid : 0;            // (C4 <= 512; threads past the end repeat piece 0 and store nothing)
         const float* wp = a.se_wet + 4 * c4;
         f32x4 wj[GJB];
@@ -463,7 +466,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 }
             }
         }
-    }
+    };
+    if (SQ > 32 && SQ <= 36) se_expand(std::integral_constant<int, 36>());      // (B3's 34 rows: one batch)
+    else se_expand(std::integral_constant<int, 32>());
     MBW_STAMP(11);
     __syncthreads();
     MBW_STAMP(12);
@@ -490,24 +495,30 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     if (wave < a.NTP) issue_tile(wave);
 
     // ---- phase 3: D *= gate (fp32 product, rounded to fp16) ----
+    // A thread keeps ONE 16-byte column chunk and walks down the rows, its eight gate values in registers (read once per image): the
+    // phase is LDS traffic, and a flat walk over (row, chunk) read 32 bytes of gate for every 16 bytes of D.
     {
         const int cpr = hid >> 3;                     // 16-byte chunks per row
-        const int total = nimg * PX * cpr;
-        const int drow = kMbwThreads / cpr, dcc = kMbwThreads - drow * cpr;
-        int row = tid / cpr, cq = tid - row * cpr;
-        for (int i = tid; i < total; i += kMbwThreads) {
-            char* p = dl + row * a.dpitch + cq * 16;
-            const float* gp = mean + (G > 1 && row >= PX ? hid : 0) + cq * 8;
-            const f16x8 v = *reinterpret_cast<const f16x8*>(p);
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-            f16x8 o;
-            o[0] = adaf_f16_of((float)v[0] * g0.x); o[1] = adaf_f16_of((float)v[1] * g0.y);
-            o[2] = adaf_f16_of((float)v[2] * g0.z); o[3] = adaf_f16_of((float)v[3] * g0.w);
-            o[4] = adaf_f16_of((float)v[4] * g1.x); o[5] = adaf_f16_of((float)v[5] * g1.y);
-            o[6] = adaf_f16_of((float)v[6] * g1.z); o[7] = adaf_f16_of((float)v[7] * g1.w);
-            *reinterpret_cast<f16x8*>(p) = o;
-            row += drow; cq += dcc;
-            if (cq >= cpr) { cq -= cpr; ++row; }
+        const int rpar = kMbwThreads / cpr;           // rows in flight (cpr <= 256: hid <= 2048)
+        const int r0 = tid / cpr, cq = tid - r0 * cpr;
+        if (r0 < rpar) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g >= nimg) break;
+                const float* gp = mean + g * hid + cq * 8;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                char* p = dl + (g * PX + r0) * a.dpitch + cq * 16;
+                const int pstep = rpar * a.dpitch;
+                for (int row = r0; row < PX; row += rpar, p += pstep) {
+                    const f16x8 v = *reinterpret_cast<const f16x8*>(p);
+                    f16x8 o;
+                    o[0] = adaf_f16_of((float)v[0] * g0.x); o[1] = adaf_f16_of((float)v[1] * g0.y);
+                    o[2] = adaf_f16_of((float)v[2] * g0.z); o[3] = adaf_f16_of((float)v[3] * g0.w);
+                    o[4] = adaf_f16_of((float)v[4] * g1.x); o[5] = adaf_f16_of((float)v[5] * g1.y);
+                    o[6] = adaf_f16_of((float)v[6] * g1.z); o[7] = adaf_f16_of((float)v[7] * g1.w);
+                    *reinterpret_cast<f16x8*>(p) = o;
+                }
+            }
         }
     }
     MBW_STAMP(13);
