@@ -61,6 +61,12 @@ EXTRA_R4 = {   # round 4 (tools/profile_r4.sh)
 EXTRA_R5 = {   # round 5 (tools/profile_r5.sh)
     "split_trace": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 4 --skip-extras --streams 1 --cpu-baseline 0 --math split_bf16   (the opt-in arithmetic: also.split_bf16)",
     "split_mfma": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0 --math split_bf16",
+    # tools/profile_r5_effnet.sh (config 5 after the zero-scratch whole-block kernels)
+    "effnet_f16_trace": "rocprofv3 --kernel-trace --stats -- python tools/effnet_probe.py 1024 144 5 f16   (EfficientNet-B3 local CNN, fp16 storage; 3 warm-up + 5 timed forwards)",
+    "effnet_f16_sq": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -- python tools/effnet_probe.py 1024 144 5 f16",
+    "effnet_f16_icache": "rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES -- python tools/effnet_probe.py 1024 144 5 f16",
+    "effnet_f16_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB; x2 for wide coalesced reads on gfx950)",
+    "effnet_f16_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB)",
 }
 if tag >= "r4":
     EXTRA = EXTRA_R4
