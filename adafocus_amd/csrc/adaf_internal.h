@@ -144,7 +144,8 @@ void adaf_launch_pack_bfrag_f16(const float* w, int n, int k, bool even_tiles, v
 int adaf_mbw_tap_row(int k);       // floats per channel in the depthwise operand rows: k*k taps + BN scale + BN bias, padded to 16 bytes
 void adaf_launch_pack_dw_rows(const float* wd, const float* sd, const float* bd, int hid, int k, float* o, hipStream_t s);
 bool adaf_mbw_eligible(int hw, int k, int stride, int cin, int hid, int cout, int sq);
-bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
+int adaf_mbw_pad_before(int hw, int k, int stride);
+bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int stride, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
                               const float* be, const float* wdl, const float* se_wr, const float* se_br,
                               const float* se_wet, const float* se_be, const void* wpf, const float* sp, const float* bp, bool skip, void* out,
                               hipStream_t s);

@@ -1840,6 +1840,13 @@ int adaf_effnet_destroy(adaf_effnet* net) {
     return ADAF_OK;
 }
 
+// Does the whole-block kernel take this block?  Its geometry: the SAME padding of the map as it is (pad rows in front as the kernel
+// computes them, output = ceil(hw / stride)): stride 1 everywhere it is instantiated, stride 2 for the 9 x 9 -> 5 x 5 block.
+static bool ef_whole_geometry(const EfBlock& b, int hw, int ohw, int pbd) {
+    return b.expand >= 0 && (b.stride == 1 || b.stride == 2) && ohw == (hw + b.stride - 1) / b.stride && pbd == adaf_mbw_pad_before(hw, b.k, b.stride) &&
+           adaf_mbw_eligible(hw, b.k, b.stride, b.cin, b.hid, b.cout, b.sq);
+}
+
 int adaf_effnet_feature_dim(const adaf_effnet* net) { return net ? net->feat : 0; }
 int adaf_effnet_block_count(const adaf_effnet* net) { return net ? (int)net->blocks.size() : 0; }
 
@@ -1867,7 +1874,7 @@ int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size) {
     for (auto& b : net->blocks) {
         const int pbd = same_pad(ps, b.k, b.stride, &tot);
         const int ohw = conv_out_len(hw, b.k, b.stride, tot);
-        if (b.expand >= 0 && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1 && adaf_mbw_eligible(hw, b.k, 1, b.cin, b.hid, b.cout, b.sq)) ++count;
+        if (ef_whole_geometry(b, hw, ohw, pbd)) ++count;
         hw = ohw;
         ps = ceil_div(ps, b.stride);
     }
@@ -1887,7 +1894,7 @@ int adaf_effnet_fused_expand_blocks(const adaf_effnet* net, int size, int pad_si
         const EfBlock& b = net->blocks[bi];
         const int pbd = same_pad(ps, b.k, b.stride, &tot);
         const int ohw = conv_out_len(hw, b.k, b.stride, tot);
-        const bool whole = whole_on && b.expand >= 0 && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1 && adaf_mbw_eligible(hw, b.k, 1, b.cin, b.hid, b.cout, b.sq);
+        const bool whole = whole_on && ef_whole_geometry(b, hw, ohw, pbd);
         if (!whole && b.expand >= 0 && bi < 32 && ((adaf_options().effnet_fused_blocks >> bi) & 1u) && b.cin % 8 == 0 && b.cin <= 64 &&
             adaf_effnet_dw_tiles_fused(b.hid, ohw, ohw, b.k, b.stride) > 0)
             ++count;
@@ -1963,7 +1970,7 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
         (void)hipMemcpyAsync(b.se_br, br, (size_t)b.sq * 4, hipMemcpyDeviceToDevice, st);
         (void)hipMemcpyAsync(b.se_be, be, (size_t)b.hid * 4, hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((b.sq * b.hid + 255) / 256)), dim3(256), 0, st, we, b.hid, b.sq, b.se_wet);
-        if (net->dtype == ADAF_DTYPE_F16 && b.expand >= 0 && b.stride == 1 && b.cin % 8 == 0 && b.hid % 16 == 0) {
+        if (net->dtype == ADAF_DTYPE_F16 && b.expand >= 0 && (b.stride == 1 || b.stride == 2) && b.cin % 8 == 0 && b.hid % 16 == 0) {
             // the whole-block kernel streams its filters as ready-made B fragments (one coalesced 1 KB load per wave instruction)
             const float *wexp, *wproj;
             if ((rc = get(net->convs[b.expand].name + ".weight", (size_t)b.hid * b.cin, &wexp)) ||
@@ -2045,13 +2052,15 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             const EfConv& D = net->convs[b.dwc];
             const EfConv& P = net->convs[b.project];
             const bool skip = b.stride == 1 && b.cin == b.cout;
-            if (f16 && net->fuse && (plan & ADAF_EF_PLAN_WHOLE_BLOCK) && b.expand >= 0 && b.wef && b.stride == 1 && ohw == hw && 2 * pbd == b.k - 1) {
+            if (f16 && net->fuse && (plan & ADAF_EF_PLAN_WHOLE_BLOCK) && b.wef && ef_whole_geometry(b, hw, ohw, pbd)) {
                 // maps small enough for a workgroup to own whole images: the block as ONE launch (mbconv_whole.hip)
                 const EfConv& E = net->convs[b.expand];
-                if (adaf_launch_mbconv_whole(cur, nc, hw, b.cin, b.hid, b.cout, b.sq, b.k, b.wef, E.scale, E.bias, b.wdl, b.se_wr,
+                if (adaf_launch_mbconv_whole(cur, nc, hw, b.stride, b.cin, b.hid, b.cout, b.sq, b.k, b.wef, E.scale, E.bias, b.wdl, b.se_wr,
                                              b.se_br, b.se_wet, b.se_be, b.wpf, P.scale, P.bias, skip, nxt, st)) {
                     char* t = cur; cur = nxt; nxt = t;
-                    out_elems = (size_t)hw * hw * b.cout;
+                    out_elems = (size_t)ohw * ohw * b.cout;
+                    hw = ohw;
+                    ps = ceil_div(ps, b.stride);
                     continue;
                 }
             }

@@ -51,6 +51,12 @@ __device__ __forceinline__ f32x2 w_swish2(f32x2 t) {
 }
 __device__ __forceinline__ f32x2 w_fma2(f32x2 a, float s, float b) { return __builtin_elementwise_fma(a, f32x2{s, s}, f32x2{b, b}); }
 
+// rows / columns of SAME padding in front of the map (TensorFlow's rule: the odd one falls behind)
+constexpr int mbw_pad_before(int hw, int k, int s) {
+    const int o = (hw + s - 1) / s, tot = (o - 1) * s + k - hw;
+    return tot > 0 ? tot / 2 : 0;
+}
+
 struct MbwArgs {
     const _Float16* x;       // [n][HW*HW][cin] block input
     const _Float16* res;     // identity rows (= x) or nullptr
@@ -83,12 +89,17 @@ struct MbwArgs {
 #define MBW_STAMP(slot_) do { } while (0)
 #endif
 
-template <int HW, int K, int G>
+// S = 2 (the block that takes a 9 x 9 map to 5 x 5): the depthwise part visits the HWO x HWO outputs only, D / squeeze / gate / project
+// run on those PXO rows, no identity.
+template <int HW, int K, int G, int S = 1>
 __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs a) {
+    static_assert(S == 1 || (S == 2 && G == 1), "stride 2: one image per workgroup");
     constexpr int PX = HW * HW;
-    constexpr int RB = (PX + 31) / 32;         // row bands per image
+    constexpr int RB = (PX + 31) / 32;         // row bands per image (input map: the expand GEMM)
     constexpr int NB = G * RB;
-    constexpr int P = (K - 1) / 2;             // SAME padding at stride 1 is symmetric
+    constexpr int HWO = (HW + S - 1) / S, PXO = HWO * HWO;      // output map (D, squeeze, project)
+    constexpr int RBO = (PXO + 31) / 32, NBO = G * RBO;
+    constexpr int P = mbw_pad_before(HW, K, S);                 // SAME padding: symmetric at stride 1
     constexpr int KC = 3;                      // k steps per prefetched chunk of B fragments (expand)
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,12 +140,17 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     MBW_STAMP(1);
 
     // row of band b this lane feeds the MFMAs with (rows past the last pixel repeat the last row: their results are never used)
-    int xoff[NB], doff[NB];
+    int xoff[NB], doff[NBO];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         int row = (b / RB) * PX + (b % RB) * 32 + nl;
         row = row < G * PX ? row : G * PX - 1;
         xoff[b] = row * a.xpitch + half * 16;
+    }
+#pragma unroll
+    for (int b = 0; b < NBO; ++b) {
+        int row = (b / RBO) * PXO + (b % RBO) * 32 + nl;
+        row = row < G * PXO ? row : G * PXO - 1;
         doff[b] = row * a.dpitch + half * 16;
     }
 
@@ -309,30 +325,30 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 f32x2 ps = {0.f, 0.f};
                 unsigned dofs = (unsigned)a.d_off + (unsigned)cc * 2u;
 #pragma unroll
-                for (int oy = 0; oy < HW; ++oy) {
-                    float s[HW + 1];
+                for (int oy = 0; oy < HWO; ++oy) {
+                    float s[HWO + 1];
 #pragma unroll
-                    for (int ox = 0; ox <= HW; ++ox) s[ox] = 0.f;
+                    for (int ox = 0; ox <= HWO; ++ox) s[ox] = 0.f;
 #pragma unroll
                     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                            for (int ox = 0; ox < HW; ++ox) {
-                                const int iy = oy + ky - P, ix = ox + kx - P;
+                            for (int ox = 0; ox < HWO; ++ox) {
+                                const int iy = oy * S + ky - P, ix = ox * S + kx - P;
                                 if (iy < 0 || iy >= HW || ix < 0 || ix >= HW) continue;      // resolved at compile time
                                 s[ox] = fmaf(MBW_M(0, iy * HW + ix), w[ky * K + kx], s[ox]);
                             }
                     // BN + swish two outputs at a time (the last pair of an odd row carries a dummy)
 #pragma unroll
-                    for (int ox = 0; ox < HW; ox += 2) {
+                    for (int ox = 0; ox < HWO; ox += 2) {
                         const f32x2 v = w_swish2(w_fma2(f32x2{s[ox], s[ox + 1]}, sdl, bdl));
-                        if (ox + 1 < HW) ps += v; else ps.x += v.x;
+                        if (ox + 1 < HWO) ps += v; else ps.x += v.x;
                         if (cok) {
                             *reinterpret_cast<_Float16*>(dsm + dofs) = (_Float16)v.x;
-                            if (ox + 1 < HW) *reinterpret_cast<_Float16*>(dsm + dofs + a.dpitch) = (_Float16)v.y;
+                            if (ox + 1 < HWO) *reinterpret_cast<_Float16*>(dsm + dofs + a.dpitch) = (_Float16)v.y;
                         }
-                        dofs += (ox + 1 < HW ? 2u : 1u) * (unsigned)a.dpitch;
+                        dofs += (ox + 1 < HWO ? 2u : 1u) * (unsigned)a.dpitch;
                     }
                 }
                 const float pst = ps.x + ps.y;
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         __syncthreads();           // X is dead, D is complete
         MBW_STAMP(9);
         {
-            const float inv_hw = 1.f / (float)PX;
+            const float inv_hw = 1.f / (float)PXO;
             const int rot = (int)((blockIdx.x * 5u) % (unsigned)a.NPAIR);
 #pragma unroll
             for (int q = 0; q < kMbwMaxRounds; ++q) {
@@ -477,8 +493,8 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
     // they do not depend on the gate, and phase 3 + its barrier is longer than their round trip ----
     constexpr int KCP = 6;                     // k steps per chunk of B fragments (project); three chunks deep
     const int KSP = a.KSP, KSPP = a.KSPP;      // real k steps / padded to whole chunks (zero fragments in the packed filter)
-    const _Float16* __restrict__ resb = a.res ? a.res + (size_t)img0 * PX * a.cout : nullptr;
-    _Float16* __restrict__ outb = a.out + (size_t)img0 * PX * a.cout;
+    const _Float16* __restrict__ resb = a.res ? a.res + (size_t)img0 * PXO * a.cout : nullptr;
+    _Float16* __restrict__ outb = a.out + (size_t)img0 * PXO * a.cout;
     const int rotp = (int)((blockIdx.x * 3u) % (unsigned)a.NTP);
     u32x4 pcur[KCP], pl0[KCP], pl1[KCP];       // the MFMAs' set and two landing sets, like the expand loop
     auto tile_of = [&](int lt) { return lt + rotp >= a.NTP ? lt + rotp - a.NTP : lt + rotp; };
@@ -507,9 +523,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 if (g >= nimg) break;
                 const float* gp = mean + g * hid + cq * 8;
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-                char* p = dl + (g * PX + r0) * a.dpitch + cq * 16;
+                char* p = dl + (g * PXO + r0) * a.dpitch + cq * 16;
                 const int pstep = rpar * a.dpitch;
-                for (int row = r0; row < PX; row += rpar, p += pstep) {
+                for (int row = r0; row < PXO; row += rpar, p += pstep) {
                     const f16x8 v = *reinterpret_cast<const f16x8*>(p);
                     f16x8 o;
                     o[0] = adaf_f16_of((float)v[0] * g0.x); o[1] = adaf_f16_of((float)v[1] * g0.y);
@@ -536,42 +552,42 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         // the identity rows of this tile travel under the products (one 2-byte load per output of the lane; unconditional loads from
         // clamped addresses -- a load inside a per-lane branch is followed by its own s_waitcnt, and 41 of those in a row were most of
         // this phase's time; values of pixels that do not exist are never stored)
-        _Float16 rv[NB][16];
+        _Float16 rv[NBO][16];
         if (resb) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NBO; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);          // pixel of the h = 0 lanes; h = 1: + 4
-                    const bool ok = b / RB < nimg && pr + 4 * half < PX;
-                    rv[b][i] = resb[ok ? obase + ((b / RB) * PX + pr) * a.cout : 0];
+                    const int pr = (b % RBO) * 32 + (i & 3) + 8 * (i >> 2);          // pixel of the h = 0 lanes; h = 1: + 4
+                    const bool ok = b / RBO < nimg && pr + 4 * half < PXO;
+                    rv[b][i] = resb[ok ? obase + ((b / RBO) * PXO + pr) * a.cout : 0];
                 }
         } else {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NBO; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) rv[b][i] = (_Float16)0.f;
         }
-        f32x16 acc[NB];
+        f32x16 acc[NBO];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBO; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         const int npc = KSPP / KCP;
         auto mma_p = [&](int k0, const u32x4 (&bb)[KCP]) {
 #pragma unroll
             for (int h = 0; h < KCP; h += 3) {
-                f16x8 af[3][NB];
+                f16x8 af[3][NBO];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     const int kk = k0 + h + u < KSP ? k0 + h + u : KSP - 1;
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(dl + doff[b] + kk * 32);
+                    for (int b = 0; b < NBO; ++b) af[u][b] = *reinterpret_cast<const f16x8*>(dl + doff[b] + kk * 32);
                 }
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b)
+                    for (int b = 0; b < NBO; ++b)
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], __builtin_bit_cast(f16x8, bb[h + u]), acc[b], 0, 0, 0);
             }
         };
@@ -593,12 +609,12 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         if (nok) {
             const float sc = a.sp[ncol], bi = a.bp[ncol];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (b / RB >= nimg) continue;
+            for (int b = 0; b < NBO; ++b) {
+                if (b / RBO >= nimg) continue;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int pr = (b % RB) * 32 + (i & 3) + 8 * (i >> 2);
-                    if (pr + 4 * half < PX) outb[obase + ((b / RB) * PX + pr) * a.cout] = adaf_f16_of(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
+                    const int pr = (b % RBO) * 32 + (i & 3) + 8 * (i >> 2);
+                    if (pr + 4 * half < PXO) outb[obase + ((b / RBO) * PXO + pr) * a.cout] = adaf_f16_of(fmaf(acc[b][i], sc, bi) + (float)rv[b][i]);
                 }
             }
         }
@@ -629,9 +645,9 @@ struct MbwPlan { int G, KS, KSP, NTP, NPAIR, xpitch, dpitch, d_off; size_t lds; 
 constexpr size_t kLdsMax = 160 * 1024;
 
 // images per workgroup and LDS layout, or false when the block does not fit
-bool plan_mbw(int hw, int cin, int hid, int cout, int sq, int gmax, MbwPlan* p) {
+bool plan_mbw(int hw, int stride, int cin, int hid, int cout, int sq, int gmax, MbwPlan* p) {
     if (cin % 8 || hid % 16 || hid > 64 * kMbwWaves * kMbwMaxRounds) return false;
-    const int px = hw * hw;
+    const int px = hw * hw, hwo = (hw + stride - 1) / stride, pxo = hwo * hwo;
     p->KS = mbw_expand_ksteps(cin);
     p->KSP = hid / 16;
     p->NTP = (cout + 31) / 32;
@@ -644,7 +660,7 @@ bool plan_mbw(int hw, int cin, int hid, int cout, int sq, int gmax, MbwPlan* p) 
             const size_t alias = (size_t)g * (hid + sq) * 4;
             if (alias > first) first = alias;
             first = (first + 15) & ~(size_t)15;
-            const size_t total = first + (size_t)g * px * dpitch;
+            const size_t total = first + (size_t)g * pxo * dpitch;
             if (total <= kLdsMax) {
                 p->G = g; p->xpitch = xpitch; p->dpitch = dpitch; p->d_off = (int)first; p->lds = total;
                 return true;
@@ -654,12 +670,12 @@ bool plan_mbw(int hw, int cin, int hid, int cout, int sq, int gmax, MbwPlan* p) 
     return false;
 }
 
-template <int HW, int K, int G>
+template <int HW, int K, int G, int S = 1>
 void launch_mbw_one(const MbwArgs& a, size_t lds, hipStream_t s) {
     // dynamic LDS above 64 KB has to be asked for -- per DEVICE (function attributes are per device and a process may hold handles on
     // several), so on every launch like the other launchers of effnet.hip; it is a host-side table update, not a device call
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_whole_kernel<HW, K, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    hipLaunchKernelGGL((mbconv_whole_kernel<HW, K, G>), dim3((unsigned)((a.n + G - 1) / G)), dim3(kMbwThreads), lds, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_whole_kernel<HW, K, G, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    hipLaunchKernelGGL((mbconv_whole_kernel<HW, K, G, S>), dim3((unsigned)((a.n + G - 1) / G)), dim3(kMbwThreads), lds, s, a);
 }
 
 // maps with an instantiated kernel: 3 x 3 .. 9 x 9 (two images per workgroup up to 5 x 5: one 32-row band each)
@@ -712,20 +728,25 @@ void adaf_launch_pack_bfrag_f16(const float* w, int n, int k, bool even_tiles, v
     hipLaunchKernelGGL(pack_bfrag_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, n, k, tiles, ks, static_cast<_Float16*>(o));
 }
 
+// stride 2: the one instantiated shape -- 9 x 9 -> 5 x 5, k = 5, one image per workgroup (B3's block 18 at 144^2 patches)
 bool adaf_mbw_eligible(int hw, int k, int stride, int cin, int hid, int cout, int sq) {
-    if (stride != 1 || (k != 3 && k != 5) || mbw_gmax(hw) == 0) return false;
+    if ((k != 3 && k != 5) || mbw_gmax(hw) == 0) return false;
+    if (stride == 2 ? !(hw == 9 && k == 5) : stride != 1) return false;
     MbwPlan p;
-    return plan_mbw(hw, cin, hid, cout, sq, mbw_gmax(hw), &p);
+    return plan_mbw(hw, stride, cin, hid, cout, sq, stride == 2 ? 1 : mbw_gmax(hw), &p);
 }
 
-// one launch for a whole MBConv block (fp16 storage, stride 1, map hw x hw); false = not eligible, nothing launched
-bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
+int adaf_mbw_pad_before(int hw, int k, int stride) { return mbw_pad_before(hw, k, stride); }
+
+// one launch for a whole MBConv block (fp16 storage, map hw x hw, SAME padding with adaf_mbw_pad_before() rows / columns in front);
+// false = not eligible, nothing launched
+bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int stride, int cin, int hid, int cout, int sq, int k, const void* wef, const float* se,
                               const float* be, const float* wdl, const float* se_wr, const float* se_br,
                               const float* se_wet, const float* se_be, const void* wpf, const float* sp, const float* bp, bool skip, void* out,
                               hipStream_t s) {
-    if (!adaf_mbw_eligible(hw, k, 1, cin, hid, cout, sq) || n <= 0) return false;
+    if (!adaf_mbw_eligible(hw, k, stride, cin, hid, cout, sq) || n <= 0 || (stride == 2 && skip)) return false;
     MbwPlan p;
-    if (!plan_mbw(hw, cin, hid, cout, sq, mbw_gmax(hw), &p)) return false;
+    if (!plan_mbw(hw, stride, cin, hid, cout, sq, stride == 2 ? 1 : mbw_gmax(hw), &p)) return false;
     MbwArgs a;
     memset(&a, 0, sizeof(a));
     a.x = static_cast<const _Float16*>(x); a.res = skip ? a.x : nullptr; a.out = static_cast<_Float16*>(out);
@@ -737,6 +758,7 @@ bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int cin, int hid, in
     a.trace = (adaf_mbw_trace_hid == 0 || adaf_mbw_trace_hid == hid) && adaf_mbw_trace_k == k ? adaf_mbw_trace_buf : nullptr;
 #endif
     a.KS = p.KS; a.KSP = p.KSP; a.KSPP = mbw_project_ksteps(hid); a.NTP = p.NTP; a.NPAIR = p.NPAIR; a.xpitch = p.xpitch; a.dpitch = p.dpitch; a.d_off = p.d_off;
+    if (stride == 2) { launch_mbw_one<9, 5, 1, 2>(a, p.lds, s); return true; }
     switch (hw) {
         case 3: launch_mbw_hw<3>(a, k, p.G, p.lds, s); break;
         case 4: launch_mbw_hw<4>(a, k, p.G, p.lds, s); break;

@@ -153,7 +153,7 @@ def init_failure_line(a, world, rank, backend, exc, launched=True):
 def load_effnet_traffic(dtype, patches, p):
     """HBM bytes per patch of the EfficientNet forward from the committed rocprofv3 PMC passes (profiles/r<N>_effnet_traffic.json, written by
     tools/publish_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/effnet_probe.py); null when not collected for this case."""
-    for tag in ("r4",):
+    for tag in ("r5", "r4"):
         path = os.path.join(ROOT, "profiles", "%s_effnet_traffic.json" % tag)
         if os.path.exists(path):
             try:
