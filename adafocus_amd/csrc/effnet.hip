@@ -1154,6 +1154,9 @@ struct StemArgs {
     void* out;            // [n][OH][OW][C0]
     int n, S, OH, OW, C0, pad, act;
     int tiles_x, tiles_y;
+#ifdef EF_TRACE
+    unsigned long long* trace;
+#endif
 };
 
 template <typename T>
@@ -1164,6 +1167,7 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) float xin[IH * IW * 4];
     __shared__ __attribute__((aligned(16))) float slab[4][32 * SP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    EF_STAMP(0);
     // a block walks the tiles of one 8-row band of one image: the filter bank is fetched once per band
     const int ty = blockIdx.x % a.tiles_y;
     const int img = blockIdx.x / a.tiles_y;
@@ -1224,6 +1228,7 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
         }
     };
     wload(0);
+    EF_STAMP(1);
     for (int tx = 0; tx < a.tiles_x; ++tx) {
         const int ox0 = tx * TW;
         if (tx) __syncthreads();                              // the previous tile's window has been consumed
@@ -1231,6 +1236,7 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
         for (int u = 0; u < WPT; ++u)
             if (tid + 256 * u < IH * IW) *reinterpret_cast<f32x4*>(xin + (tid + 256 * u) * 4) = wv[u];
         __syncthreads();
+        if (tx == 1) EF_STAMP(2);
         if (tx + 1 < a.tiles_x) wload(tx + 1);
         f32x16 acc[2];
 #pragma unroll
@@ -1248,6 +1254,7 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
             }
         }
         // epilogue: BN + activation, through the wave's slab, 16-byte stores of V consecutive channels
+        if (tx == 1) EF_STAMP(3);
         __builtin_amdgcn_wave_barrier();
         act_switch(a.act, [&](auto AC) {
 #pragma unroll
@@ -1259,6 +1266,7 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
             }
         });
         __builtin_amdgcn_wave_barrier();
+        if (tx == 1) EF_STAMP(4);
         for (int i = lane; i < 32 * cpr; i += 64) {
             const int p = i / cpr, cq = i - p * cpr;
             const int oy = oy0 + 2 * wave + (p >> 4), ox = ox0 + (p & 15);
@@ -1272,7 +1280,10 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
                 *reinterpret_cast<u32x4*>(ob + ((size_t)oy * a.OW + ox) * a.C0 + cq * V) = Chunk<T>::pack(v);
             }
         }
+        if (tx == 1) EF_STAMP(5);
+        if (tx == 0) EF_STAMP(6);
     }
+    EF_STAMP(7);
 }
 
 // [C,1,K,K] (PyTorch depthwise) -> [K*K][C]
@@ -1624,6 +1635,9 @@ bool adaf_launch_ef_stem(const float* x4, int dtype, int n, int size, int oh, in
     StemArgs a;
     a.x4 = x4; a.w = w; a.scale = scale; a.bias = bias; a.out = out; a.n = n; a.S = size; a.OH = oh; a.OW = ow; a.C0 = c0; a.pad = pad; a.act = act;
     a.tiles_x = (ow + 15) / 16; a.tiles_y = (oh + 7) / 8;
+#ifdef EF_TRACE
+    a.trace = ef_trace_k == -1 ? ef_trace_buf : nullptr;         // (adaf_ef_set_trace(buf, 0, -1, 0) traces the stem)
+#endif
     const dim3 grid((unsigned)((size_t)n * a.tiles_y)), block(256);
     if (dtype == ADAF_DTYPE_F16) hipLaunchKernelGGL((ef_stem_kernel<_Float16>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((ef_stem_kernel<float>), grid, block, 0, s, a);
