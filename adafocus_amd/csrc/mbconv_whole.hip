@@ -1,6 +1,7 @@
 // Whole-image MBConv blocks of EfficientNet (BASELINE config 5, fp16 storage): expand 1x1 + BN + swish -> depthwise k x k + BN + swish
 // -> squeeze-and-excite -> gated project 1x1 + BN (+ identity) as ONE launch for the blocks whose map is small enough that a
-// workgroup owns whole images (9 x 9 and 5 x 5 at 144^2 patches: 15 of B3's 26 blocks: 9-17 and 19-24; block 25's 2304 hidden channels exceed the 2048 the kernel walks).  The 6x-expanded map never exists in HBM
+// workgroup owns whole images (9 x 9 and 5 x 5 at 144^2 patches: 16 of B3's 26 blocks: 9-17 and 19-24 at stride 1, block 18 -- 9 x 9 -> 5 x 5 --
+// at stride 2; block 25's 2304 hidden channels exceed the 2048 the kernel walks).  The 6x-expanded map never exists in HBM
 // (it does not even exist in LDS: it goes from the MFMA accumulators straight into the depthwise taps), the depthwise output
 // lives in LDS only, the squeeze is an in-block reduction and the two SE matrix products run inside the block -- four launches
 // and three HBM round trips of the widest tensors of the block become one launch that reads the block input and writes the block
@@ -20,6 +21,15 @@
 //   2  squeeze -> reduce FC + swish -> expand FC + sigmoid (the arithmetic of se_gate_kernel), gate in LDS
 //   3  D *= gate in place (fp32 product rounded to fp16: the operand gated_project_kernel hands its MFMAs)
 //   4  project GEMM: A fragments from D, B fragments streamed like phase 1, BN (+ identity) epilogue, fp16 stores
+//
+// Two rules of this file, both measured:
+//   * NO SCRATCH.  A spilled register is an HBM write, and every later s_waitcnt vmcnt of the wave waits for its acknowledgement: with
+//     46 spilled dwords the kernel's L2 round trips measured 8-10 k cycles instead of ~800 (tools/mbw_trace.py, tools/exp/l2_burst_bench.hip).
+//   * NO GLOBAL LOAD INTO A REGISTER OF AN MFMA THAT MAY STILL BE IN FLIGHT -- neither one it reads (B fragments loaded straight into the
+//     set the previous chunk's products used) nor one it writes (loads that the allocator placed in accumulator registers it knew to be
+//     dead): results then differed from run to run in a few hundred values per forward.  B fragments land in sets no MFMA reads and move
+//     through VALU copies; loads behind a K loop are issued after a VALU instruction has read the last MFMA's result, pinned by
+//     scheduling barriers (tools/exp/effnet_determinism.py, tests/test_effnet.py::test_b3_fp16_forward_is_the_same_from_run_to_run).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -397,7 +397,8 @@ int adaf_effnet_feature_dim(const adaf_effnet* net);
 int adaf_effnet_block_count(const adaf_effnet* net);
 int adaf_effnet_block_info(const adaf_effnet* net, int block, int* info8);
 int adaf_effnet_set_dtype(adaf_effnet* net, int dtype);
-/* on (DEFAULT): fp16 storage only -- the stride-1 MBConv blocks whose map is at most 9 x 9 (blocks 9-17 and 19-24 of B3 at 144^2: 15 blocks; block 25 (hid 2304 > 2048) keeps the four-launch plan;
+/* on (DEFAULT): fp16 storage only -- the stride-1 MBConv blocks whose map is at most 9 x 9 and the stride-2 block that takes a 9 x 9
+ * map to 5 x 5 (blocks 9-17, 18 and 19-24 of B3 at 144^2: 16 blocks; block 25 (hid 2304 > 2048) keeps the four-launch plan;
  * patches) run as ONE launch per block: a workgroup owns whole images, the 6x-expanded map goes from the MFMA accumulators
  * straight into the depthwise taps, the depthwise output and the squeeze-and-excite live in LDS, the block reads its input and
  * writes its output (csrc/mbconv_whole.hip).  off = the four-launch plan (expand, depthwise, SE gate, gated project).  Same
