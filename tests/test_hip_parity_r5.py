@@ -344,3 +344,41 @@ def test_split_bf16_position_major_tap_skipping_bit_identical(dev, p, n):
         ops.set_conv_pos_major(True, dev)
     assert torch.isfinite(got).all() and got.abs().max().item() > 0.1
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("p,n,tsm", [(96, 1024, 0), (96, 16, 0), (144, 96, 12), (128, 264, 8)])
+def test_trunk_is_the_same_from_run_to_run(dev, p, n, tsm):
+    """The same patches through the ResNet-50 trunk six times: bit-identical every time, in both arithmetic modes, at the headline batch
+    (1024 patches: the batched tiles), at 16 patches (the small-batch conv form) and with the fused temporal shift.  (Why this is
+    asked: EfficientNet's whole-block kernel once gave run-to-run differences inside every tolerance -- global loads that landed in
+    registers of MFMAs still in flight, DESIGN 3.7.3.  The trunk's operands travel through LDS, not through such registers; this
+    test keeps it that way.)"""
+    from adafocus_amd.resnet import resnet50
+    from tests.helpers import rnd
+    net = resnet50(num_classes=200).eval()
+    net.load_state_dict(synth_sd("ACT", 1007 + p, "focuser.net.", keep_prefix=False), strict=True)
+    net = net.to(dev)
+    net.tsm_segments = tsm
+    x = rnd((n, 3, p, p), 5100 + p + n).to(dev)
+    from adafocus_amd.utils import nchw_to_nhwc4
+    x4 = nchw_to_nhwc4(x)
+    with torch.no_grad():
+        ref = net.features_nhwc4(x4).clone()
+        for _ in range(5):
+            assert torch.equal(net.features_nhwc4(x4), ref)
+
+
+def test_glancer_is_the_same_from_run_to_run(dev):
+    """The MobileNetV2 glancer (MFMA 1x1 convs fed straight from registers in its fused MBConv kernels) on the same 64 frames, six times."""
+    from adafocus_amd.mobilenet import mobilenet_v2
+    from tests.helpers import rnd
+    net = mobilenet_v2().eval()
+    sd = {k: v for k, v in synth_sd("ACT", 505, "glancer.net.", keep_prefix=False).items() if not k.startswith("classifier")}
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev)
+    x = rnd((64, 3, 224, 224), 5200).to(dev)
+    with torch.no_grad():
+        fm, fv = [t.clone() for t in net.get_featmap(x)]
+        for _ in range(5):
+            fm2, fv2 = net.get_featmap(x)
+            assert torch.equal(fm2, fm) and torch.equal(fv2, fv)
