@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/adafocus.h"
+#include <type_traits>
 
 struct adaf_handle {
     int device = 0;
@@ -137,6 +138,26 @@ bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
 bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw);
 void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s);
+
+#ifdef __HIPCC__
+// Sum over the 64 lanes of a wave; every lane ends up with the same bits.  A butterfly (1, 2, 4, 8, 16, 32) whose first four steps stay on
+// the VALU: quad permutes for 1 and 2, then the half-row and row MIRRORS for 4 and 8 -- after the step before them the lanes of a group hold
+// identical bits, so taking the mirrored lane IS the xor exchange --, ds_swizzle for 16, v_permlane32_swap for 32.  (__shfl_xor compiles to
+// ds_bpermute_b32: six dependent LDS round trips per sum -- the squeeze FC of the EfficientNet kernels spent more time in them than in its
+// filter rows.)  All 64 lanes must be active.  The SE kernels of effnet.hip and mbconv_whole.hip share it: their gates agree bit for bit.
+__device__ __forceinline__ float adaf_wave_sum(float v) {
+    auto dpp = [](float x, auto ctrl_tag) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl_tag)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>());      // quad_perm [1, 0, 3, 2]
+    v += dpp(v, std::integral_constant<int, 0x4E>());      // quad_perm [2, 3, 0, 1]
+    v += dpp(v, std::integral_constant<int, 0x141>());     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>());     // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));      // lane ^ 16
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return v + __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);                                // lane ^ 32
+}
+#endif
 
 // mbconv_whole.hip: whole-image MBConv blocks (EfficientNet, fp16 storage)
 size_t adaf_mbw_bfrag_halfs(int n, int k, bool even_tiles);

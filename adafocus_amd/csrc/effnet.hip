@@ -880,6 +880,7 @@ __global__ __launch_bounds__(NT) void se_gate_kernel(const float* __restrict__ p
     __syncthreads();
     for (int j = wave; j < SQ; j += NT / 64) {
         const float* w = wr + (size_t)j * C;
+        const float bj = br[j];            // (requested with the row, not behind the reduction)
         float s[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) s[g] = 0.f;
@@ -894,10 +895,9 @@ __global__ __launch_bounds__(NT) void se_gate_kernel(const float* __restrict__ p
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s[g] += __shfl_xor(s[g], off, 64);
+            s[g] = adaf_wave_sum(s[g]);
             if (lane == 0) {
-                const float v = s[g] + br[j];
+                const float v = s[g] + bj;
                 sq[g * SQ + j] = v * fast_sigmoid(v);
             }
         }

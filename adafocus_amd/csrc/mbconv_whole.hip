@@ -387,10 +387,12 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
         constexpr int NP = decltype(np_tag)::value;
         constexpr int SEB = NP == 4 ? 5 : NP == 6 ? 8 : 4;          // rows per wave per batch: SEB * NP 16-byte pieces in flight per lane
         f32x4 wv[SEB][NP];
+        float brv[SEB];            // the rows' biases travel with them (as a load inside `if (lane == 0)` each was a round trip of its own)
         auto se_load = [&](int j0) {
 #pragma unroll
             for (int r = 0; r < SEB; ++r) {
                 const int j = j0 + r * kMbwWaves < SQ ? j0 + r * kMbwWaves : SQ - 1;
+                brv[r] = a.se_br[j];
                 const float* wrow = a.se_wr + (size_t)j * hid + 4 * (lane < C4 ? lane : 0);      // (hid < 256: lanes past the row read lane 0's piece, never used)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) wv[r][q] = *reinterpret_cast<const f32x4*>(wrow + (lane + 64 * q < C4 ? 256 * q : 0));
@@ -435,10 +437,9 @@ __global__ __launch_bounds__(kMbwThreads) void mbconv_whole_kernel(const MbwArgs
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) sg[g] += __shfl_xor(sg[g], off, 64);
+                    sg[g] = adaf_wave_sum(sg[g]);
                     if (lane == 0 && j < SQ) {
-                        const float v = sg[g] + a.se_br[j];
+                        const float v = sg[g] + brv[r];
                         sqv[g * SQ + j] = v * w_sigmoid(v);
                     }
                 }
