@@ -1286,6 +1286,183 @@ __global__ __launch_bounds__(256) void ef_stem_kernel(const StemArgs a) {
     EF_STAMP(7);
 }
 
+// ---- stem, packed form (C0 <= 48; B3's 40): the same tile walk with the GEMM on the real problem size.  ef_stem_kernel multiplies
+// K = 9 taps x 4 channels (one of them zero) x 64 columns; here k = 3 tap + channel runs to 27 (+ one zero: 14 steps of 2), columns 0-31 are
+// one 32-column tile, and columns 32-47 a SIXTEEN-column tile on v_mfma_f32_16x16x4_f32 (two 16-row blocks x 7 steps of 4, half the
+// passes of the 32x32x2 form): 14 x 64 + 14 x 32 MFMA cycles per band instead of 36 x 64.  A lane's A value for (step, k lane) is ONE float
+// of the staged window at an offset that depends on the lane only through its k lane: the offsets are computed once per thread.  The
+// filter bank arrives in lane order from a buffer packed at finalize (no LDS round trip, no barrier).  Exact fp32 products as before, and
+// BIT-IDENTICAL to ef_stem_kernel: an fp32 MFMA adds its products in k order as a chain of fused multiply-adds, the non-zero products come
+// in the same order here, and the ones dropped were exact zeros (tests/test_effnet.py::test_packed_stem_bit_identical_to_the_k36_stem).
+struct StemPArgs {
+    const float* x4;      // [n][S][S][4]
+    const float* wl;      // packed filter bank [64 lanes][24]: 14 values of the 32-column tile, 7 of the 16-column tile, 3 x 0
+    const float* scale;   // [C0]
+    const float* bias;
+    void* out;            // [n][OH][OW][C0]
+    int n, S, OH, OW, C0, pad, act;
+    int tiles_x, tiles_y;
+#ifdef EF_TRACE
+    unsigned long long* trace;
+#endif
+};
+
+template <typename T, bool TILEB>
+__global__ __launch_bounds__(256) void ef_stem_packed_kernel(const StemPArgs a) {
+    constexpr int V = Chunk<T>::V;
+    constexpr int TH = 8, TW = 16, IH = 2 * TH + 1, IW = 2 * TW + 1;
+    constexpr int SP = 52;                                   // slab pitch in floats (48 columns + 4)
+    __shared__ __attribute__((aligned(16))) float xin[IH * IW * 4];
+    __shared__ __attribute__((aligned(16))) float slab[4][32 * SP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    EF_STAMP(0);
+    const int ty = blockIdx.x % a.tiles_y;
+    const int img = blockIdx.x / a.tiles_y;
+    const int oy0 = ty * TH;
+    const float* xb = a.x4 + (size_t)img * a.S * a.S * 4;
+    const int nl = lane & 31, half = lane >> 5;            // 32x32x2 operands: row / column nl, k lane `half`
+    const int r16 = lane & 15, kq = lane >> 4;             // 16x16x4 operands: row / column r16, k lane kq
+    // filter bank: six 16-byte loads of this lane's 24 values
+    float wA[14], wB[7];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.wl + lane * 24);
+        f32x4 t[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) t[q] = wp[q];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) wA[i] = t[i >> 2][i & 3];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) wB[i] = t[(14 + i) >> 2][(14 + i) & 3];
+    }
+    const float scA = nl < a.C0 ? a.scale[nl] : 0.f, biA = nl < a.C0 ? a.bias[nl] : 0.f;
+    const float scB = 32 + r16 < a.C0 ? a.scale[32 + r16] : 0.f, biB = 32 + r16 < a.C0 ? a.bias[32 + r16] : 0.f;
+    // window offsets (floats) of k = 3 tap + channel: tap (k / 3) -> row tap / 3, column tap % 3 of the 3 x 3 window, channel k % 3;
+    // k = 27 is the zero step (its filter value is 0: any finite A will do -- offset 0)
+    auto koff = [](int k) {
+        const int kc = k < 27 ? k : 0;
+        const int tap = (kc * 11) >> 5, ch = kc - 3 * tap;          // kc / 3 for kc < 32
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        return (ky * IW + kx) * 4 + ch;
+    };
+    int offA[14], offB[7];
+#pragma unroll
+    for (int st = 0; st < 14; ++st) offA[st] = koff(2 * st + half);
+#pragma unroll
+    for (int st = 0; st < 7; ++st) offB[st] = koff(4 * st + kq);
+    const int cpr = a.C0 / V;                                // 16-byte chunks per output pixel
+    T* ob = static_cast<T*>(a.out) + (size_t)img * a.OH * a.OW * a.C0;
+    float* sl = slab[wave];
+    // this lane's pixels of the band (row 2 wave + (p >> 4), column p & 15 for band pixel p): p = nl for the 32-row tile, p = 16 rb + r16 for the 16-row blocks
+    const float* winA = xin + ((2 * (2 * wave + (nl >> 4))) * IW + 2 * (nl & 15)) * 4;
+    const float* winB0 = xin + ((2 * (2 * wave)) * IW + 2 * r16) * 4;
+    const float* winB1 = winB0 + 2 * IW * 4;
+    constexpr int WPT = (IH * IW + 255) / 256;               // window pixels per thread
+    f32x4 wv[WPT];
+    const int iy0 = oy0 * 2 - a.pad;
+    int wr[WPT], wc[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int i = tid + 256 * u;
+        wr[u] = i / IW; wc[u] = i - wr[u] * IW;
+    }
+    auto wload = [&](int tx) {
+        const int ix0 = tx * TW * 2 - a.pad;
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int iy = iy0 + wr[u], ix = ix0 + wc[u];
+            const bool ok = (unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S;
+            wv[u] = *reinterpret_cast<const f32x4*>(xb + (ok ? ((size_t)iy * a.S + ix) * 4 : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int iy = iy0 + wr[u], ix = ix0 + wc[u];
+            if (!((unsigned)iy < (unsigned)a.S && (unsigned)ix < (unsigned)a.S)) wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    wload(0);
+    EF_STAMP(1);
+    for (int tx = 0; tx < a.tiles_x; ++tx) {
+        const int ox0 = tx * TW;
+        if (tx) __syncthreads();                              // the previous tile's window has been consumed
+#pragma unroll
+        for (int u = 0; u < WPT; ++u)
+            if (tid + 256 * u < IH * IW) *reinterpret_cast<f32x4*>(xin + (tid + 256 * u) * 4) = wv[u];
+        __syncthreads();
+        if (tx == 1) EF_STAMP(2);
+        if (tx + 1 < a.tiles_x) wload(tx + 1);
+        f32x16 acc;
+        f32x4 accB[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        accB[0] = accB[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float av[14], bv0[7], bv1[7];
+#pragma unroll
+        for (int st = 0; st < 14; ++st) av[st] = winA[offA[st]];
+        if constexpr (TILEB) {
+#pragma unroll
+            for (int st = 0; st < 7; ++st) { bv0[st] = winB0[offB[st]]; bv1[st] = winB1[offB[st]]; }
+        }
+#pragma unroll
+        for (int st = 0; st < 14; ++st) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], wA[st], acc, 0, 0, 0);
+            if constexpr (TILEB) {
+                if (st < 7) {
+                    accB[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv0[st], wB[st], accB[0], 0, 0, 0);
+                    accB[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv1[st], wB[st], accB[1], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: BN + activation, through the wave's slab, 16-byte stores of V consecutive channels
+        if (tx == 1) EF_STAMP(3);
+        __builtin_amdgcn_wave_barrier();
+        act_switch(a.act, [&](auto AC) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                sl[((i & 3) + 8 * (i >> 2) + 4 * half) * SP + nl] = act_of<decltype(AC)::value>(fmaf(acc[i], scA, biA), a.act);
+            if constexpr (TILEB) {
+                // 16x16 result: lane (column r16, k lane kq) holds rows 4 kq + i of its block
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        sl[(16 * rb + 4 * kq + i) * SP + 32 + r16] = act_of<decltype(AC)::value>(fmaf(accB[rb][i], scB, biB), a.act);
+            }
+        });
+        __builtin_amdgcn_wave_barrier();
+        if (tx == 1) EF_STAMP(4);
+        for (int i = lane; i < 32 * cpr; i += 64) {
+            const int p = i / cpr, cq = i - p * cpr;
+            const int oy = oy0 + 2 * wave + (p >> 4), ox = ox0 + (p & 15);
+            if (oy < a.OH && ox < a.OW) {
+                float v[V];
+#pragma unroll
+                for (int e = 0; e < V; e += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(sl + p * SP + cq * V + e);
+                    v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+                }
+                *reinterpret_cast<u32x4*>(ob + ((size_t)oy * a.OW + ox) * a.C0 + cq * V) = Chunk<T>::pack(v);
+            }
+        }
+        if (tx == 1) EF_STAMP(5);
+        if (tx == 0) EF_STAMP(6);
+    }
+    EF_STAMP(7);
+}
+
+// [C0][3][3][4] (the stem filter as the engine packs it: tap-major, 4 channels) -> the packed kernel's per-lane bank [64][24]:
+// o[lane][st] (st < 14) = w[lane & 31][k = 2 st + (lane >> 5)], o[lane][14 + st] (st < 7) = w[32 + (lane & 15)][k = 4 st + (lane >> 4)], k = 3 tap + channel
+__global__ void pack_stem_bank_kernel(const float* __restrict__ w, int c0, float* __restrict__ o) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * 24) return;
+    const int lane = idx / 24, j = idx - lane * 24;
+    int col, k;
+    if (j < 14) { col = lane & 31; k = 2 * j + (lane >> 5); }
+    else if (j < 21) { col = 32 + (lane & 15); k = 4 * (j - 14) + (lane >> 4); }
+    else { o[idx] = 0.f; return; }
+    const int tap = k / 3, ch = k - 3 * tap;
+    o[idx] = (col < c0 && k < 27) ? w[(size_t)col * 36 + tap * 4 + ch] : 0.f;
+}
+
 // [C,1,K,K] (PyTorch depthwise) -> [K*K][C]
 __global__ void pack_dw_kxk_kernel(const float* __restrict__ w, int c, int kk, float* __restrict__ o) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1628,17 +1805,40 @@ int adaf_launch_gated_project(const void* x, int dtype, int m, int hw, int k, co
 }
 
 // returns false when the shape is not the one the stem kernel is written for (C0 <= 64, chunks of whole 16 bytes)
-bool adaf_launch_ef_stem(const float* x4, int dtype, int n, int size, int oh, int ow, int pad, const float* w, const float* scale,
+void adaf_launch_pack_stem_bank(const float* w, int c0, float* o, hipStream_t s) {
+    hipLaunchKernelGGL(pack_stem_bank_kernel, dim3(6), dim3(256), 0, s, w, c0, o);
+}
+
+// bank: the packed filter bank of adaf_launch_pack_stem_bank (C0 <= 48: the packed kernel) or nullptr
+bool adaf_launch_ef_stem(const float* x4, int dtype, int n, int size, int oh, int ow, int pad, const float* w, const float* bank, const float* scale,
                          const float* bias, int c0, int act, void* out, hipStream_t s) {
     const int v = dtype == ADAF_DTYPE_F16 ? 8 : 4;
     if (c0 > 64 || c0 % v) return false;
+    const dim3 block(256);
+    if (bank && c0 <= 48 && (adaf_options().effnet_plan & ADAF_EF_PLAN_PACKED_STEM)) {
+        StemPArgs a;
+        a.x4 = x4; a.wl = bank; a.scale = scale; a.bias = bias; a.out = out; a.n = n; a.S = size; a.OH = oh; a.OW = ow; a.C0 = c0; a.pad = pad; a.act = act;
+        a.tiles_x = (ow + 15) / 16; a.tiles_y = (oh + 7) / 8;
+#ifdef EF_TRACE
+        a.trace = ef_trace_k == -1 ? ef_trace_buf : nullptr;
+#endif
+        const dim3 grid((unsigned)((size_t)n * a.tiles_y));
+        if (dtype == ADAF_DTYPE_F16) {
+            if (c0 > 32) hipLaunchKernelGGL((ef_stem_packed_kernel<_Float16, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((ef_stem_packed_kernel<_Float16, false>), grid, block, 0, s, a);
+        } else {
+            if (c0 > 32) hipLaunchKernelGGL((ef_stem_packed_kernel<float, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((ef_stem_packed_kernel<float, false>), grid, block, 0, s, a);
+        }
+        return true;
+    }
     StemArgs a;
     a.x4 = x4; a.w = w; a.scale = scale; a.bias = bias; a.out = out; a.n = n; a.S = size; a.OH = oh; a.OW = ow; a.C0 = c0; a.pad = pad; a.act = act;
     a.tiles_x = (ow + 15) / 16; a.tiles_y = (oh + 7) / 8;
 #ifdef EF_TRACE
     a.trace = ef_trace_k == -1 ? ef_trace_buf : nullptr;         // (adaf_ef_set_trace(buf, 0, -1, 0) traces the stem)
 #endif
-    const dim3 grid((unsigned)((size_t)n * a.tiles_y)), block(256);
+    const dim3 grid((unsigned)((size_t)n * a.tiles_y));
     if (dtype == ADAF_DTYPE_F16) hipLaunchKernelGGL((ef_stem_kernel<_Float16>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((ef_stem_kernel<float>), grid, block, 0, s, a);
     return true;
@@ -1685,6 +1885,7 @@ struct adaf_effnet {
     // stride 1, maps up to 9 x 9).  On by default; adaf_effnet_set_fusion(net, 0) restores the four-launch plan (tests, A/B).
     bool fuse = true;
     bool finalized = false;
+    float* stem_bank = nullptr;      // the stem filter in the packed kernel's lane order (C0 <= 48; ef_stem_packed_kernel)
     // Every derived weight buffer (packed filters, folded BN, SE matrices, B fragments) is carved out of a few large slabs: a
     // launch of the whole-block kernel reads ~14 of them, and as separate small hipMalloc()s each sat in pages of its own.
     std::vector<void*> slabs;
@@ -1968,6 +2169,13 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
         }
         adaf_launch_fold_bn(g, b, m, v, 1e-3f, L.cout, L.scale, L.bias, st);     // utils.py: batch_norm_epsilon = 1e-3
     }
+    {
+        const EfConv& S = net->convs[net->stem];
+        if (S.cout <= 48 && S.k == 3 && S.cin_pad == 4) {
+            if (!net->stem_bank && !(net->stem_bank = static_cast<float*>(net->carve(64 * 24 * 4)))) return efail(h, ADAF_E_NOMEM, "effnet: hipMalloc");
+            adaf_launch_pack_stem_bank(S.w, S.cout, net->stem_bank, st);
+        }
+    }
     for (size_t bi = 0; bi < net->blocks.size(); ++bi) {
         EfBlock& b = net->blocks[bi];
         char nm[48];
@@ -2052,7 +2260,7 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
         const EfConv& S = net->convs[net->stem];
         const unsigned plan = adaf_options().effnet_plan;
         const bool own_stem = (plan & ADAF_EF_PLAN_OWN_STEM) != 0;       // off = the generic engine (A/B)
-        if (!(own_stem && adaf_launch_ef_stem(frames_nhwc4 + (size_t)f0 * size * size * 4, net->dtype, nc, size, hw, hw, pb0, S.w, S.scale, S.bias,
+        if (!(own_stem && adaf_launch_ef_stem(frames_nhwc4 + (size_t)f0 * size * size * 4, net->dtype, nc, size, hw, hw, pb0, S.w, net->stem_bank, S.scale, S.bias,
                                               S.cout, ADAF_ACT_SWISH, cur, st)) &&
             (rc = run_dense(net, S, frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size, hw, hw, pb0, ADAF_ACT_SWISH, cur, f16, st)))
             return efail(h, rc, "effnet: stem launch");

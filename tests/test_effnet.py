@@ -507,3 +507,25 @@ def test_b3_fp16_forward_is_the_same_from_run_to_run(dev, size, image_size):
         ref = m.features_nhwc4(x4).clone()
         for _ in range(5):
             assert torch.equal(m.features_nhwc4(x4), ref), size
+
+
+@pytest.mark.parametrize("name,dtype,size", [("efficientnet-b3", "f32", 144), ("efficientnet-b3", "f32", 100), ("efficientnet-b3", "f16", 75),
+                                              ("efficientnet-b0", "f32", 96), ("efficientnet-b3", "f16", 144)])
+def test_packed_stem_bit_identical_to_the_k36_stem(dev, name, dtype, size):
+    """The stem with k packed to 27 (+ 1) and columns 32-47 on a 16-column MFMA tile (ef_stem_packed_kernel; B3's 40 channels: 14 x
+    32x32x2 + 14 x 16x16x4 steps per band) against the K = 36 x 64-column form (option bit ADAF_EF_PLAN_PACKED_STEM off).  An fp32 MFMA
+    adds its products in k order as a chain of fused multiply-adds (tools/exp/mfma_order_test.hip), the packed form visits the
+    non-zero products in the same order and the dropped ones were exact zeros: torch.equal, in both storage modes, on ragged tiles
+    (100, 75) and for a 32-channel stem (B0: no second tile)."""
+    from adafocus_amd import _lib as L
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, name, 200, dtype=dtype)
+    x4 = nchw_to_nhwc4(_smooth((3, 3, size, size), 880 + size).to(dev))
+    plan = int(L.get_option("effnet_plan"))
+    assert plan & L.EF_PLAN_PACKED_STEM
+    with torch.no_grad():
+        new = m.engine().forward_blocks(x4, 0).float().clone()
+        with L.option("effnet_plan", plan & ~L.EF_PLAN_PACKED_STEM):
+            old = m.engine().forward_blocks(x4, 0).float().clone()
+    assert new.shape == old.shape and torch.isfinite(new).all() and float(new.abs().max()) > 0.1
+    assert torch.equal(new, old)
