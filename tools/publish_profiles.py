@@ -123,8 +123,8 @@ print("traffic: %d dispatches over %d passes, %.1f MB / launch" % (fd, passes, p
 # EfficientNet-B3 (config 5): HBM bytes per patch of the whole forward, every kernel counted
 ef_f, ef_w = os.path.join(PROF, "%s_effnet_f16_fetch.md" % tag), os.path.join(PROF, "%s_effnet_f16_write.md" % tag)
 if os.path.exists(ef_f) and os.path.exists(ef_w):
-    fs, nf = all_kernels_sum(ef_f, "FETCH_SIZE", "ef_stem_kernel")
-    ws, nw = all_kernels_sum(ef_w, "WRITE_SIZE", "ef_stem_kernel")
+    fs, nf = all_kernels_sum(ef_f, "FETCH_SIZE", "ef_stem_")
+    ws, nw = all_kernels_sum(ef_w, "WRITE_SIZE", "ef_stem_")
     per_patch = int((2 * fs / max(nf, 1) + ws / max(nw, 1)) * 1024 / 1024)
     json.dump({"source": "profiles/%s_effnet_f16_fetch.md + %s_effnet_f16_write.md (rocprofv3 --pmc, separate passes, EVERY kernel of the forward)" % (tag, tag),
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per forward / 1024 patches (FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950)",
