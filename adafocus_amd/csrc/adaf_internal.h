@@ -39,7 +39,7 @@ struct AdafOptions {
     int mbv2_chunk = 512;         // "mbv2_chunk": frames per chunk of the MobileNetV2 forward
     int latency_rows = 1536;      // "latency_rows": GEMM rows up to which a new trunk sends convs to the small-batch form
     int latency_linear_rows = 128;  // "latency_linear_rows": the same for adaf_linear / GRU projections
-    unsigned effnet_plan = 127u;  // "effnet_plan": ADAF_EF_PLAN_* bits
+    unsigned effnet_plan = 255u;  // "effnet_plan": ADAF_EF_PLAN_* bits
     unsigned effnet_fused_blocks = 0xffffffffu;   // "effnet_fused_blocks": MBConv blocks (bit = block index) the fused expand + depthwise launch may take
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
     int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)
@@ -185,6 +185,7 @@ int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s); 
 int adaf_pick_conv_tile(int M, int N, int K, int cus);
 int adaf_launch_conv_lat(const ConvArgs& a, hipStream_t s);   // conv_lat.hip: small-batch form (tile id 95), 1 = launched, 0 = not eligible
 int adaf_launch_conv_pool(ConvArgs a, int hw, float* pool_out, int pool_ld, hipStream_t s);   // 1 = launched (tile id 96), 0 = not eligible
+int adaf_launch_conv_pool16(ConvArgs a, int hw, float* pool_out, int pool_ld, hipStream_t s); // fp16 operands (EfficientNet's head); same return
 bool adaf_conv_tile_exists(int tile);   // is `tile` an id adaf_launch_conv_gemm has a kernel for
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
 // conv2 3x3 (64 -> 64) -> conv3 1x1 (+ identity, ReLU) [-> the next block's conv1 1x1] in one launch (stage 1 of the trunk);

@@ -288,7 +288,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a0, float* smem, f
 // parks the activated values in an LDS tile; after one barrier a thread per (image, channel) adds the pool_hw pixels IN PIXEL
 // ORDER and divides by pool_hw -- the order and the operations of avgpool_kernel (misc_ops.hip), so the features are
 // bit-identical to conv + separate pool (tests/test_hip_parity_r3.py).  Saves the 75 MB map's round trip and a launch.
-template <int TM, int TN, int BM, int BN, int NW>
+// SIG (fp16-operand launches: EfficientNet's head conv, adaf_launch_conv_pool16): the activation may be swish / sigmoid, finished by
+// finish_act exactly as conv_epilogue does (clamp bounds open for them), so the pooled features are the bits of conv + avgpool_kernel.
+template <int TM, int TN, int BM, int BN, int NW, bool SIG = false>
 __device__ __forceinline__ void conv_epilogue_pool(const ConvArgs& a, float* smem, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                    int lane, int wave, int tile_m) {
     constexpr int WM = TM * 32, WN = TN * 32, SP = WN + 4, PP = BN + 4;
@@ -303,7 +305,8 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvArgs& a, float* sme
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nn) : one4;
     const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nn) : zero4;
-    const float act_lo = a.act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
+    const int sig = !SIG ? 0 : a.act == ADAF_ACT_SIGMOID ? 1 : a.act == ADAF_ACT_SWISH ? 2 : 0;
+    const float act_lo = (a.act == ADAF_ACT_NONE || sig) ? -__builtin_inff() : 0.f;
     const float act_hi = a.act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -326,6 +329,7 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvArgs& a, float* sme
             o.y = fminf(fmaxf(fmaf(v.y, sc.y, bi.y) + rv.y, act_lo), act_hi);
             o.z = fminf(fmaxf(fmaf(v.z, sc.z, bi.z) + rv.z, act_lo), act_hi);
             o.w = fminf(fmaxf(fmaf(v.w, sc.w, bi.w) + rv.w, act_lo), act_hi);
+            if constexpr (SIG) { o.x = finish_act(o.x, sig); o.y = finish_act(o.y, sig); o.z = finish_act(o.z, sig); o.w = finish_act(o.w, sig); }
             *reinterpret_cast<f32x4*>(P + lrow * PP + wn * WN + 4 * c4) = o;
         }
     }
@@ -564,7 +568,7 @@ template <int BM, int BN, int WGM, int WGN, bool DENSE, int PIPE, bool SPECIAL, 
           bool LEAN = false, bool POOL = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (BM == 128 && BN == 128 && WGM * WGN == 4) ? 2 : 1)   // 128x128: two blocks per CU
 void conv_gemm_glds_kernel(const ConvArgs a) {
-    static_assert(!POOL || (LEAN && DENSE && DT == 0), "pooled epilogue: the lean dense fp32 kernel");
+    static_assert(!POOL || (DENSE && !SPECIAL && ((LEAN && DT == 0) || (!LEAN && DT == 4))), "pooled epilogue: the lean dense fp32 kernel, or the dense fp16-operand kernel with fp32 features");
     static_assert(!PM || (!DENSE && (EMU == 0 || BSP) && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe, or split tiles with pre-split weights");
     static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && EMU == 0 && !BSP && PIPE == 1), "lean K loop: plain fp32-pipe launches");
     constexpr int NW = WGM * WGN;
@@ -1087,7 +1091,7 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
     }
     __syncthreads();   // all fragment reads done before the slabs overwrite the stage buffers
     if constexpr (POOL) {
-        conv_epilogue_pool<TM, TN, BM, BN, NW>(a, smem, acc, m0, n0, wm, wn, lane, wave, tile_m);
+        conv_epilogue_pool<TM, TN, BM, BN, NW, (DT & 4) != 0>(a, smem, acc, m0, n0, wm, wn, lane, wave, tile_m);
         return;
     }
     if (PM) conv_epilogue<TM, TN, (DT & 3)>(a, smem, acc, m0, n0, wm, wn, lane, wave, a.OH * a.OW, pm_p, a.pm_images);
@@ -1870,6 +1874,22 @@ int adaf_launch_conv_pool(ConvArgs a, int hw, float* pool_out, int pool_ld, hipS
     a.tiles_n = (a.N + 63) / 64;
     a.nblocks = ((a.M + a.pool_rows - 1) / a.pool_rows) * a.tiles_n;
     hipLaunchKernelGGL((conv_gemm_glds_kernel<128, 64, 2, 2, true, 1, false, 0, false, 0, false, true, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return 1;
+}
+
+// The same for fp16 operands and fp32 features (EfficientNet's head conv 1x1 + BN + swish + global average pool, effnet.hip): the 128 x 64
+// tile of launch_glds16 -- the tile the unfused head conv runs on, same MFMA instruction and k order -- with whole images per tile and
+// conv_epilogue_pool<SIG>.  `a` arrives in ELEMENT units like adaf_launch_conv_gemm's fp16 launches.  1 = launched, 0 = not eligible.
+int adaf_launch_conv_pool16(ConvArgs a, int hw, float* pool_out, int pool_ld, hipStream_t s) {
+    if (!adaf_options().conv_pool) return 0;
+    if (!a.in16 || a.out16 || a.res || a.split_n || a.tsm_T > 0 || a.wsp || !conv_glds16_ok(a)) return 0;
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || (a.K & 63) || (a.N & 3) || !a.vec_epi) return 0;
+    if (hw <= 0 || hw > 128 || a.M % hw || (128 / hw) * hw * 10 < 128 * 9 || (pool_ld & 3) || (reinterpret_cast<size_t>(pool_out) & 15)) return 0;
+    a.pool_hw = hw; a.pool_rows = (128 / hw) * hw; a.pool_out = pool_out; a.pool_ld = pool_ld;
+    a.tiles_n = (a.N + 63) / 64;
+    a.nblocks = ((a.M + a.pool_rows - 1) / a.pool_rows) * a.tiles_n;
+    a.K /= 2; a.cin /= 2; a.ldx /= 2;
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<128, 64, 2, 2, true, 1, false, 0, false, 4, false, false, true>), dim3(a.nblocks), dim3(256), 0, s, a);
     return 1;
 }
 

@@ -2325,6 +2325,20 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             continue;
         }
         float* fm = featmap ? featmap + (size_t)f0 * hw * hw * net->feat : reinterpret_cast<float*>(bufE);
+        // fp16 storage, pooled features only: the head conv with the global average pool in its epilogue (conv_gemm.hip
+        // adaf_launch_conv_pool16: no fp32 map -- 157 MB per 1024 patches of 144^2 -- and one launch; the bits of conv + avgpool_kernel)
+        if (f16 && featvec && !featmap && (plan & ADAF_EF_PLAN_HEAD_POOL) && net->feat % 4 == 0 && ldvec % 4 == 0) {
+            const EfConv& Hc = net->convs[net->head];
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = reinterpret_cast<const float*>(cur); a.w = reinterpret_cast<const float*>(Hc.w16);
+            a.scale = Hc.scale; a.bias = Hc.bias;
+            a.M = nc * hw * hw; a.N = Hc.cout; a.K = Hc.cin_pad;
+            a.cin = Hc.cin_pad; a.H = a.OH = hw; a.W = a.OW = hw; a.KH = a.KW = 1; a.stride = 1;
+            a.ldx = Hc.cin_pad; a.ldo = Hc.cout; a.ldr = Hc.cout; a.act = ADAF_ACT_SWISH;
+            a.zeros = net->h->zeros; a.vec_epi = 1; a.in16 = 1;
+            if (adaf_launch_conv_pool16(a, hw * hw, featvec + (size_t)f0 * ldvec, ldvec, st)) continue;
+        }
         if ((rc = run_dense(net, net->convs[net->head], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, fm, false, st)))
             return efail(h, rc, "effnet: head launch");
         if (featvec) {

@@ -529,3 +529,31 @@ def test_packed_stem_bit_identical_to_the_k36_stem(dev, name, dtype, size):
             old = m.engine().forward_blocks(x4, 0).float().clone()
     assert new.shape == old.shape and torch.isfinite(new).all() and float(new.abs().max()) > 0.1
     assert torch.equal(new, old)
+
+
+@pytest.mark.parametrize("name,size,n", [("efficientnet-b3", 144, 7), ("efficientnet-b3", 96, 30), ("efficientnet-b3", 128, 9),
+                                         ("efficientnet-b0", 144, 3), ("efficientnet-b3", 224, 2)])
+def test_head_conv_with_pool_in_its_epilogue_bit_identical(dev, name, size, n):
+    """fp16 storage, pooled features: the head conv (1x1 + BN + swish) with the global average pool in its epilogue (conv_gemm.hip
+    adaf_launch_conv_pool16, option bit ADAF_EF_PLAN_HEAD_POOL: whole images per 128-row tile, the activated tile parked in LDS, a
+    thread per (image, 4 channels) adds the pixels in pixel order and divides) against head conv -> fp32 map -> avgpool_kernel: same
+    MFMA instruction and k order, same epilogue arithmetic, same order of the pool's additions -- torch.equal.  25 / 9 / 16-pixel maps
+    (5 / 14 / 8 images per tile: n leaves a ragged last tile, and at 96^2 more than two tiles); 7 x 7 maps (224^2) fill a tile to 77 %
+    and keep the two launches, as does the unpooled map."""
+    from adafocus_amd import _lib as L
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, name, 200, dtype="f16")
+    x4 = nchw_to_nhwc4(_smooth((n, 3, size, size), 1300 + size).to(dev))
+    plan = int(L.get_option("effnet_plan"))
+    assert plan & L.EF_PLAN_HEAD_POOL
+    with torch.no_grad():
+        new = m.features_nhwc4(x4).clone()
+        fmap = m.extract_features(x4[..., :3].permute(0, 3, 1, 2).contiguous()).float()
+        with L.option("effnet_plan", plan & ~L.EF_PLAN_HEAD_POOL):
+            old = m.features_nhwc4(x4).clone()
+    assert new.shape == old.shape and new.shape[0] == n
+    assert torch.isfinite(new).all() and float(new.abs().max()) > 1e-3
+    assert torch.equal(new, old)
+    pooled = fmap.mean(dim=(2, 3))
+    assert (pooled - new).abs().max().item() < 1e-5 * max(1.0, float(pooled.abs().max()))
+    assert (new[0] - new[1]).abs().max().item() > 1e-3            # the images really differ
