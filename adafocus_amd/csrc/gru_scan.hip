@@ -87,11 +87,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const bool fc = a.fcw != nullptr;
     const int steps_total = T + (fc ? 1 : 0);
     const int nchunk = (B - bbeg + 63) >> 6;
+    // What the gate math of a step needs besides the products -- the step's input projections, the previous state of the thread's own
+    // (clip, unit) -- does not depend on the products: it is REQUESTED BEFORE them (three HBM / L2 round trips that used to start behind the
+    // step's block barrier), and the hidden biases are per-thread constants of the whole scan (256 % JB == 0: a thread keeps its unit).
+    constexpr int GIT = (64 * JB + 255) / 256;              // gate elements per thread and chunk of 64 clips
+    static_assert(256 % JB == 0, "a thread keeps its hidden unit across its gate elements");
+    const int gj = j0 + tid % JB;
+    const float bh_r = a.bhh[gj], bh_z = a.bhh[H + gj], bh_n = a.bhh[2 * H + gj];
     for (int t = 0; t < steps_total; ++t) {
         const bool have_prev = t > 0 || a.h0 != nullptr;
         for (int ch = 0; ch < nchunk; ++ch) {
             const int b0 = bbeg + (ch << 6);
             const int rows = B - b0 < 64 ? B - b0 : 64;
+            float g_r[GIT], g_z[GIT], g_n[GIT], g_hp[GIT];
+            if (t < T) {
+#pragma unroll
+                for (int it = 0; it < GIT; ++it) {
+                    const int idx = tid + 256 * it;
+                    const int b = b0 + (idx < rows * JB ? idx / JB : 0);
+                    const float* gir = a.gi + ((size_t)b * T + t) * 3 * H + gj;
+                    g_r[it] = gir[0]; g_z[it] = gir[H]; g_n[it] = gir[2 * H];
+                    g_hp[it] = !have_prev ? 0.f : t > 0 ? a.hs[((size_t)b * T + (t - 1)) * H + gj] : a.h0[(size_t)b * H + gj];
+                }
+            }
             if (have_prev) {
                 const int mt = (rows + 31) >> 5;
                 for (int m = 0; m < mt; ++m) {
@@ -115,20 +133,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 __syncthreads();
             }
             if (t < T) {
-                for (int idx = tid; idx < rows * JB; idx += 256) {
+#pragma unroll
+                for (int it = 0; it < GIT; ++it) {
+                    const int idx = tid + 256 * it;
+                    if (idx >= rows * JB) break;
                     const int bl = idx / JB, jj = idx - bl * JB, j = j0 + jj, b = b0 + bl;
-                    float hr = a.bhh[j], hz = a.bhh[H + j], hn = a.bhh[2 * H + j], hp = 0.f;
+                    float hr = bh_r, hz = bh_z, hn = bh_n;
+                    const float hp = g_hp[it];
                     if (have_prev) {
                         const int m = bl >> 5, row = bl & 31;
                         hr += (red[0][m][row][jj] + red[1][m][row][jj]) + (red[2][m][row][jj] + red[3][m][row][jj]);
                         hz += (red[0][m][row][JB + jj] + red[1][m][row][JB + jj]) + (red[2][m][row][JB + jj] + red[3][m][row][JB + jj]);
                         hn += (red[0][m][row][2 * JB + jj] + red[1][m][row][2 * JB + jj]) + (red[2][m][row][2 * JB + jj] + red[3][m][row][2 * JB + jj]);
-                        hp = t > 0 ? a.hs[((size_t)b * T + (t - 1)) * H + j] : a.h0[(size_t)b * H + j];
                     }
-                    const float* gir = a.gi + ((size_t)b * T + t) * 3 * H;
-                    const float r = sigm(gir[j] + hr);
-                    const float z = sigm(gir[H + j] + hz);
-                    const float nn = tanhf(gir[2 * H + j] + r * hn);
+                    const float r = sigm(g_r[it] + hr);
+                    const float z = sigm(g_z[it] + hz);
+                    const float nn = tanhf(g_n[it] + r * hn);
                     a.hs[((size_t)b * T + t) * H + j] = (1.f - z) * nn + z * hp;
                 }
             }

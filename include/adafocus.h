@@ -414,6 +414,9 @@ int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size);
  * expanded map of those blocks never exists in HBM.  Same arithmetic per stored value as the two launches (the two MFMA shapes
  * give the same bits); the tile plan, and with it the order of the squeeze partial sums, is its own. */
 int adaf_effnet_fused_expand_blocks(const adaf_effnet* net, int size, int pad_size);
+/* ADAF_EF_PLAN_HEAD_POOL (fp16 storage, `features` requested without `featmap`, head maps that fill a 128-row tile to >= 90 %: 3 x 3, 4 x 4,
+ * 5 x 5): the head conv 1x1 + BN + swish does not write its fp32 map -- the global average pool runs in the conv launch's epilogue
+ * (csrc/conv_gemm.hip adaf_launch_conv_pool16), adding a map's pixels in pixel order and dividing, as the pool launch does: the same bits. */
 int adaf_effnet_set_param(adaf_effnet* net, const char* name, const float* dev_ptr, size_t numel);
 int adaf_effnet_finalize(adaf_effnet* net, void* stream);
 size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int pad_size);
