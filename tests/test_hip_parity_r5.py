@@ -382,3 +382,33 @@ def test_glancer_is_the_same_from_run_to_run(dev):
         for _ in range(5):
             fm2, fv2 = net.get_featmap(x)
             assert torch.equal(fm2, fm) and torch.equal(fv2, fv)
+
+
+@pytest.mark.parametrize("n,tsm", [(520, 0), (512, 8), (520, 8), (600, 0)])
+def test_glancer_half_chunk_pairs_equal_small_chunks(dev, n, tsm):
+    """A glancer batch that fits one chunk but holds >= 512 frames travels as a PAIR of half chunks on the two streams (csrc/mobilenetv2.hip
+    chunk_frames; whole clips per chunk under the temporal shift: 65 clips of 8 -> 33 + 32): the frames' map and pooled vector equal, bit
+    for bit, what chunks of 128 frames give -- a frame's arithmetic does not depend on the chunk it travels in -- several times over (chunk limit
+    1024 here so that odd halves occur; at the default limit of 512 the rule takes exactly 512 frames)."""
+    from adafocus_amd import _lib as L
+    from adafocus_amd.mobilenet import mobilenet_v2
+    from adafocus_amd.utils import nchw_to_nhwc4
+    from tests.helpers import rnd
+    net = mobilenet_v2().eval()
+    sd = {k: v for k, v in synth_sd("ACT", 505, "glancer.net.", keep_prefix=False).items() if not k.startswith("classifier")}
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev)
+    x4 = nchw_to_nhwc4(rnd((n, 3, 64, 64), 5300 + n + tsm).to(dev))
+
+    def run():
+        out = net._engine.features(x4, tsm, 8) if tsm else net._engine.features(x4)
+        return [t.clone() for t in out]
+    with torch.no_grad():
+        with L.option("mbv2_chunk", 128):
+            ref = run()
+        for _ in range(3):
+            with L.option("mbv2_chunk", 1024):        # (the default, 512, pairs exactly 512 frames: the Something-Something batch)
+                got = run()
+            assert len(got) == len(ref) == 2
+            for g, r in zip(got, ref):
+                assert torch.isfinite(g).all() and float(g.abs().max()) > 1e-3 and torch.equal(g, r)
