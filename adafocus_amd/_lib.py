@@ -167,7 +167,7 @@ def handle(device):
     return _handles[idx]
 
 
-EF_PLAN_WHOLE_BLOCK, EF_PLAN_TINY_DW, EF_PLAN_STRIP_PROJECT, EF_PLAN_STRIP_EXPAND, EF_PLAN_OWN_STEM, EF_PLAN_FUSED_EXPAND, EF_PLAN_PACKED_STEM, EF_PLAN_HEAD_POOL = 1, 2, 4, 8, 16, 32, 64, 128
+EF_PLAN_WHOLE_BLOCK, EF_PLAN_TINY_DW, EF_PLAN_STRIP_PROJECT, EF_PLAN_STRIP_EXPAND, EF_PLAN_OWN_STEM, EF_PLAN_FUSED_EXPAND, EF_PLAN_PACKED_STEM, EF_PLAN_HEAD_POOL, EF_PLAN_PAIR_CHUNKS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 def get_option(key):

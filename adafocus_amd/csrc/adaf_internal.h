@@ -39,7 +39,7 @@ struct AdafOptions {
     int mbv2_chunk = 512;         // "mbv2_chunk": frames per chunk of the MobileNetV2 forward
     int latency_rows = 1536;      // "latency_rows": GEMM rows up to which a new trunk sends convs to the small-batch form
     int latency_linear_rows = 128;  // "latency_linear_rows": the same for adaf_linear / GRU projections
-    unsigned effnet_plan = 255u;  // "effnet_plan": ADAF_EF_PLAN_* bits
+    unsigned effnet_plan = 511u;  // "effnet_plan": ADAF_EF_PLAN_* bits
     unsigned effnet_fused_blocks = 0xffffffffu;   // "effnet_fused_blocks": MBConv blocks (bit = block index) the fused expand + depthwise launch may take
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
     int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)

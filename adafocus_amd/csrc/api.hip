@@ -79,7 +79,7 @@ namespace {
 struct OptKey { const char* name; int kind; double lo, hi; };      // kind: index into the switch of opt_ref
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
-                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 255}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
+                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 511}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
                            {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}, {"gru_barrier", 15, 0, 1}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

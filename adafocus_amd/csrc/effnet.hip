@@ -1886,6 +1886,11 @@ struct adaf_effnet {
     bool fuse = true;
     bool finalized = false;
     float* stem_bank = nullptr;      // the stem filter in the packed kernel's lane order (C0 <= 48; ef_stem_packed_kernel)
+    // Two patch chunks travel through the network side by side (ADAF_EF_PLAN_PAIR_CHUNKS; the second on a library-owned stream forked from
+    // and joined to the caller's stream by events, one helper per caller stream -- as adaf_mobilenetv2 does): the launches of the 9 x 9 and
+    // 5 x 5 stages, the SE gates and every launch's ramp and tail leave room that a neighbour fills.
+    struct Aux { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    std::map<hipStream_t, Aux> aux;
     // Every derived weight buffer (packed filters, folded BN, SE matrices, B fragments) is carved out of a few large slabs: a
     // launch of the whole-block kernel reads ~14 of them, and as separate small hipMalloc()s each sat in pages of its own.
     std::vector<void*> slabs;
@@ -2013,6 +2018,9 @@ void slab_sizes(const adaf_effnet* net, int size, int pad_size, int dtype, size_
 
 int chunk_frames(int n) {
     const int c = adaf_options().effnet_chunk > 0 ? adaf_options().effnet_chunk : 1024;
+    // a batch that fits one chunk but holds >= 512 patches travels as a pair of half chunks (see adaf_effnet::Aux): 1024 patches of
+    // 144^2 6.21 -> 5.95 ms (tools/effnet_streams_probe.py); a patch's arithmetic does not depend on the chunk it travels in
+    if ((adaf_options().effnet_plan & ADAF_EF_PLAN_PAIR_CHUNKS) && n <= c && n >= 512) return (n + 1) / 2;
     return n < c ? n : c;
 }
 
@@ -2051,6 +2059,11 @@ int adaf_effnet_create(adaf_handle* h, float width_coefficient, float depth_coef
 int adaf_effnet_destroy(adaf_effnet* net) {
     if (!net) return ADAF_OK;
     for (void* p : net->slabs) (void)hipFree(p);
+    for (auto& kv : net->aux) {
+        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+        if (kv.second.ev_fork) (void)hipEventDestroy(kv.second.ev_fork);
+        if (kv.second.ev_join) (void)hipEventDestroy(kv.second.ev_join);
+    }
     delete net;
     return ADAF_OK;
 }
@@ -2220,8 +2233,9 @@ size_t adaf_effnet_workspace_bytes(const adaf_effnet* net, int n, int size, int 
     const size_t es = net->dtype == ADAF_DTYPE_F16 ? 2 : 4;
     const int chunk = chunk_frames(n);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al((size_t)chunk * io * es) * 2 + al((size_t)chunk * ex * es) + al((size_t)chunk * dw * es) + al((size_t)chunk * pc * 4) +
-           al((size_t)chunk * gc * 4);
+    const size_t per_chunk = al((size_t)chunk * io * es) * 2 + al((size_t)chunk * ex * es) + al((size_t)chunk * dw * es) + al((size_t)chunk * pc * 4) +
+                             al((size_t)chunk * gc * 4);
+    return per_chunk * (n > chunk ? 2 : 1);      // two chunks in flight (whether or not the pairing is switched on)
 }
 
 int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int size, int pad_size, int upto_block, void* block_out,
@@ -2242,16 +2256,16 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
     slab_sizes(net, size, pad_size, net->dtype, &io, &ex, &dws, &pc, &gc);
     const int chunk = chunk_frames(n);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    char* base = static_cast<char*>(ws);
-    char* bufA = base;
-    char* bufB = bufA + al((size_t)chunk * io * es);
-    char* bufE = bufB + al((size_t)chunk * io * es);
-    char* bufD = bufE + al((size_t)chunk * ex * es);
-    float* part = reinterpret_cast<float*>(bufD + al((size_t)chunk * dws * es));
-    float* gate = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + al((size_t)chunk * pc * 4));
-
-    for (int f0 = 0; f0 < n; f0 += chunk) {
-        const int nc = (n - f0) < chunk ? (n - f0) : chunk;
+    const size_t per_chunk = al((size_t)chunk * io * es) * 2 + al((size_t)chunk * ex * es) + al((size_t)chunk * dws * es) + al((size_t)chunk * pc * 4) +
+                             al((size_t)chunk * gc * 4);
+    // one chunk of patches through the whole network on stream `st` with its own part of the workspace
+    auto run_chunk = [&](int f0, int nc, char* base, hipStream_t st) -> int {
+        char* bufA = base;
+        char* bufB = bufA + al((size_t)chunk * io * es);
+        char* bufE = bufB + al((size_t)chunk * io * es);
+        char* bufD = bufE + al((size_t)chunk * ex * es);
+        float* part = reinterpret_cast<float*>(bufD + al((size_t)chunk * dws * es));
+        float* gate = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + al((size_t)chunk * pc * 4));
         int rc, tot;
         const int pb0 = same_pad(pad_size, 3, 2, &tot);
         int hw = conv_out_len(size, 3, 2, tot), ps = ceil_div(pad_size, 2);
@@ -2322,7 +2336,7 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
         if (upto_block >= 0) {
             (void)hipMemcpyAsync(static_cast<char*>(block_out) + (size_t)f0 * out_elems * es, cur, (size_t)nc * out_elems * es,
                                  hipMemcpyDeviceToDevice, st);
-            continue;
+            return ADAF_OK;
         }
         float* fm = featmap ? featmap + (size_t)f0 * hw * hw * net->feat : reinterpret_cast<float*>(bufE);
         // fp16 storage, pooled features only: the head conv with the global average pool in its epilogue (conv_gemm.hip
@@ -2337,7 +2351,7 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             a.cin = Hc.cin_pad; a.H = a.OH = hw; a.W = a.OW = hw; a.KH = a.KW = 1; a.stride = 1;
             a.ldx = Hc.cin_pad; a.ldo = Hc.cout; a.ldr = Hc.cout; a.act = ADAF_ACT_SWISH;
             a.zeros = net->h->zeros; a.vec_epi = 1; a.in16 = 1;
-            if (adaf_launch_conv_pool16(a, hw * hw, featvec + (size_t)f0 * ldvec, ldvec, st)) continue;
+            if (adaf_launch_conv_pool16(a, hw * hw, featvec + (size_t)f0 * ldvec, ldvec, st)) return ADAF_OK;
         }
         if ((rc = run_dense(net, net->convs[net->head], cur, f16, nc, hw, hw, hw, hw, 0, ADAF_ACT_SWISH, fm, false, st)))
             return efail(h, rc, "effnet: head launch");
@@ -2346,6 +2360,38 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
             else hipLaunchKernelGGL((avgpool_any_kernel<float>), dim3((unsigned)(((size_t)nc * net->feat + 255) / 256)), dim3(256), 0, st, fm, nc,
                                     hw * hw, net->feat, featvec + (size_t)f0 * ldvec, ldvec);
         }
+        return ADAF_OK;
+    };
+    const bool pair = (adaf_options().effnet_plan & ADAF_EF_PLAN_PAIR_CHUNKS) != 0 && n > chunk;
+    adaf_effnet::Aux* ax = nullptr;
+    if (pair) {
+        ax = &net->aux[st];
+        if (!ax->stream) {
+            if (net->aux.size() > 16) return efail(h, ADAF_E_NOMEM, "effnet: more than 16 caller streams");
+            if (hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ax->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ax->ev_join, hipEventDisableTiming) != hipSuccess)
+                return efail(h, ADAF_E_NOMEM, "effnet: could not create the second-chunk stream");
+        }
+    }
+    char* base0 = static_cast<char*>(ws);
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int nc = (n - f0) < chunk ? (n - f0) : chunk;
+        int rc;
+        if (pair && f0 + chunk < n) {
+            const int f1 = f0 + chunk;
+            const int nc1 = (n - f1) < chunk ? (n - f1) : chunk;
+            (void)hipEventRecord(ax->ev_fork, st);
+            (void)hipStreamWaitEvent(ax->stream, ax->ev_fork, 0);
+            rc = run_chunk(f0, nc, base0, st);
+            if (!rc) rc = run_chunk(f1, nc1, base0 + per_chunk, ax->stream);
+            // ALWAYS join, also when a launch failed after the fork: whatever the helper stream still has queued writes the caller's
+            // workspace / outputs, and the caller may reuse them as soon as this call returns
+            (void)hipEventRecord(ax->ev_join, ax->stream);
+            (void)hipStreamWaitEvent(st, ax->ev_join, 0);
+            if (rc) return rc;
+            f0 = f1;
+        } else if ((rc = run_chunk(f0, nc, base0, st))) return rc;
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADAF_OK : efail(h, ADAF_E_LAUNCH, "effnet forward: %s", hipGetErrorString(e));

@@ -87,7 +87,8 @@ enum {
     ADAF_EF_PLAN_OWN_STEM = 16,      /* EfficientNet's own 3x3 / stride-2 stem kernel instead of the generic engine */
     ADAF_EF_PLAN_FUSED_EXPAND = 32,  /* fp16 storage: the expand conv computed inside the depthwise launch (no expanded map in HBM) */
     ADAF_EF_PLAN_PACKED_STEM = 64,   /* stems of up to 48 channels: k packed to 28 (no zero channel), columns 32-47 on a 16-column MFMA tile */
-    ADAF_EF_PLAN_HEAD_POOL = 128     /* fp16 storage, pooled features only: the global average pool in the head conv's epilogue (no fp32 map) */
+    ADAF_EF_PLAN_HEAD_POOL = 128,    /* fp16 storage, pooled features only: the global average pool in the head conv's epilogue (no fp32 map) */
+    ADAF_EF_PLAN_PAIR_CHUNKS = 256   /* two chunks of patches side by side on two streams (a batch of >= 512 patches that fits one chunk: two halves) */
 };
 int adaf_set_option(adaf_handle* h, const char* key, double value);
 double adaf_get_option(const char* key);

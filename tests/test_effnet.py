@@ -557,3 +557,28 @@ def test_head_conv_with_pool_in_its_epilogue_bit_identical(dev, name, size, n):
     pooled = fmap.mean(dim=(2, 3))
     assert (pooled - new).abs().max().item() < 1e-5 * max(1.0, float(pooled.abs().max()))
     assert (new[0] - new[1]).abs().max().item() > 1e-3            # the images really differ
+
+
+@pytest.mark.parametrize("dtype,size,n", [("f16", 75, 513), ("f16", 96, 520), ("f32", 75, 513)])
+def test_half_chunk_pairs_bit_identical_to_one_chunk(dev, dtype, size, n):
+    """A batch of >= 512 patches that fits one chunk travels as a PAIR of half chunks on two streams (option bit ADAF_EF_PLAN_PAIR_CHUNKS;
+    the second half on a library-owned stream forked from / joined to the caller's by events, with its own half of the workspace): block
+    outputs, the map and the pooled features equal the single pass bit for bit -- a patch's arithmetic does not depend on the chunk it
+    travels in -- on odd halves (257 + 256: a ragged image pair / group at the seam), several times over, in both storage modes."""
+    from adafocus_amd import _lib as L
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, "efficientnet-b3", 200, dtype=dtype)
+    x4 = nchw_to_nhwc4(_smooth((n, 3, size, size), 1700 + size + n).to(dev))
+    plan = int(L.get_option("effnet_plan"))
+    assert plan & L.EF_PLAN_PAIR_CHUNKS
+    with torch.no_grad():
+        with L.option("effnet_plan", plan & ~L.EF_PLAN_PAIR_CHUNKS):
+            ref = [m.engine().forward_blocks(x4, k).float().clone() for k in (3, 9, 25)] + [m.features_nhwc4(x4).clone()]
+            ref_map = m.engine().forward(x4, m.image_size or 0, want_map=True, want_vec=True)
+            ref_map = [t.clone() for t in ref_map]
+        for _ in range(3):
+            got = [m.engine().forward_blocks(x4, k).float() for k in (3, 9, 25)] + [m.features_nhwc4(x4)]
+            for k, g, r in zip((3, 9, 25, "features"), got, ref):
+                assert torch.isfinite(g).all() and torch.equal(g, r), (dtype, size, n, k)
+            fm, fv = m.engine().forward(x4, m.image_size or 0, want_map=True, want_vec=True)
+            assert torch.equal(fm, ref_map[0]) and torch.equal(fv, ref_map[1])
