@@ -1,5 +1,7 @@
 """EfficientNet-B3 local CNN (BASELINE config 5) timing probe: N patches of P^2 through adaf_effnet in fp32 and fp16 storage.
-usage: python tools/effnet_probe.py [N=1024] [P=144] [iters=20] [dtypes=f32,f16]"""
+usage: python tools/effnet_probe.py [N=1024] [P=144] [iters=20] [dtypes=f32,f16] [effnet_plan]
+(effnet_plan: the library option of that name, e.g. 255 = everything but ADAF_EF_PLAN_PAIR_CHUNKS -- one chunk on one stream, so that a kernel
+trace shows every kernel alone on the device)"""
 import os
 import sys
 import time
@@ -14,6 +16,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 144
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dtypes = sys.argv[4].split(",") if len(sys.argv) > 4 else ["f32", "f16"]
+if len(sys.argv) > 5:
+    from adafocus_amd import _lib  # noqa: E402
+    _lib.set_option("effnet_plan", int(sys.argv[5]))
 dev = torch.device("cuda:0")
 x4 = torch.randn((n, p, p, 4), device=dev)
 x4[..., 3] = 0

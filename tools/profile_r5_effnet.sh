@@ -9,7 +9,9 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { local name=$1; shift; rocprofv3 "$@" > $OUT/r5_$name.log 2>&1; }
-EFF16="python $R/tools/effnet_probe.py 1024 144 5 f16"
+# (effnet_plan 255 = without ADAF_EF_PLAN_PAIR_CHUNKS: one chunk on one stream, every kernel alone on the device -- the plan the committed r5_effnet_* summaries
+#  were collected under, before the pairing existed; the default forward runs the same kernels as two half chunks side by side)
+EFF16="python $R/tools/effnet_probe.py 1024 144 5 f16 255"
 run effnet_f16_trace --kernel-trace --stats --output-format csv -d $OUT/prof_r5_effnet_f16_trace -- $EFF16
 run effnet_f16_sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/prof_r5_effnet_f16_sq -- $EFF16
 run effnet_f16_icache --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES --output-format csv -d $OUT/prof_r5_effnet_f16_icache -- $EFF16
