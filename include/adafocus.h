@@ -415,6 +415,10 @@ int adaf_effnet_whole_blocks(const adaf_effnet* net, int size, int pad_size);
  * expanded map of those blocks never exists in HBM.  Same arithmetic per stored value as the two launches (the two MFMA shapes
  * give the same bits); the tile plan, and with it the order of the squeeze partial sums, is its own. */
 int adaf_effnet_fused_expand_blocks(const adaf_effnet* net, int size, int pad_size);
+/* ADAF_EF_PLAN_PAIR_CHUNKS: adaf_effnet_forward sends two chunks of patches through the network side by side -- a batch of >= 512 patches that
+ * fits one chunk ("effnet_chunk") is cut into two halves -- the second on a stream the library owns (one per caller stream, forked from and
+ * joined to it by events inside the call: the call stays asynchronous and stream-ordered for the caller; adaf_effnet_workspace_bytes covers
+ * both chunks).  A patch's results do not depend on the chunk it travels in. */
 /* ADAF_EF_PLAN_HEAD_POOL (fp16 storage, `features` requested without `featmap`, head maps that fill a 128-row tile to >= 90 %: 3 x 3, 4 x 4,
  * 5 x 5): the head conv 1x1 + BN + swish does not write its fp32 map -- the global average pool runs in the conv launch's epilogue
  * (csrc/conv_gemm.hip adaf_launch_conv_pool16), adding a map's pixels in pixel order and dividing, as the pool launch does: the same bits. */
