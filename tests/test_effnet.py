@@ -582,3 +582,30 @@ def test_half_chunk_pairs_bit_identical_to_one_chunk(dev, dtype, size, n):
                 assert torch.isfinite(g).all() and torch.equal(g, r), (dtype, size, n, k)
             fm, fv = m.engine().forward(x4, m.image_size or 0, want_map=True, want_vec=True)
             assert torch.equal(fm, ref_map[0]) and torch.equal(fv, ref_map[1])
+
+
+def test_chunk_pairs_inside_a_captured_hot_path(dev):
+    """The paired half chunks fork to a library-owned stream and join back inside adaf_effnet_forward: captured into a HIP graph
+    (GFV.capture_hot_path: the fork / join events become graph dependencies) the step replays bit-identically to the eager launch,
+    on new inputs, several times -- B = 32, T = 16: 512 patches, the smallest batch that pairs."""
+    from adafocus_amd import _lib as L
+    from adafocus_amd.gfv_net import GFV
+    assert int(L.get_option("effnet_plan")) & L.EF_PLAN_PAIR_CHUNKS
+    b, t = 32, 16
+    m = GFV(_act_args(local_arch="efficientnet-b3", local_dtype="f16", patch_size=96, batch_size=b)).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 1007).items()}, strict=True)
+    m = m.to(dev)
+    g = m.capture_hot_path(b, t)
+    for seed in (71, 72, 73):
+        fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=seed)).to(dev).view(b * t, 3, 224, 224)
+        _, act = synth.synth_actions(b * t, 7, seed=seed + 10)
+        act = torch.from_numpy(act).to(dev)
+        gv = rnd((b, t, 1280), seed + 20, 0.5).to(dev)
+        with torch.no_grad():
+            lg, last, _ = m.hot_path(fr, gv, act, b, t)
+            lg, last = lg.clone(), last.clone()
+            for _ in range(2):
+                glg, glast = g(fr, gv, act)
+                torch.cuda.synchronize()
+                assert torch.isfinite(glg).all() and torch.equal(glg, lg) and torch.equal(glast, last), seed
