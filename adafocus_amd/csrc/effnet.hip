@@ -2362,12 +2362,12 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
         }
         return ADAF_OK;
     };
-    const bool pair = (adaf_options().effnet_plan & ADAF_EF_PLAN_PAIR_CHUNKS) != 0 && n > chunk;
+    // (a 17th caller stream gets no helper: its chunks simply follow one another on its own stream -- same results)
+    const bool pair = (adaf_options().effnet_plan & ADAF_EF_PLAN_PAIR_CHUNKS) != 0 && n > chunk && (net->aux.count(st) || net->aux.size() < 16);
     adaf_effnet::Aux* ax = nullptr;
     if (pair) {
         ax = &net->aux[st];
         if (!ax->stream) {
-            if (net->aux.size() > 16) return efail(h, ADAF_E_NOMEM, "effnet: more than 16 caller streams");
             if (hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ax->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ax->ev_join, hipEventDisableTiming) != hipSuccess)

@@ -609,3 +609,20 @@ def test_chunk_pairs_inside_a_captured_hot_path(dev):
                 glg, glast = g(fr, gv, act)
                 torch.cuda.synchronize()
                 assert torch.isfinite(glg).all() and torch.equal(glg, lg) and torch.equal(glast, last), seed
+
+
+def test_chunk_pairs_from_more_caller_streams_than_helpers(dev):
+    """The library keeps one helper stream per caller stream, 16 at most; a 17th caller stream gets none and its two half chunks follow
+    one another on its own stream: 20 caller streams, the same features bit for bit from every one of them."""
+    from adafocus_amd.utils import nchw_to_nhwc4
+    m, _ = _net(dev, "efficientnet-b3", 200, dtype="f16")
+    x4 = nchw_to_nhwc4(_smooth((512, 3, 75, 75), 1900).to(dev))
+    with torch.no_grad():
+        ref = m.features_nhwc4(x4).clone()
+        torch.cuda.synchronize()
+        for i in range(20):
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                got = m.features_nhwc4(x4)
+            s.synchronize()
+            assert torch.equal(got, ref), i
