@@ -408,12 +408,12 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
         return ADAF_OK;
     };
     const size_t per_chunk = (size_t)chunk * (2 * io + ex + dws);
-    const bool pair = net->pair && n > chunk;
+    // (a 17th caller stream gets no helper: its chunks follow one another on its own stream -- same results)
+    const bool pair = net->pair && n > chunk && (net->aux.count(st) || net->aux.size() < 16);
     adaf_mobilenetv2::Aux* ax = nullptr;
     if (pair) {
         ax = &net->aux[st];
         if (!ax->stream) {
-            if (net->aux.size() > 16) return mfail(h, ADAF_E_NOMEM, "mobilenetv2: more than 16 caller streams");
             if (hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ax->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ax->ev_join, hipEventDisableTiming) != hipSuccess)

@@ -412,3 +412,25 @@ def test_glancer_half_chunk_pairs_equal_small_chunks(dev, n, tsm):
             assert len(got) == len(ref) == 2
             for g, r in zip(got, ref):
                 assert torch.isfinite(g).all() and float(g.abs().max()) > 1e-3 and torch.equal(g, r)
+
+
+def test_glancer_from_more_caller_streams_than_helpers(dev):
+    """adaf_mobilenetv2 keeps one second-chunk helper stream per caller stream, 16 at most; a 17th caller stream gets none (its chunks
+    follow one another on its own stream) instead of an error: 20 caller streams, the same map and vector from every one of them."""
+    from adafocus_amd.mobilenet import mobilenet_v2
+    from adafocus_amd.utils import nchw_to_nhwc4
+    from tests.helpers import rnd
+    net = mobilenet_v2().eval()
+    sd = {k: v for k, v in synth_sd("ACT", 505, "glancer.net.", keep_prefix=False).items() if not k.startswith("classifier")}
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev)
+    x4 = nchw_to_nhwc4(rnd((512, 3, 64, 64), 5400).to(dev))
+    with torch.no_grad():
+        ref = [t.clone() for t in net._engine.features(x4)]
+        torch.cuda.synchronize()
+        for i in range(20):
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                got = net._engine.features(x4)
+            s.synchronize()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
