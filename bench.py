@@ -93,6 +93,21 @@ def config5_row(dev, b, streams, frames, steps=30):
                 e1.record()
                 torch.cuda.synchronize()
                 cnn_ms = min(cnn_ms, e0.elapsed_time(e1) / 5)
+            # the same forward as ONE chunk on one stream (the default cuts a batch of >= 512 patches into two half chunks that travel side by
+            # side on two streams, ADAF_EF_PLAN_PAIR_CHUNKS; bit-identical): what the pairing buys, measured in this run
+            from adafocus_amd import _lib as _L
+            one_ms = float("inf")
+            with _L.option("effnet_plan", int(_L.get_option("effnet_plan")) & ~_L.EF_PLAN_PAIR_CHUNKS):
+                for _ in range(2):
+                    net.features_nhwc4(x4)
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        net.features_nhwc4(x4)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    one_ms = min(one_ms, e0.elapsed_time(e1) / 5)
         elem = 2 if dtype == "f16" else 4
         by = float(workload.effnet_block_bytes_per_frame("efficientnet-b3", p, elem)) * b * t      # block-level algorithmic bytes
         plan = float(workload.effnet_bytes_per_frame("efficientnet-b3", p, elem)) * b * t            # in + out of every launch that runs
@@ -103,6 +118,7 @@ def config5_row(dev, b, streams, frames, steps=30):
                           "plan_bytes_per_patch": int(plan / (b * t)), "plan_gbs": round(plan / cnn_ms / 1e6, 1),
                           "plan_frac": round(plan / cnn_ms / 1e6 / HBM_PEAK_GBS, 4),
                           "traffic_bytes_per_patch": load_effnet_traffic(dtype, b * t, p),
+                          "ms_one_chunk": round(one_ms, 3), "chunk_pairs": bool(int(_L.get_option("effnet_plan")) & _L.EF_PLAN_PAIR_CHUNKS),
                           "whole_block_launches": int(net.engine().whole_blocks(p)),
                           "fused_expand_launches": int(net.engine().fused_expand_blocks(p)),
                           "tflops": round(2.0 * workload.effnet_macs_per_frame("efficientnet-b3", p) * b * t / cnn_ms / 1e9, 1)}}
