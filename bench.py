@@ -439,6 +439,68 @@ def cpu_baseline(t, p, threads):
     raise RuntimeError("cpu baseline leg failed: %s" % out.stderr[-400:])
 
 
+def bench_summary(res):
+    """The numbers a reader of the LAST 2 KB of the line needs (the driver keeps only the tail of stdout): every figure below is a copy of an
+    entry further up the same line, never a new measurement.  Must stay <= 1.5 KB; tests/test_bench_launch.py parses it back from the tail."""
+    def g(*path, default=None):
+        o = res
+        for k in path:
+            if not isinstance(o, dict) or k not in o:
+                return default
+            o = o[k]
+        return o
+
+    def row(*path):
+        r = g(*path)
+        if not isinstance(r, dict):
+            return None
+        if "error" in r:
+            return {"error": str(r["error"])[:60]}
+        out = {"clips_per_s": r.get("clips_per_s", r.get("value"))}
+        if "frac_of_f32_mfma_peak" in r:
+            out["frac"] = r["frac_of_f32_mfma_peak"]
+        return out
+
+    also = "also"
+    s = {
+        "value": res.get("value"), "ms_per_step": res.get("ms_per_step"),
+        "serial_value": g("serial_value", "value"), "sustained": g("sustained", "value"),
+        "roofline_frac": g("roofline", "frac"), "back_to_back_frac": g("roofline", "back_to_back", "frac"),
+        "trunk_ms": g("roofline", "back_to_back", "trunk_ms"), "traffic_over_algorithmic": None,
+        "split_bf16": None,
+        "config2": row(also, "config2_T8_P96_act"), "config3": row(also, "config3_T16_P128_act"), "config4": row(also, "config4_T8_P128_sth_tsm"),
+        "config5_f16": None,
+        "sth_shipped": {"hot_path": g(also, "sth_shipped_T8_12_P144", "hot_path", "clips_per_s"),
+                        "full_forward": g(also, "sth_shipped_T8_12_P144", "full_forward_from_uint8", "value")},
+        "glancer": {"ms": g("next_rows", "f2_glancer_mobilenetv2", "ms"), "frac_hbm": g("next_rows", "f2_glancer_mobilenetv2", "frac"),
+                    "frac_f32_mfma": g("next_rows", "f2_glancer_mobilenetv2", "frac_of_f32_mfma_peak"),
+                    "traffic_over_block_bytes": g("next_rows", "f2_glancer_mobilenetv2", "traffic_over_block_bytes")},
+        "policy_ms": g("next_rows", "f2_policy", "ms"), "ingest_frac_hbm": g("next_rows", "f1_ingest_u8", "frac"),
+        "full_forward": g("next_rows", "full_forward_from_uint8", "value"),
+        "full_forward_pipelined": g("next_rows", "full_forward_from_uint8_pipelined", "value"),
+        "evaluate_loop": g("next_rows", "evaluate_loop", "value"),
+        "latency_B1_T8_P96_ms": g(also, "latency_small_batch", "B1_T8_P96", "eager_ms"),
+        "gather_frac_hbm": g("gather", "frac"),
+        "cpu_baseline": g("cpu_baseline", "value"), "gpu_over_cpu": None,
+    }
+    tr, ab = g("roofline", "traffic"), g("roofline", "algorithmic_bytes_per_launch")
+    if tr and ab:
+        s["traffic_over_algorithmic"] = round(tr / ab, 2)
+    sp = g(also, "split_bf16")
+    if isinstance(sp, dict):
+        s["split_bf16"] = {"error": str(sp["error"])[:60]} if "error" in sp else {
+            "clips_per_s": sp.get("clips_per_s"), "serial": g(also, "split_bf16", "serial", "clips_per_s"),
+            "frac_bf16_pipe": g(also, "split_bf16", "roofline", "frac"), "max_abs_logit_diff": sp.get("max_abs_logit_diff_vs_f32")}
+    c5 = g(also, "config5_T16_P144_efficientnet_b3", "f16_storage")
+    if isinstance(c5, dict):
+        s["config5_f16"] = {"clips_per_s": c5.get("clips_per_s"), "local_cnn_ms": g(also, "config5_T16_P144_efficientnet_b3", "f16_storage", "local_cnn", "ms"),
+                            "frac_hbm": g(also, "config5_T16_P144_efficientnet_b3", "f16_storage", "local_cnn", "frac"),
+                            "frac_structural": g(also, "config5_T16_P144_efficientnet_b3", "f16_storage", "local_cnn", "structural_frac")}
+    if s["cpu_baseline"] and res.get("value"):
+        s["gpu_over_cpu"] = round(res["value"] / s["cpu_baseline"], 1)
+    return s
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -880,6 +942,8 @@ def main():
         if world == 1 and a.cpu_baseline and not a.skip_extras:
             res["cpu_baseline"] = cpu_baseline(t, p, a.cpu_threads)
     if rank == 0:
+        res.pop("summary", None)
+        res["summary"] = bench_summary(res)      # LAST key: the driver keeps the tail of the line
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

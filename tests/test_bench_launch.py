@@ -50,6 +50,45 @@ def test_bench_eight_ranks_dry_run():
     assert abs(r["value"] - 32 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 0.01
 
 
+
+def test_bench_summary_is_the_tail_of_the_line():
+    """The driver keeps only the last few KB of bench.py's stdout: the compact `summary` object must be the LAST key of the line and parse
+    back from its last 2 KB on its own -- from a dry run, and from a full line of the previous round (every row filled)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1", "--sustained-steps", "4",
+                          "--batch", "4", "--frames", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+
+    def summary_from_tail(text):
+        tail = text.rstrip()[-2048:]
+        i = tail.rfind('"summary": ')
+        assert i >= 0, tail[-400:]
+        body = tail[i + len('"summary": '):]
+        assert body.endswith("}}")
+        return json.loads(body[:-1])       # (the line's own closing brace follows the object)
+
+    s = summary_from_tail(out.stdout)
+    assert s["value"] > 0 and s["sustained"] > 0 and "glancer" in s and "split_bf16" in s
+    assert list(json.loads(out.stdout.strip().splitlines()[-1]).keys())[-1] == "summary"
+
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r5_bench_lines", "bench_s2u.json")).read().strip().splitlines()[-1])
+    full.pop("summary", None)
+    full["summary"] = bench.bench_summary(full)
+    text = json.dumps(full)
+    assert len(json.dumps(full["summary"])) <= 1536
+    s = summary_from_tail(text)
+    assert s["serial_value"] == full["serial_value"]["value"] and s["back_to_back_frac"] == full["roofline"]["back_to_back"]["frac"]
+    assert s["split_bf16"]["clips_per_s"] == full["also"]["split_bf16"]["clips_per_s"]
+    assert s["glancer"]["ms"] == full["next_rows"]["f2_glancer_mobilenetv2"]["ms"]
+    assert s["full_forward"] == full["next_rows"]["full_forward_from_uint8"]["value"]
+    assert s["evaluate_loop"] == full["next_rows"]["evaluate_loop"]["value"]
+    assert s["sth_shipped"]["full_forward"] == full["also"]["sth_shipped_T8_12_P144"]["full_forward_from_uint8"]["value"]
+    assert s["config3"]["clips_per_s"] == full["also"]["config3_T16_P128_act"]["clips_per_s"]
+
+
 def test_bench_distributed_init_failure_leaves_one_diagnosable_line():
     """A failure inside the distributed-init guard (rendezvous or the first collective -- where an RCCL problem shows up on the first
     unattended 8-GPU run) must produce ONE JSON line on stdout with `error`, `rccl_ranks: 0`, the exception text and the HSA_* / NCCL_* /
