@@ -35,6 +35,7 @@ struct AdafOptions {
     int conv_pool = 1;            // "conv_pool": global average pool in the last conv3's epilogue
     int resize_lds_kb = 20;       // "resize_lds_kb": staged rows per block of the resampling gather
     int mb_wave = 1;              // "mb_wave": wave-private MBConv kernels of the MobileNetV2 glancer
+    int mb_strip = 1;             // "mb_strip": strip-walking forms of the glancer's front kernels (mbstrip.hip, round 6); 0 = the wave-private tiles
     int dw3_variant = 4;          // "dw3_variant": thread tile of the stand-alone depthwise 3x3 (0: 4x2, 1: 2x2, 2: 4x1, 3: 7x2, 4: 4x4)
     int mbv2_chunk = 512;         // "mbv2_chunk": frames per chunk of the MobileNetV2 forward
     int latency_rows = 1536;      // "latency_rows": GEMM rows up to which a new trunk sends convs to the small-batch form
@@ -134,6 +135,8 @@ struct MbStemArgs {       // fused stem -> block 1 (t = 1: depthwise + project) 
     const float* zeros;
 };
 void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s);
+bool adaf_mb_stem_b1_strip_ok(int S, int H1);                      // mbstrip.hip
+void adaf_launch_mb_stem_b1_strip(MbStemArgs a, hipStream_t s);
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
 bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw);

@@ -80,7 +80,7 @@ struct OptKey { const char* name; int kind; double lo, hi; };      // kind: inde
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
                            {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 511}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
-                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}, {"gru_barrier", 15, 0, 1}};
+                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}, {"gru_barrier", 15, 0, 1}, {"mb_strip", 16, 0, 1}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
     for (const OptKey& k : kOptKeys)
@@ -166,6 +166,7 @@ int adaf_set_option(adaf_handle* h, const char* key, double value) {
         case 13: o.stem_rows = (int)value; break;
         case 14: o.split_stage1_f32 = (int)value; break;
         case 15: o.gru_barrier = (int)value; break;
+        case 16: o.mb_strip = (int)value; break;
         default: o.effnet_chunk = (int)value; break;
     }
     return ADAF_OK;
@@ -191,6 +192,7 @@ double adaf_get_option(const char* key) {
         case 13: return o.stem_rows;
         case 14: return o.split_stage1_f32;
         case 15: return o.gru_barrier;
+        case 16: return o.mb_strip;
         default: return o.effnet_chunk;
     }
 }

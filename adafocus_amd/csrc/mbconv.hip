@@ -901,6 +901,7 @@ void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s) {
 }
 
 void adaf_launch_mb_stem_b1(MbStemArgs a, int cus, hipStream_t s) {
+    if (mb_wave_enabled() && adaf_mb_stem_b1_strip_ok(a.S, a.H1)) return adaf_launch_mb_stem_b1_strip(a, s);
     if (mb_wave_enabled()) {
         a.tiles_x = (a.H1 + 7) / 8;
         a.tiles_y = (a.H1 + 3) / 4;
