@@ -891,6 +891,7 @@ bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw) {
 }
 
 void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s) {
+    if (adaf_mb_block_strip_ok(a.cin, a.hid, a.cout, 1, a.H, a.W)) return adaf_launch_mb_block_strip(a, s);
     a.tiles_x = (a.OW + 7) / 8;
     a.tiles_y = (a.OH + 3) / 4;
     const long long tiles = (long long)a.n * a.tiles_x * a.tiles_y;

@@ -42,6 +42,11 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
+// acc += a * b on two packed fp32 lanes.  As inline asm because clang 22 UNPACKS a v_pk_fma_f32 that follows an MFMA into two v_fma_f32 ("to
+// co-issue with the MFMA"): on gfx950 nothing co-issues (tools/exp/mfma_valu_overlap.hip: MFMA + VALU time is additive, also inside one wave), so
+// the pair costs 9.6 instead of 6.6 cycles -- a third of the tap FMAs of these kernels were unpacked.  Same arithmetic, one rounding per lane.
+__device__ __forceinline__ void pkfma(f32x2& acc, f32x2 a, f32x2 b) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+
 constexpr int SW_OW = 14;                    // output columns of a strip
 constexpr int SW_EP = 36;                    // floats per pixel of the ring (32 channels + 4: conflict-free 16-byte reads)
 constexpr int SW_ROWF = 18 * SW_EP;          // 16 columns + 2 the idle lanes n = 14, 15 read past
@@ -119,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
     auto step = [&](auto PAR, int s) {
         constexpr int par = decltype(PAR)::value;
         constexpr int SL0 = par ? 1 : 3, SL1 = par ? 2 : 0;
-        if (left) {
+        if (left) {       // (wave-uniform: the empty asm keeps it a branch -- if-converted it is 12 selects in every step of every strip)
+            asm volatile("");
             af[0] = zl0 ? zero4 : af[0];
             af[1] = zl1 ? zero4 : af[1];
             af[3] = zl0 ? zero4 : af[3];
@@ -131,7 +137,6 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
         for (int kk = 0; kk < 5; ++kk)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bs[kk][s4], acc, 0, 0, 0);
-        if (s + 1 < nsteps) fetch();
         // BN + ReLU6; stem outputs outside the map are the depthwise conv's zero padding
         {
             const f32x2 sc2 = {ssc, ssc}, bi2 = {sbi, sbi};
@@ -142,16 +147,24 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
                 acc[r + 1] = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
             }
         }
+        // The next step's pixels are requested only HERE: a returning load is not interlocked against an MFMA that still has to read the
+        // register it lands in (DESIGN / LABNOTES "a load may not land in an MFMA's registers", round 5) -- the VALU reads of the chain's
+        // result above are, so past this point every MFMA that reads af[] has retired.
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps) fetch();
+        __builtin_amdgcn_sched_barrier(0);
         if (s == 0) {
+            asm volatile("");
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = 0.f;           // E row -1
         }
         if (s == nsteps - 1) {
+            asm volatile("");
 #pragma unroll
             for (int r = 8; r < 16; ++r) acc[r] = 0.f;          // E row H1
         }
-        if (left && half == 0) { acc[0] = 0.f; acc[8] = 0.f; }     // E column -1   (ec = 0: rows r = 0, 8 of half 0)
-        if (right && half == 1) { acc[7] = 0.f; acc[15] = 0.f; }   // E column H1   (ec = 15: rows r = 7, 15 of half 1)
+        if (left) { asm volatile(""); if (half == 0) { acc[0] = 0.f; acc[8] = 0.f; } }     // E column -1   (ec = 0: rows r = 0, 8 of half 0)
+        if (right) { asm volatile(""); if (half == 1) { acc[7] = 0.f; acc[15] = 0.f; } }   // E column H1   (ec = 15: rows r = 7, 15 of half 1)
         __builtin_amdgcn_wave_barrier();        // the previous step's tap reads are issued (same-wave LDS traffic runs in order)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ewr[(r < 8 ? SL0 : SL1) * SW_ROWF + ((r & 3) + 8 * ((r >> 2) & 1)) * SW_EP] = acc[r];
@@ -172,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
                     const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
                     if (e < 3) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) s0[i] = __builtin_elementwise_fma(v[i], tap[e * 3 + kx][i], s0[i]);
+                        for (int i = 0; i < 4; ++i) pkfma(s0[i], v[i], tap[e * 3 + kx][i]);
                     }
                     if (e > 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) s1[i] = __builtin_elementwise_fma(v[i], tap[(e - 1) * 3 + kx][i], s1[i]);
+                        for (int i = 0; i < 4; ++i) pkfma(s1[i], v[i], tap[(e - 1) * 3 + kx][i]);
                     }
                 }
             float d0[8], d1[8];
@@ -209,6 +222,246 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A whole stride-1 inverted-residual block (expand 1x1 -> BN/ReLU6 -> depthwise 3x3 -> BN/ReLU6 -> project 1x1 -> BN [+ identity]) as
+// strip segments: a wave owns 14 output columns x SEG output rows of a frame.  The hidden channels are walked in chunks of 32 in the
+// OUTER loop -- a chunk's filter rows, taps and affines are fetched once per segment -- and the segment's rows in steps of two
+// expanded rows in the inner loop (SEG / 2 + 1 steps: one row of vertical halo above and below the segment is recomputed, 10 / 8),
+// exactly as the stem kernel above walks a frame: expanded rows into the four-row ring, the taps of the two output rows they complete
+// straight into the B operand of the project conv's 16x16x4 chain.  The project accumulators of all SEG rows stay in registers across
+// the chunks (SEG / 2 row pairs x 2 rows x two 16-channel blocks), so the project conv sums its k slices in the conv engine's order
+// (slices of 32, a partial last slice zero-filled): bit-identical to mb_block_w_kernel and to the three separate launches.
+// The depthwise taps and affines of every chunk sit in LDS in the order the lanes consume them ([chunk][k group][tap][8]): a lane's
+// 8 channels x 9 taps would be 72 registers next to 64 of accumulators.  The input needs no padding select at all: expanded pixels
+// outside the map are forced to zero (the depthwise conv pads the EXPANDED map), rows outside the frame load as zeros anyway.
+constexpr int SW_SEG = 8;                    // output rows of a segment
+constexpr int SW_TAPF = 11 * 8;              // floats per (chunk, k group): 9 taps | depthwise scale | depthwise bias, 8 channels each
+constexpr int SW_MAXCH = 6;                  // chunks (hid <= 192)
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) {
+    constexpr int KK = CIN / 8, NST = SW_SEG / 2 + 1;
+    __shared__ __attribute__((aligned(16))) float Eall[4][SW_RING];
+    __shared__ __attribute__((aligned(16))) float Tall[SW_MAXCH * 4 * SW_TAPF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hid = a.hid, nchunks = (hid + 31) >> 5;
+    for (int idx = tid; idx < nchunks * 4 * SW_TAPF; idx += 256) {
+        const int q = idx & 7, t = (idx >> 3) % 11, cg = idx / SW_TAPF;
+        const int ch = 32 * (cg >> 2) + kq(cg & 3, q);
+        float v = 0.f;
+        if (ch < hid) v = t < 9 ? a.wd[(size_t)t * hid + ch] : t == 9 ? a.sd[ch] : a.bd[ch];
+        Tall[idx] = v;
+    }
+    float* Ew = Eall[wave];
+    for (int i = lane; i < SW_RING; i += 64) Ew[i] = 0.f;
+    __syncthreads();
+    const int nstrips = a.tiles_x, nsegs = a.tiles_y;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.n * nstrips * nsegs) return;
+    const int img = item / (nstrips * nsegs), rem = item - img * (nstrips * nsegs);
+    const int seg = rem / nstrips, sx = rem - seg * nstrips;        // (the strips of a row segment are neighbours: they share input lines)
+    const int ox0 = sx * SW_OW, y0 = seg * SW_SEG;
+    const int H = a.H, W = a.W;
+    const int rows = H - y0 < SW_SEG ? H - y0 : SW_SEG;             // output rows of this segment (even)
+    const int nsteps = rows / 2 + 1;
+    const bool left = sx == 0, right = sx == nstrips - 1, top = seg == 0, bottom = y0 + rows == H;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- expand GEMM roles: A row p = lane & 31 = (er = p >> 4, ec = p & 15) is input pixel (y0 - 1 + 2 s + er, ox0 - 1 + ec), k = 8 kk + 4 half ..
+    const int half = lane >> 5, nl = lane & 31;
+    const int er = nl >> 4, ec = nl & 15;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)img * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+    const int voff0 = (((y0 - 1 + er) * W + ox0 - 1 + ec) * CIN + 4 * half) * 4;
+    const int rstep = 2 * W * CIN * 4;
+    float* ewr = Ew + (4 * half) * SW_EP + pos_of(nl);
+
+    // ---- depthwise / project roles: (output column n, k group g)
+    const int n = lane & 15, g = lane >> 4;
+    const float* erd = Ew + n * SW_EP + 8 * g;
+    const float* tw = Tall + g * SW_TAPF;
+
+    f32x4 P[SW_SEG / 2][2][2];          // [row pair][row][16-channel block]
+#pragma unroll
+    for (int i = 0; i < SW_SEG / 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { P[i][j][0] = zero4; P[i][j][1] = zero4; }
+
+    // Chunk operands.  bf / af are read by the expand chain, wp by the project chains: a global load may only target them once a VALU
+    // instruction has read the result of an MFMA issued after their last reader (see the stem kernel) -- so the next chunk's bf and its
+    // first pixels are requested in the chunk's LAST step behind the epilogue, and wp of a chunk in its step 0 behind the epilogue (by
+    // then the previous chunk's project chains have retired; step 0 has no project products of its own).
+    f32x4 bf[KK], af[KK];
+    float esc, ebi, wp[2][8];
+    auto load_bf = [&](int c) {
+        const int nch = 32 * c + nl;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            bf[kk] = nch < hid ? *reinterpret_cast<const f32x4*>(a.we + (size_t)nch * CIN + 8 * kk + 4 * half) : zero4;
+    };
+    auto load_bn = [&](int c) {
+        const int nch = 32 * c + nl;
+        esc = nch < hid ? a.se[nch] : 0.f;
+        ebi = nch < hid ? a.be[nch] : 0.f;
+    };
+    auto load_wp = [&](int c) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = 32 * c + kq(g, q);
+                wp[m][q] = (16 * m + n < a.cout && k < hid) ? a.wp[(size_t)(16 * m + n) * hid + k] : 0.f;
+            }
+    };
+    auto fetch = [&](int s) {
+        const int vo = voff0 + s * rstep;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) af[kk] = bload(rsrc, vo + 32 * kk);
+    };
+    load_bf(0);
+    load_bn(0);
+    fetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const float* tc = tw + c * 4 * SW_TAPF;
+        auto step = [&](auto SC) {
+            constexpr int s = decltype(SC)::value;
+            constexpr int par = s & 1;
+            constexpr int SL0 = par ? 1 : 3, SL1 = par ? 2 : 0;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
+            {
+                const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, sc2, bi2);
+                    acc[r] = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f);
+                    acc[r + 1] = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (the chain has retired: see above)
+            if (s == 0) load_wp(c);
+            if (s + 1 < NST && s + 1 < nsteps) fetch(s + 1);
+            else if (c + 1 < nchunks) {
+                load_bf(c + 1);
+                load_bn(c + 1);
+                fetch(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) {
+                if (top) {
+                    asm volatile("");
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[r] = 0.f;       // expanded row -1
+                }
+            } else if (bottom && s == nsteps - 1) {
+                asm volatile("");
+#pragma unroll
+                for (int r = 8; r < 16; ++r) acc[r] = 0.f;          // expanded row H
+            }
+            if (left) { asm volatile(""); if (half == 0) { acc[0] = 0.f; acc[8] = 0.f; } }      // expanded column -1
+            if (right) { asm volatile(""); if (half == 1) { acc[7] = 0.f; acc[15] = 0.f; } }    // expanded column W
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ewr[(r < 8 ? SL0 : SL1) * SW_ROWF + ((r & 3) + 8 * ((r >> 2) & 1)) * SW_EP] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (s > 0) {
+                constexpr int slot[4] = {par ? 3 : 1, par ? 0 : 2, SL0, SL1};
+                f32x2 s0[4], s1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s0[i] = f32x2{0.f, 0.f}; s1[i] = f32x2{0.f, 0.f}; }
+                f32x2 tprev[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 tcur[3][4];
+                    if (e < 3) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const f32x4 ta = *reinterpret_cast<const f32x4*>(tc + (e * 3 + kx) * 8), tb = *reinterpret_cast<const f32x4*>(tc + (e * 3 + kx) * 8 + 4);
+                            tcur[kx][0] = f32x2{ta.x, ta.y}; tcur[kx][1] = f32x2{ta.z, ta.w}; tcur[kx][2] = f32x2{tb.x, tb.y}; tcur[kx][3] = f32x2{tb.z, tb.w};
+                        }
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* p = erd + slot[e] * SW_ROWF + kx * SW_EP;
+                        const f32x4 va = *reinterpret_cast<const f32x4*>(p), vb = *reinterpret_cast<const f32x4*>(p + 4);
+                        const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
+                        if (e < 3) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pkfma(s0[i], v[i], tcur[kx][i]);
+                        }
+                        if (e > 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pkfma(s1[i], v[i], tprev[kx][i]);
+                        }
+                    }
+                    if (e < 3) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) tprev[kx][i] = tcur[kx][i];
+                    }
+                }
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(tc + 72), sb = *reinterpret_cast<const f32x4*>(tc + 76);
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(tc + 80), bb = *reinterpret_cast<const f32x4*>(tc + 84);
+                const f32x2 dsc[4] = {{sa.x, sa.y}, {sa.z, sa.w}, {sb.x, sb.y}, {sb.z, sb.w}}, dbi[4] = {{ba.x, ba.y}, {ba.z, ba.w}, {bb.x, bb.y}, {bb.z, bb.w}};
+                float d0[8], d1[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 r0 = __builtin_elementwise_fma(s0[i], dsc[i], dbi[i]), r1 = __builtin_elementwise_fma(s1[i], dsc[i], dbi[i]);
+                    d0[2 * i] = __builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f); d0[2 * i + 1] = __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f);
+                    d1[2 * i] = __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f); d1[2 * i + 1] = __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        P[s - 1][0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[m][q], d0[q], P[s - 1][0][m], 0, 0, 0);
+                        P[s - 1][1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[m][q], d1[q], P[s - 1][1][m], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        if (nsteps > 2) step(std::integral_constant<int, 2>{});
+        if (nsteps > 3) step(std::integral_constant<int, 3>{});
+        if (nsteps > 4) step(std::integral_constant<int, 4>{});
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- project BN (+ identity), 16-byte stores: this lane holds output channels 16 m + 4 g .. + 3 of pixel (row, ox0 + n)
+    if (n < SW_OW) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int co = 16 * m + 4 * g;
+            if (co < a.cout) {
+                const f32x4 psc = *reinterpret_cast<const f32x4*>(a.sp + co), pbi = *reinterpret_cast<const f32x4*>(a.bp + co);
+#pragma unroll
+                for (int i = 0; i < SW_SEG / 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int y = y0 + 2 * i + j;
+                        if (2 * i + j < rows) {
+                            const size_t gi = (((size_t)img * H + y) * W + ox0 + n) * a.cout + co;
+                            f32x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaf(P[i][j][m][r], psc[r], pbi[r]);
+                            if (a.res) {
+                                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + gi);
+                                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                            }
+                            *reinterpret_cast<f32x4*>(a.out2 + gi) = v;
+                        }
+                    }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool adaf_mb_stem_b1_strip_ok(int S, int H1) { return adaf_options().mb_strip != 0 && S == 2 * H1 && H1 % SW_OW == 0 && H1 >= SW_OW; }
@@ -218,4 +471,19 @@ void adaf_launch_mb_stem_b1_strip(MbStemArgs a, hipStream_t s) {
     a.tiles_y = 1;
     a.total_tiles = a.n * a.tiles_x;
     hipLaunchKernelGGL(mb_stem_b1_s_kernel, dim3((unsigned)((a.total_tiles + 3) / 4)), dim3(256), 0, s, a);
+}
+
+// whole stride-1 blocks as strip segments (b3, b5, b6 of MobileNetV2 1.0 at 224^2): square maps whose side is a multiple of 14
+bool adaf_mb_block_strip_ok(int cin, int hid, int cout, int stride, int h, int w) {
+    return adaf_options().mb_strip != 0 && stride == 1 && (cin == 24 || cin == 32) && hid <= 32 * SW_MAXCH && hid % 4 == 0 && cout % 4 == 0 &&
+           cout <= 32 && h == w && w % SW_OW == 0 && h % 2 == 0;
+}
+
+void adaf_launch_mb_block_strip(MbFuseArgs a, hipStream_t s) {
+    a.tiles_x = a.W / SW_OW;
+    a.tiles_y = (a.H + SW_SEG - 1) / SW_SEG;
+    const long long items = (long long)a.n * a.tiles_x * a.tiles_y;
+    const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+    if (a.cin == 24) hipLaunchKernelGGL((mb_block_s_kernel<24>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((mb_block_s_kernel<32>), grid, block, 0, s, a);
 }
