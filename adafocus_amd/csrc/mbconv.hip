@@ -886,12 +886,13 @@ void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s) {
 
 // whole-block kernel: stride-1 blocks with up to 32 output channels (b3, b5, b6 of MobileNetV2 1.0)
 bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw) {
+    if (mb_wave_enabled() && stride == 2) return adaf_mb_block_strip_ok(cin, hid, cout, stride, hw, hw);     // (stride 2: the strip form only)
     return mb_wave_enabled() && stride == 1 && (cin == 16 || cin == 24 || cin == 32) && hid % 4 == 0 && hid <= 192 && cout % 4 == 0 &&
            cout <= 32 && hw >= 28;
 }
 
 void adaf_launch_mb_block(MbFuseArgs a, hipStream_t s) {
-    if (adaf_mb_block_strip_ok(a.cin, a.hid, a.cout, 1, a.H, a.W)) return adaf_launch_mb_block_strip(a, s);
+    if (adaf_mb_block_strip_ok(a.cin, a.hid, a.cout, a.OH == a.H ? 1 : 2, a.H, a.W)) return adaf_launch_mb_block_strip(a, s);
     a.tiles_x = (a.OW + 7) / 8;
     a.tiles_y = (a.OH + 3) / 4;
     const long long tiles = (long long)a.n * a.tiles_x * a.tiles_y;

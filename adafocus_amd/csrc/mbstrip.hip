@@ -304,14 +304,18 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
         esc = nch < hid ? a.se[nch] : 0.f;
         ebi = nch < hid ? a.be[nch] : 0.f;
     };
+    const float* pw = a.wp + (size_t)n * hid + kq(g, 0);       // (one lane base + a per-chunk scalar + immediates: kq(g, q) - kq(g, 0) = 8 (q >> 1) + 2 (q & 1))
     auto load_wp = [&](int c) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            const float* pm = pw + (size_t)(16 * m) * hid + 32 * c;
+            const bool mv = 16 * m + n < a.cout;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = 32 * c + kq(g, q);
-                wp[m][q] = (16 * m + n < a.cout && k < hid) ? a.wp[(size_t)(16 * m + n) * hid + k] : 0.f;
+                wp[m][q] = (mv && k < hid) ? pm[8 * (q >> 1) + 2 * (q & 1)] : 0.f;
             }
+        }
     };
     auto fetch = [&](int s) {
         const int vo = voff0 + s * rstep;
@@ -462,6 +466,220 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A whole STRIDE-2 inverted-residual block (expand 1x1 -> BN/ReLU6 -> depthwise 3x3 / 2 -> BN/ReLU6 -> project 1x1 -> BN) as strip
+// segments: a wave owns 14 output columns x 4 output rows <- 29 (computed: 32) x 9 pixels of the expanded map.  An expanded ROW of the
+// strip is one 32-row MFMA band; a step computes two of them (rows 2 y - 2, 2 y - 1 for output row y; the first step of a segment only
+// the one row the segment's first output needs), the row shared with the previous output stays in a three-slot ring.  Columns are
+// stored even | odd (position (c & 1) * 17 + (c >> 1)) so that the taps' stride-2 reads are unit-stride across lanes.  One output row
+// per step: the taps of a chunk fit in registers beside the 32 accumulators of the segment (filled from the LDS table once per chunk).
+// The project conv rides in the same launch (b2: 96 -> 24, b4: 144 -> 32 at 224^2 frames): neither expanded map reaches HBM, and the
+// project launch and its read of the depthwise map are gone.  Same products in the same order as mb_expand_dw_w_kernel + the engine's
+// 1x1 conv: bit-identical.
+constexpr int S2_SEG = 4;
+constexpr int S2_ROWF = 34 * SW_EP;          // 32 columns + 2 the idle lanes read past, even | odd halves of 17
+constexpr int S2_RING = 3 * S2_ROWF;
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a) {
+    constexpr int KK = CIN / 8, NST = S2_SEG + 1;
+    __shared__ __attribute__((aligned(16))) float Eall[4][S2_RING];
+    __shared__ __attribute__((aligned(16))) float Tall[SW_MAXCH * 4 * SW_TAPF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hid = a.hid, nchunks = (hid + 31) >> 5;
+    for (int idx = tid; idx < nchunks * 4 * SW_TAPF; idx += 256) {
+        const int q = idx & 7, t = (idx >> 3) % 11, cg = idx / SW_TAPF;
+        const int ch = 32 * (cg >> 2) + kq(cg & 3, q);
+        float v = 0.f;
+        if (ch < hid) v = t < 9 ? a.wd[(size_t)t * hid + ch] : t == 9 ? a.sd[ch] : a.bd[ch];
+        Tall[idx] = v;
+    }
+    float* Ew = Eall[wave];
+    for (int i = lane; i < S2_RING; i += 64) Ew[i] = 0.f;
+    __syncthreads();
+    const int nstrips = a.tiles_x, nsegs = a.tiles_y;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.n * nstrips * nsegs) return;
+    const int img = item / (nstrips * nsegs), rem = item - img * (nstrips * nsegs);
+    const int seg = rem / nstrips, sx = rem - seg * nstrips;
+    const int ox0 = sx * SW_OW, y0 = seg * S2_SEG;
+    const int H = a.H, W = a.W, OH = a.OH, OW = a.OW;
+    const int rows = OH - y0 < S2_SEG ? OH - y0 : S2_SEG;
+    const int nsteps = rows + 1;
+    const bool left = sx == 0, top = seg == 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- expand GEMM roles: A row p = lane & 31 = expanded column 2 ox0 - 1 + p of expanded row 2 y0 - 2 + 2 s + band
+    const int half = lane >> 5, nl = lane & 31;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)img * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+    const int voff0 = (((2 * y0 - 2) * W + 2 * ox0 - 1 + nl) * CIN + 4 * half) * 4;
+    const int rband = W * CIN * 4, rstep = 2 * rband;
+    float* ewr = Ew + (2 * half) * SW_EP + pos_of(nl);      // accumulator row r: column c = (r & 3) + 8 (r >> 2) + 4 half -> position (c & 1) * 17 + (c >> 1)
+
+    // ---- depthwise / project roles: (output column n, k group g)
+    const int n = lane & 15, g = lane >> 4;
+    const float* erd = Ew + n * SW_EP + 8 * g;              // tap kx of output column n: expanded column 2 n + kx -> position n | 17 + n | n + 1
+    const float* tw = Tall + g * SW_TAPF;
+
+    f32x4 P[S2_SEG][2];
+#pragma unroll
+    for (int i = 0; i < S2_SEG; ++i) { P[i][0] = zero4; P[i][1] = zero4; }
+
+    // chunk operands: requested behind VALU reads of MFMA results only (see the kernels above)
+    f32x4 bf[KK], afa[KK], afb[KK];
+    float esc, ebi, wp[2][8];
+    auto load_bf = [&](int c) {
+        const int nch = 32 * c + nl;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            bf[kk] = nch < hid ? *reinterpret_cast<const f32x4*>(a.we + (size_t)nch * CIN + 8 * kk + 4 * half) : zero4;
+    };
+    auto load_bn = [&](int c) {
+        const int nch = 32 * c + nl;
+        esc = nch < hid ? a.se[nch] : 0.f;
+        ebi = nch < hid ? a.be[nch] : 0.f;
+    };
+    const float* pw = a.wp + (size_t)n * hid + kq(g, 0);       // (one lane base + a per-chunk scalar + immediates: kq(g, q) - kq(g, 0) = 8 (q >> 1) + 2 (q & 1))
+    auto load_wp = [&](int c) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float* pm = pw + (size_t)(16 * m) * hid + 32 * c;
+            const bool mv = 16 * m + n < a.cout;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = 32 * c + kq(g, q);
+                wp[m][q] = (mv && k < hid) ? pm[8 * (q >> 1) + 2 * (q & 1)] : 0.f;
+            }
+        }
+    };
+    auto fetch = [&](int s) {       // (step 0 needs its second row only)
+        int vo = voff0 + s * rstep;
+        asm volatile("" : "+v"(vo));        // (recomputed per use: hoisted out of the chunk loop the ten step offsets are spilled)
+        if (s > 0) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) afa[kk] = bload(rsrc, vo + 32 * kk);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) afb[kk] = bload(rsrc, vo + rband + 32 * kk);
+    };
+    load_bf(0);
+    load_bn(0);
+    fetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const float* tc = tw + c * 4 * SW_TAPF;
+        // the chunk's taps and depthwise affine: 8 channels x (9 + 2) of this lane's k group, from the table
+        f32x2 tap[9][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 ta = *reinterpret_cast<const f32x4*>(tc + t * 8), tb = *reinterpret_cast<const f32x4*>(tc + t * 8 + 4);
+            tap[t][0] = f32x2{ta.x, ta.y}; tap[t][1] = f32x2{ta.z, ta.w}; tap[t][2] = f32x2{tb.x, tb.y}; tap[t][3] = f32x2{tb.z, tb.w};
+        }
+        auto step = [&](auto SC) {
+            constexpr int s = decltype(SC)::value;
+            constexpr int SLA = (2 * s) % 3, SLB = (2 * s + 1) % 3, SLP = (2 * s + 2) % 3;      // (2 s - 1) % 3
+            // one expanded row = one band: chain -> BN / ReLU6 -> ring, row A (absent in step 0) then row B
+            auto band = [&](const f32x4 (&af)[KK], int slotf, bool zero_row) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
+                const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, sc2, bi2);
+                    acc[r] = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f);
+                    acc[r + 1] = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
+                }
+                if (zero_row) {
+                    asm volatile("");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;          // expanded row -1
+                }
+                if (left) { asm volatile(""); if (half == 0) acc[0] = 0.f; }     // expanded column -1
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ewr[slotf + ((r & 1) * 17 + ((r & 3) >> 1) + 4 * (r >> 2)) * SW_EP] = acc[r];
+            };
+            __builtin_amdgcn_wave_barrier();        // the previous step's tap reads are issued
+            if (s > 0) band(afa, SLA * S2_ROWF, false);
+            band(afb, SLB * S2_ROWF, s == 0 && top);
+            __builtin_amdgcn_sched_barrier(0);      // (both chains have retired: their results were read)
+            if (s == 0) load_wp(c);
+            if (s + 1 < NST && s + 1 < nsteps) fetch(s + 1);
+            else if (c + 1 < nchunks) {
+                load_bf(c + 1);
+                load_bn(c + 1);
+                fetch(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (s > 0) {
+                constexpr int slot[3] = {SLP, SLA, SLB};
+                f32x2 s0[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s0[i] = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* p = erd + slot[ky] * S2_ROWF + (kx == 1 ? 17 : kx == 2 ? 1 : 0) * SW_EP;
+                        const f32x4 va = *reinterpret_cast<const f32x4*>(p), vb = *reinterpret_cast<const f32x4*>(p + 4);
+                        const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pkfma(s0[i], v[i], tap[ky * 3 + kx][i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (one expanded row's reads in flight at a time: 24 registers, not 72)
+                }
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(tc + 72), sb = *reinterpret_cast<const f32x4*>(tc + 76);
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(tc + 80), bb = *reinterpret_cast<const f32x4*>(tc + 84);
+                const f32x2 dsc[4] = {{sa.x, sa.y}, {sa.z, sa.w}, {sb.x, sb.y}, {sb.z, sb.w}}, dbi[4] = {{ba.x, ba.y}, {ba.z, ba.w}, {bb.x, bb.y}, {bb.z, bb.w}};
+                float d0[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 r0 = __builtin_elementwise_fma(s0[i], dsc[i], dbi[i]);
+                    d0[2 * i] = __builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f); d0[2 * i + 1] = __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    P[s - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0][q], d0[q], P[s - 1][0], 0, 0, 0);
+                    P[s - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[1][q], d0[q], P[s - 1][1], 0, 0, 0);
+                }
+            }
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        if (nsteps > 2) step(std::integral_constant<int, 2>{});
+        if (nsteps > 3) step(std::integral_constant<int, 3>{});
+        if (nsteps > 4) step(std::integral_constant<int, 4>{});
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (n < SW_OW) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int co = 16 * m + 4 * g;
+            if (co < a.cout) {
+                const f32x4 psc = *reinterpret_cast<const f32x4*>(a.sp + co), pbi = *reinterpret_cast<const f32x4*>(a.bp + co);
+#pragma unroll
+                for (int i = 0; i < S2_SEG; ++i)
+                    if (i < rows) {
+                        const size_t gi = (((size_t)img * OH + y0 + i) * OW + ox0 + n) * a.cout + co;
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaf(P[i][m][r], psc[r], pbi[r]);
+                        if (a.res) {
+                            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + gi);
+                            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                        }
+                        *reinterpret_cast<f32x4*>(a.out2 + gi) = v;
+                    }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool adaf_mb_stem_b1_strip_ok(int S, int H1) { return adaf_options().mb_strip != 0 && S == 2 * H1 && H1 % SW_OW == 0 && H1 >= SW_OW; }
@@ -475,11 +693,22 @@ void adaf_launch_mb_stem_b1_strip(MbStemArgs a, hipStream_t s) {
 
 // whole stride-1 blocks as strip segments (b3, b5, b6 of MobileNetV2 1.0 at 224^2): square maps whose side is a multiple of 14
 bool adaf_mb_block_strip_ok(int cin, int hid, int cout, int stride, int h, int w) {
-    return adaf_options().mb_strip != 0 && stride == 1 && (cin == 24 || cin == 32) && hid <= 32 * SW_MAXCH && hid % 4 == 0 && cout % 4 == 0 &&
-           cout <= 32 && h == w && w % SW_OW == 0 && h % 2 == 0;
+    if (adaf_options().mb_strip == 0 || hid > 32 * SW_MAXCH || hid % 4 || cout % 4 || cout > 32 || h != w) return false;
+    if (stride == 1) return (cin == 24 || cin == 32) && w % SW_OW == 0 && h % 2 == 0;
+    // stride 2 (b2, b4 at 224^2): even maps whose half is a multiple of 14
+    return stride == 2 && (cin == 16 || cin == 24) && w % 2 == 0 && (w / 2) % SW_OW == 0;
 }
 
 void adaf_launch_mb_block_strip(MbFuseArgs a, hipStream_t s) {
+    if (a.OH != a.H) {      // stride 2
+        a.tiles_x = a.OW / SW_OW;
+        a.tiles_y = (a.OH + S2_SEG - 1) / S2_SEG;
+        const long long items = (long long)a.n * a.tiles_x * a.tiles_y;
+        const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+        if (a.cin == 16) hipLaunchKernelGGL((mb_block_s2_kernel<16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((mb_block_s2_kernel<24>), grid, block, 0, s, a);
+        return;
+    }
     a.tiles_x = a.W / SW_OW;
     a.tiles_y = (a.H + SW_SEG - 1) / SW_SEG;
     const long long items = (long long)a.n * a.tiles_x * a.tiles_y;
