@@ -80,7 +80,7 @@ struct OptKey { const char* name; int kind; double lo, hi; };      // kind: inde
 const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
                            {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
                            {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 511}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
-                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}, {"gru_barrier", 15, 0, 1}, {"mb_strip", 16, 0, 1}};
+                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}, {"gru_barrier", 15, 0, 1}, {"mb_strip", 16, 0, 1}, {"gru_graph_persistent", 17, 0, 1}};
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
     for (const OptKey& k : kOptKeys)
@@ -167,6 +167,7 @@ int adaf_set_option(adaf_handle* h, const char* key, double value) {
         case 14: o.split_stage1_f32 = (int)value; break;
         case 15: o.gru_barrier = (int)value; break;
         case 16: o.mb_strip = (int)value; break;
+        case 17: o.gru_graph_persistent = (int)value; break;
         default: o.effnet_chunk = (int)value; break;
     }
     return ADAF_OK;
@@ -193,6 +194,7 @@ double adaf_get_option(const char* key) {
         case 14: return o.split_stage1_f32;
         case 15: return o.gru_barrier;
         case 16: return o.mb_strip;
+        case 17: return o.gru_graph_persistent;
         default: return o.effnet_chunk;
     }
 }
@@ -1047,15 +1049,18 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
     int rc;
     // all input projections at once: gi[b*T+t, :] = W_ih x[b,t] + b_ih
     if ((rc = linear_launch(h, x, batch * steps, ldx, feat, 3 * hidden, w_ih, b_ih, gi, 0, st))) return rc;
-    if (h->gru_persistent && steps + 1 <= batch * 3 * hidden &&
+    // While `st` is being captured into a HIP graph (GFV.capture_hot_path, the small-batch latency mode) the slot events below cannot be part
+    // of the capture (an event recorded outside a capture cannot be waited on inside one), so a captured persistent scan would sit OUTSIDE the
+    // throttle that keeps the grid barrier's blocks co-resident: two graphs replayed side by side, or a graph beside eager hot paths, could
+    // starve each other into the barrier's time-out (NaN-poisoned logits).  A capture therefore takes the launch-per-step form, which has no
+    // grid barrier, unless the option "gru_graph_persistent" says the caller guarantees exclusive use (HotPathGraph then checks the time-out
+    // counter every few replays).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (h->gru_persistent && steps + 1 <= batch * 3 * hidden && (!capturing || adaf_options().gru_graph_persistent) &&
         adaf_gru_scan_persistent_ok(batch, hidden, fc_w ? classes : 0, h->scan_resident)) {
         // the whole recurrence (+ classifier) in one kernel; `gh` only lends its first steps+1 words to the grid barrier
-        // (while `st` is being captured into a HIP graph -- GFV.capture_hot_path, the small-batch latency mode -- the slot
-        // events stay out of it: an event recorded outside a capture cannot be waited on inside one, and a graph is
-        // replayed on ONE stream, where consecutive scans are ordered anyway)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cap);
-        const bool capturing = cap != hipStreamCaptureStatusNone;
         // a scan cut into two slices (batch > 32) takes two sets of blocks, i.e. two of the slots the resident-block budget is made of
         const int groups = (2 * steps + 2 <= batch * 3 * hidden) ? adaf_gru_scan_groups(batch, h->scan_resident) : 1;
         const int need = groups > h->scan_slots ? h->scan_slots : groups;

@@ -209,17 +209,19 @@ class GFV(nn.Module):
         logits, last = self.classifier(feature)
         return logits, last, feature
 
-    def capture_hot_path(self, b, t, frame_shape=None):
+    def capture_hot_path(self, b, t, frame_shape=None, exclusive=False, check_every=16):
         """Latency mode for small batches (BASELINE config 1 is B = 2; the reference's published CPU figure is a bs = 1
         latency): one hot-path step for a FIXED (B, T) captured into a HIP graph, so its ~50 dependent, nearly empty
-        launches are replayed back to back by the runtime instead of being issued one by one from Python.  Same kernels,
-        same order: bit-identical to hot_path().  Returns a HotPathGraph; call it with (frames, glancer vectors, actions).
-        EXCLUSIVE USE: a captured persistent GRU scan is outside the library's `scan_slots` throttle (slot events cannot be part of a
-        capture), so while a graph replays, no other stream may run hot paths / GRU scans on this device and one graph must not be
-        replayed on two streams at once -- more co-resident scans than the grid barrier was budgeted for starve each other; the only
-        symptom is the barrier time-out (NaN-poisoned logits, counted by hip_ops.gru_scan_timeouts(), which the evaluation loops
-        check).  Latency mode is one stream by definition; for overlapped batches use the eager hot_path on several streams."""
-        return HotPathGraph(self, b, t, frame_shape)
+        launches are replayed back to back by the runtime instead of being issued one by one from Python.  Returns a
+        HotPathGraph; call it with (frames, glancer vectors, actions).
+        The persistent GRU scan's grid barrier needs its blocks co-resident, which the library guarantees for eager launches by
+        throttling scans over `scan_slots` events -- events that cannot be part of a capture.  So by default a capture takes the
+        GRU's launch-per-step form (no grid barrier: any number of graphs may replay side by side, beside eager hot paths; same
+        arithmetic as hot_path() under hip_ops.set_gru_persistent(0), bit for bit).  `exclusive=True` keeps the persistent scan in the
+        graph (bit-identical to the default eager hot_path()): the caller then promises that nothing else runs GRU scans on the device
+        while the graph replays, and the graph checks the barrier's time-out counter every `check_every` replays (a device
+        synchronisation; 0 = never) and raises AdafError instead of handing out NaN-poisoned logits."""
+        return HotPathGraph(self, b, t, frame_shape, exclusive=exclusive, check_every=check_every)
 
     def glance(self, input_prime):
         """Reference layout: (featmap (B,T,1280,h,w) [a permuted view of the pixel-major map], vec (B,T,1280))."""
@@ -247,12 +249,16 @@ class HotPathGraph:
     """A captured hot-path step (GFV.capture_hot_path).  The graph reads the static buffers `frames` (B*T,3,H,W),
     `gvec` (B,T,1280) and `actions` (B*T,2) and writes `logits` (B*T,C) / `last` (B,C); __call__ copies its arguments into
     the static inputs (or write them in place and call replay()).  One graph = one stream: replay it from the stream the
-    results are consumed on."""
+    results are consumed on.  See GFV.capture_hot_path for `exclusive` / `check_every`."""
 
-    def __init__(self, model, b, t, frame_shape=None):
+    def __init__(self, model, b, t, frame_shape=None, exclusive=False, check_every=16):
+        from . import _lib, hip_ops
         dev = next(model.parameters()).device
         hh = model.input_size
         self.b, self.t = b, t
+        self.device = dev
+        self.exclusive, self.check_every = bool(exclusive), int(check_every)
+        self._replays = 0
         self.frames = torch.zeros(tuple(frame_shape) if frame_shape else (b * t, 3, hh, hh), device=dev)
         self.gvec = torch.zeros((b, t, model.glancer.feature_dim), device=dev) if model.with_glancer else None
         self.actions = torch.zeros((b * t, 2), device=dev)
@@ -264,12 +270,29 @@ class HotPathGraph:
                 model.hot_path(self.frames, self.gvec, self.actions, b, t)
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
+        self._timeouts0 = hip_ops.gru_scan_timeouts(dev) if self.exclusive else 0
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.logits, self.last, self.feature = model.hot_path(self.frames, self.gvec, self.actions, b, t)
+        with _lib.option("gru_graph_persistent", 1 if self.exclusive else 0):
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.logits, self.last, self.feature = model.hot_path(self.frames, self.gvec, self.actions, b, t)
+
+    def check(self):
+        """exclusive graphs: synchronise and raise if a persistent scan's grid barrier has timed out since the capture (its logits are
+        NaN-poisoned: something else ran GRU scans beside this graph)."""
+        from . import _lib, hip_ops
+        if self.exclusive:
+            n = hip_ops.gru_scan_timeouts(self.device)
+            if n != self._timeouts0:
+                self._timeouts0 = n
+                raise _lib.AdafError("HotPathGraph: %d block(s) of a persistent GRU scan timed out at their grid barrier -- an `exclusive` graph "
+                                     "was replayed beside other GRU scans; the affected logits are NaN-poisoned" % n)
 
     def replay(self):
         self.graph.replay()
+        if self.exclusive and self.check_every > 0:
+            self._replays += 1
+            if self._replays % self.check_every == 0:
+                self.check()
         return self.logits, self.last
 
     def __call__(self, frames, gvec, actions):

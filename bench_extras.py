@@ -280,7 +280,8 @@ def latency_rows(dev, cases=((1, 8), (2, 8), (2, 16)), p=96, iters=200):
             torch.cuda.synchronize()
             eager = (time.perf_counter() - t0) / iters
             ref = lg.clone()
-            g = m.capture_hot_path(b, t)
+            # `exclusive`: the persistent GRU scan stays in the graph (the same kernels as the eager step; this process runs nothing beside it)
+            g = m.capture_hot_path(b, t, exclusive=True, check_every=0)
             g(fr, gv, act)
             torch.cuda.synchronize()
             same = bool(torch.equal(g.logits, ref))
@@ -289,6 +290,17 @@ def latency_rows(dev, cases=((1, 8), (2, 8), (2, 16)), p=96, iters=200):
                 g.replay()
             torch.cuda.synchronize()
             graph = (time.perf_counter() - t0) / iters
+            g.check()
+            # the default capture: GRU in its launch-per-step form (no grid barrier: safe beside other graphs / eager hot paths)
+            gs = m.capture_hot_path(b, t)
+            gs(fr, gv, act)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                gs.replay()
+            torch.cuda.synchronize()
+            graph_safe = (time.perf_counter() - t0) / iters
+            del gs
             # the same step with every conv on the engine's batched tiles (the round-2 plan): what the small-batch form buys
             trunk = m.focuser.net._sync()
             trunk.set_latency_rows(0)
@@ -303,13 +315,14 @@ def latency_rows(dev, cases=((1, 8), (2, 8), (2, 16)), p=96, iters=200):
             same_bits = bool(torch.equal(lg, ref))
             trunk.set_latency_rows(-1)
         rows["B%d_T%d_P%d" % (b, t, p)] = {"eager_ms": round(eager * 1e3, 4), "graph_ms": round(graph * 1e3, 4),
+                                            "graph_default_capture_ms": round(graph_safe * 1e3, 4),
                                             "clips_per_s": round(b / min(eager, graph), 1), "graph_bit_identical_to_eager": same,
                                             "batched_tiles_only_ms": round(batched * 1e3, 4),
                                             "speedup_over_batched_tiles": round(batched / min(eager, graph), 3),
                                             "bit_identical_to_batched_tiles": same_bits}
         del g, m
     rows["note"] = ("one hot-path step (gather + ResNet-50 + GRU classifier) per call, back to back, %d calls; eager = Python-issued "
-                    "launches, graph = GFV.capture_hot_path replay; convs with <= 1536 GEMM rows run on the small-batch form "
+                    "launches, graph = GFV.capture_hot_path(exclusive=True) replay (persistent GRU scan in the graph), graph_default_capture = the default capture (GRU launch per step: no grid barrier, may replay beside anything); convs with <= 1536 GEMM rows run on the small-batch form "
                     "(csrc/conv_lat.hip: v_mfma_f32_16x16x4_f32 chains in the engine's k order), batched_tiles_only_ms = the same step "
                     "with that switched off (adaf_resnet50_set_latency_rows(net, 0))" % iters)
     return rows

@@ -596,7 +596,7 @@ def test_chunk_pairs_inside_a_captured_hot_path(dev):
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 1007).items()}, strict=True)
     m = m.to(dev)
-    g = m.capture_hot_path(b, t)
+    g = m.capture_hot_path(b, t, exclusive=True, check_every=1)      # (persistent GRU scan in the graph: the same kernels as the eager step)
     for seed in (71, 72, 73):
         fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=seed)).to(dev).view(b * t, 3, 224, 224)
         _, act = synth.synth_actions(b * t, 7, seed=seed + 10)

@@ -599,13 +599,16 @@ def test_validate_sth_loop_against_golden(dev, vd):
     assert torch.equal(nb[4], lg) and nb[2] == [None] * vd
 
 
-def test_latency_mode_graph_replay_bit_identical(dev):
+def test_latency_mode_graph_replay_bit_identical(dev, ops):
     """GFV.capture_hot_path: BASELINE config 1's step (B = 2, T = 8, P = 96) captured into a HIP graph and replayed on new
-    inputs equals the eagerly launched step bit for bit (same kernels, same order), also for B = 1."""
+    inputs equals the eagerly launched step bit for bit (same kernels, same order), also for B = 1 -- the default capture (GRU in
+    its launch-per-step form: no grid barrier inside a graph) against eager mode 0, the `exclusive` capture (persistent scan in the
+    graph, time-out counter checked after every replay) against the default eager step."""
     m, _ = _act_model(dev)
     for b in (2, 1):
         t = 8
         g = m.capture_hot_path(b, t)
+        gx = m.capture_hot_path(b, t, exclusive=True, check_every=1)
         for seed in (61, 62, 63):
             fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=seed)).to(dev).view(b * t, 3, 224, 224)
             _, act = synth.synth_actions(b * t, 7, seed=seed + 10)
@@ -614,9 +617,57 @@ def test_latency_mode_graph_replay_bit_identical(dev):
             with torch.no_grad():
                 lg, last, _ = m.hot_path(fr, gv, act, b, t)
                 lg, last = lg.clone(), last.clone()
-                glg, glast = g(fr, gv, act)
+                try:
+                    ops.set_gru_persistent(0, dev)
+                    lg0, last0, _ = m.hot_path(fr, gv, act, b, t)
+                    lg0, last0 = lg0.clone(), last0.clone()
+                finally:
+                    ops.set_gru_persistent(1, dev)
+                glg, glast = [v.clone() for v in g(fr, gv, act)]
+                xlg, xlast = [v.clone() for v in gx(fr, gv, act)]
             torch.cuda.synchronize()
-            assert torch.equal(glg, lg) and torch.equal(glast, last), (b, seed)
+            assert torch.equal(glg, lg0) and torch.equal(glast, last0), (b, seed)
+            assert torch.equal(xlg, lg) and torch.equal(xlast, last), (b, seed)
+            assert (lg0 - lg).abs().max().item() < 1e-4        # (the two GRU forms differ in summation order only)
+
+
+def test_two_captured_hot_paths_replayed_concurrently_never_hand_out_nan(dev, ops):
+    """two captured hot paths replayed at the same time on two streams.  Default captures carry no grid barrier, so
+    every replay is bit-identical to the graph's own single-stream result.  `exclusive` captures (persistent scan, outside the slot
+    throttle) either complete bit-identically or raise AdafError at their check -- NaN logits are never handed out silently."""
+    from adafocus_amd._lib import AdafError
+    m, _ = _act_model(dev)
+    b, t = 2, 8
+    fr = torch.from_numpy(synth.synth_frames(b, t, 224, seed=71)).to(dev).view(b * t, 3, 224, 224)
+    act = torch.from_numpy(synth.synth_actions(b * t, 7, seed=72)[1]).to(dev)
+    gv = rnd((b, t, 1280), 73, 0.5).to(dev)
+    for exclusive in (False, True):
+        g1 = m.capture_hot_path(b, t, exclusive=exclusive, check_every=1)
+        g2 = m.capture_hot_path(b, t, exclusive=exclusive, check_every=1)
+        with torch.no_grad():
+            ref = g1(fr, gv, act)[0].clone()
+            g2(fr, gv, act)
+            torch.cuda.synchronize()
+            s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            raised = False
+            try:
+                for _ in range(20):
+                    with torch.cuda.stream(s1):
+                        g1.graph.replay()
+                    with torch.cuda.stream(s2):
+                        g2.graph.replay()
+                torch.cuda.synchronize()
+                g1.check()
+                g2.check()
+            except AdafError:
+                raised = True
+        torch.cuda.synchronize()
+        if exclusive:
+            assert raised or (torch.equal(g1.logits, ref) and torch.equal(g2.logits, ref))
+            assert raised or bool(torch.isfinite(g1.logits).all() and torch.isfinite(g2.logits).all())
+        else:
+            assert not raised and torch.equal(g1.logits, ref) and torch.equal(g2.logits, ref)
+        del g1, g2
 
 
 # ------------------------------------------------------------------------------------ GRU scan

@@ -1,0 +1,87 @@
+"""Round 6: the strip-walking front of the MobileNetV2 glancer (csrc/mbstrip.hip; SURVEY.md §8 a10 / f2,
+ACT/models/mobilenet.py:42-68,71-148) against the wave-private tile kernels it replaces and the three-launch plan."""
+import pytest
+import torch
+
+from adafocus_amd import _lib as L
+from tests.helpers import rnd, synth_sd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the HIP path needs the MI355X"
+    return torch.device("cuda:0")
+
+
+def _glancer(dev, seed=505):
+    from adafocus_amd.mobilenet import mobilenet_v2
+    net = mobilenet_v2().eval()
+    sd = {k: v for k, v in synth_sd("ACT", seed, "glancer.net.", keep_prefix=False).items() if not k.startswith("classifier")}
+    net.load_state_dict(sd, strict=False)
+    return net.to(dev)
+
+
+def _frames(dev, n, size, seed):
+    x4 = torch.zeros((n, size, size, 4), device=dev)
+    x4[..., :3] = rnd((n, size, size, 3), seed).to(dev)
+    return x4
+
+
+def test_strip_kernels_bit_identical_to_tiles_and_to_the_three_launch_plan(dev):
+    """Strips need maps whose side is a multiple of 14 (stem output; 28 for the stride-2 blocks): 224^2 takes every strip kernel (stem + b1,
+    b2 .. b6), 56 / 84 / 140 / 168 some of them with edge strips only, partial last row segments (28 / 8, 42 / 8) and ragged strides, 200 and
+    120 none (the tile kernels).  Every plan must produce the same feature map, bit for bit: strips, tiles, tiles without the whole-block
+    kernels, the unfused three launches."""
+    net = _glancer(dev)
+    for n, size in ((5, 224), (3, 56), (2, 84), (3, 140), (2, 168), (3, 200), (4, 120), (520, 56)):
+        x4 = _frames(dev, n, size, 600 + size)
+        outs = []
+        with torch.no_grad():
+            for strip, fusion in ((1, True), (0, True), (1, 9), (0, False)):
+                with L.option("mb_strip", strip):
+                    net._engine.fusion = fusion
+                    fm, fv = net.features_from_nhwc4(x4)
+                    outs.append((fm.clone(), fv.clone()))
+        net._engine.fusion = True
+        for fm, fv in outs[1:]:
+            assert torch.equal(fm, outs[0][0]) and torch.equal(fv, outs[0][1]), (n, size)
+        assert outs[0][0].abs().max().item() > 0.1
+
+
+def test_strip_kernels_run_to_run_and_batch_position(dev):
+    """The strip kernels request their operands behind VALU reads of the MFMA chains that read the landing registers (a returning load is not
+    interlocked against an in-flight MFMA): the same batch ten times must give the same bits, and a frame's features must not depend on its
+    position in the batch (1024 frames = two chunks side by side on two streams; 5 frames = a partial block of strips)."""
+    net = _glancer(dev, 506)
+    x4 = _frames(dev, 1024, 224, 77)
+    with torch.no_grad():
+        ref = [t.clone() for t in net.features_from_nhwc4(x4)]
+        for _ in range(10):
+            fm, fv = net.features_from_nhwc4(x4)
+            assert torch.equal(fm, ref[0]) and torch.equal(fv, ref[1])
+        sub = torch.cat([x4[1000:1003], x4[5:7]])
+        fm, fv = net.features_from_nhwc4(sub)
+        assert torch.equal(fm[:3], ref[0][1000:1003]) and torch.equal(fm[3:], ref[0][5:7]) and torch.equal(fv[3:], ref[1][5:7])
+
+
+def test_sth_glancer_with_temporal_shift_on_strips(dev):
+    """The Something-Something glancer (temporal shift in front of the residual blocks' expand convs, STH/models/gfv_net.py:235-246) at 224^2:
+    the shifted input is materialised once and the strip kernels read it, the identity rows stay unshifted -- strips == tiles == unfused."""
+    from adafocus_amd.gfv_net_sth import Glancer
+    from tests.test_state_dict_compat import sth_args
+    gl = Glancer(sth_args()).eval()
+    gl.load_state_dict(synth_sd("STH", 78, "glancer.", keep_prefix=False), strict=True)
+    gl = gl.to(dev)
+    x = rnd((16, 3, 224, 224), 56).to(dev)
+    outs = []
+    with torch.no_grad():
+        for strip, fusion in ((1, True), (0, True), (0, False)):
+            with L.option("mb_strip", strip):
+                gl.net._engine.fusion = fusion
+                fm, logit = gl(x)
+                outs.append((fm.clone(), logit.clone()))
+    gl.net._engine.fusion = True
+    for fm, logit in outs[1:]:
+        assert torch.equal(fm, outs[0][0]) and torch.equal(logit, outs[0][1])
