@@ -272,8 +272,11 @@ class HotPathGraph:
         torch.cuda.synchronize(dev)
         self._timeouts0 = hip_ops.gru_scan_timeouts(dev) if self.exclusive else 0
         self.graph = torch.cuda.CUDAGraph()
+        # captured on a stream of its OWN: the engines key their scratch (trunk workspace, GRU buffers) by the stream they are called on, and
+        # torch's default capture stream is one per process -- two graphs captured on it would share scratch and race when replayed side by side
+        self._capture_stream = torch.cuda.Stream(device=dev)
         with _lib.option("gru_graph_persistent", 1 if self.exclusive else 0):
-            with torch.no_grad(), torch.cuda.graph(self.graph):
+            with torch.no_grad(), torch.cuda.graph(self.graph, stream=self._capture_stream):
                 self.logits, self.last, self.feature = model.hot_path(self.frames, self.gvec, self.actions, b, t)
 
     def check(self):
