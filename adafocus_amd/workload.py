@@ -81,14 +81,16 @@ def mobilenetv2_macs_per_frame(size=224):
     return macs
 
 
-def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_blocks=True):
+def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_blocks=True, strips=True):
     """HBM bytes per frame of the glancer's launch plan (csrc/mobilenetv2.hip): every launch's activation inputs +
     outputs (+ residual), fp32, weights ignored (2.2 M parameters shared by >= 512 frames per launch).
     fused=True: stem + block 1 are one kernel and the expand -> depthwise pairs of the blocks with cin <= 32 on maps
     >= 28^2 are one kernel each (csrc/mbconv.hip), so their wide intermediates never reach HBM.
     fused_tail=True: additionally expand -> depthwise -> project of the 14^2 / 7^2 blocks are one kernel each.
     whole_blocks=True (with fused): the stride-1 blocks with cin, cout <= 32 on maps >= 28^2 (b3, b5, b6) run expand ->
-    depthwise -> project + identity in one kernel (mb_block_w_kernel): block input in (and once more as the identity), output out."""
+    depthwise -> project + identity in one kernel (mb_block_w_kernel): block input in (and once more as the identity), output out.
+    strips=True (round 6, csrc/mbstrip.hip; maps whose output side is a multiple of 14): the stride-2 blocks with 16 / 24 input channels
+    (b2, b4) are whole-block launches too -- their depthwise map and the project launch's read of it are gone."""
     hw = _out(size, 3, 2, 1)
     elems = size * size * 4                                  # pixel-major NHWC4 frames, read once
     first = True
@@ -106,7 +108,8 @@ def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_bl
             last = b
             continue
         pair_fused = fused and b["inp"] <= 32 and b["hw"] >= 28
-        if pair_fused and whole_blocks and b["stride"] == 1 and b["oup"] <= 32 and hid <= 192:
+        s2_whole = strips and b["stride"] == 2 and b["inp"] in (16, 24) and b["ohw"] % 14 == 0
+        if pair_fused and whole_blocks and (b["stride"] == 1 or s2_whole) and b["oup"] <= 32 and hid <= 192:
             elems += hin * b["inp"] + hout * b["oup"] + (hout * b["oup"] if res else 0)
         elif fused_tail and b["hw"] <= 14:
             elems += hin * b["inp"] + hout * b["oup"]        # whole block in one kernel (residual = its own input)

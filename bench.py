@@ -501,6 +501,11 @@ def bench_summary(res):
     return s
 
 
+def _lib_opt(key):
+    from adafocus_amd import _lib
+    return _lib.get_option(key)
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -879,7 +884,7 @@ def main():
                 ing_bytes = float(b * t * 224 * 224 * (3 + 16))
                 gl_fusion = int(model.glancer.net._engine.fusion)        # adaf_mobilenetv2_set_fusion bits (True = 1)
                 gl_bytes = float(b * t) * workload.mobilenetv2_bytes_per_frame(224, fused=bool(gl_fusion & 1), fused_tail=model.glancer.net.fused_tail(),
-                                                                                whole_blocks=not (gl_fusion & 8))
+                                                                                whole_blocks=not (gl_fusion & 8), strips=bool(_lib_opt("mb_strip")))
                 gl_flop = 2.0 * workload.mobilenetv2_macs_per_frame(224)
                 gl_block = float(b * t) * workload.mobilenetv2_block_bytes_per_frame(224)
                 gl_traffic = load_glancer_traffic(b * t)
