@@ -21,7 +21,7 @@ CONV_TILES = 4
 
 # every symbol include/adafocus.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "adaf_version", "adaf_create", "adaf_destroy", "adaf_last_error", "adaf_device_cus", "adaf_set_gru_persistent", "adaf_set_conv_pos_major", "adaf_gru_scan_timeouts", "adaf_set_option", "adaf_get_option",
+    "adaf_version", "adaf_create", "adaf_destroy", "adaf_last_error", "adaf_device_cus", "adaf_set_gru_persistent", "adaf_set_conv_pos_major", "adaf_gru_scan_timeouts", "adaf_set_global_option", "adaf_get_global_option",
     "adaf_crop_gather_f32", "adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32", "adaf_pack_conv_weight_f32",
     "adaf_fold_bn_f32", "adaf_maxpool3x3s2_f32", "adaf_global_avgpool_f32", "adaf_temporal_shift_f32",
     "adaf_resnet50_create", "adaf_resnet50_destroy", "adaf_resnet50_set_param", "adaf_resnet50_finalize",
@@ -32,7 +32,7 @@ SYMBOLS = (
     "adaf_mobilenetv2_set_param", "adaf_mobilenetv2_finalize", "adaf_mobilenetv2_workspace_bytes",
     "adaf_mobilenetv2_forward", "adaf_mobilenetv2_set_fusion", "adaf_grid_actions_f32", "adaf_gru_seq_forward_f32",
     "adaf_crop_gather_nhwc4_f32", "adaf_ingest_u8_f32", "adaf_crop_resize_f32", "adaf_resize_nearest_f32",
-    "adaf_conv2d_bn_act_f16", "adaf_pack_conv_weight_f16", "adaf_cast_f32_f16", "adaf_dwconv3x3_bn_act_f16", "adaf_mobilenetv2_set_dtype",
+    "adaf_conv2d_bn_act_f16", "adaf_pack_conv_weight_f16", "adaf_cast_f32_f16", "adaf_dwconv3x3_bn_act_f16",
     "adaf_pack_dw_weight_kxk_f32", "adaf_dwconv_same_workspace_bytes", "adaf_dwconv_same_bn_act", "adaf_se_gate_f32", "adaf_conv1x1_gated_bn",
     "adaf_effnet_create", "adaf_effnet_destroy", "adaf_effnet_feature_dim", "adaf_effnet_block_count", "adaf_effnet_block_info",
     "adaf_effnet_set_dtype", "adaf_effnet_set_fusion", "adaf_effnet_whole_blocks", "adaf_effnet_fused_expand_blocks", "adaf_effnet_set_param", "adaf_effnet_finalize", "adaf_effnet_workspace_bytes", "adaf_effnet_forward",
@@ -69,9 +69,9 @@ def load_library():
     lib.adaf_set_gru_persistent.argtypes = [vp, ip]
     lib.adaf_set_conv_pos_major.argtypes = [vp, ip]
     lib.adaf_gru_scan_timeouts.argtypes = [vp, C.POINTER(C.c_uint)]
-    lib.adaf_set_option.argtypes = [vp, C.c_char_p, C.c_double]
-    lib.adaf_get_option.argtypes = [C.c_char_p]
-    lib.adaf_get_option.restype = C.c_double
+    lib.adaf_set_global_option.argtypes = [C.c_char_p, C.c_double]
+    lib.adaf_get_global_option.argtypes = [C.c_char_p]
+    lib.adaf_get_global_option.restype = C.c_double
     lib.adaf_crop_gather_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, ip, vp, vp]
     for name in ("adaf_conv2d_bn_act_f32", "adaf_conv2d_naive_f32"):
         getattr(lib, name).argtypes = [vp, C.POINTER(ConvParams), vp, vp, vp, vp, vp, vp, vp]
@@ -123,7 +123,6 @@ def load_library():
     lib.adaf_pack_conv_weight_f16.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp]
     lib.adaf_cast_f32_f16.argtypes = [vp, vp, C.c_size_t, vp, ip, vp]
     lib.adaf_dwconv3x3_bn_act_f16.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, vp, vp, ip, vp, vp]
-    lib.adaf_mobilenetv2_set_dtype.argtypes = [vp, ip]
     lib.adaf_pack_dw_weight_kxk_f32.argtypes = [vp, vp, ip, ip, vp, vp]
     lib.adaf_dwconv_same_workspace_bytes.restype = C.c_size_t
     lib.adaf_dwconv_same_workspace_bytes.argtypes = [ip, ip, ip, ip, ip, ip, ip]
@@ -171,18 +170,19 @@ EF_PLAN_WHOLE_BLOCK, EF_PLAN_TINY_DW, EF_PLAN_STRIP_PROJECT, EF_PLAN_STRIP_EXPAN
 
 
 def get_option(key):
-    """Current value of a process-wide tuning / A-B switch of the library (include/adafocus.h: adaf_get_option)."""
-    v = load_library().adaf_get_option(key.encode())
+    """Current value of a process-wide tuning / A-B switch of the library (include/adafocus.h: adaf_get_global_option)."""
+    v = load_library().adaf_get_global_option(key.encode())
     if v != v:
-        raise AdafError("adaf_get_option: unknown key %r" % key)
+        raise AdafError("adaf_get_global_option: unknown key %r" % key)
     return v
 
 
 def set_option(key, value, device=None):
-    """Set a process-wide switch (include/adafocus.h: adaf_set_option); returns the previous value."""
+    """Set a process-wide switch (include/adafocus.h: adaf_set_global_option -- global state of the library, no handle); returns the
+    previous value."""
     old = get_option(key)
-    h = handle(device if device is not None else torch.cuda.current_device())
-    check(load_library().adaf_set_option(h, key.encode(), float(value)), h)
+    if load_library().adaf_set_global_option(key.encode(), float(value)) != 0:
+        raise AdafError("adaf_set_global_option: %s = %r is out of range" % (key, value))
     return old
 
 

@@ -27,16 +27,66 @@ struct adaf_handle {
     std::string err;
 };
 
-// Process-wide tuning / A-B switches of the library (adaf_set_option / adaf_get_option in include/adafocus.h; defaults = the plan
+// Helper streams for networks that run two frame chunks side by side (adaf_mobilenetv2, adaf_effnet): one (stream, fork event, join event) per
+// CALLER stream, so forwards issued from different streams do not serialise their second chunks on one shared helper.  At most kMax entries:
+// a further caller stream takes over the least recently used entry (round 6; earlier the 17th stream got no helper and stopped pairing -- and
+// entries of destroyed streams were never reused).  An entry is nothing but a helper stream and two events that are re-recorded on every call,
+// so handing it to another caller stream (or to a recycled handle value) is harmless.  Guarded by a mutex: host threads may run the same
+// network on different streams.  prepare() creates a few entries ahead (finalize): the first paired call may then happen under stream capture.
+#include <mutex>
+#include <vector>
+struct AdafAuxPool {
+    struct Aux { hipStream_t key = nullptr; hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; unsigned long long used = 0; };
+    static constexpr size_t kMax = 16;
+    std::vector<Aux> entries;
+    std::mutex mu;
+    unsigned long long tick = 0;
+    AdafAuxPool() { entries.reserve(kMax); }      // (entries never move: callers hold pointers into the vector)
+    bool create(Aux* a) {
+        return hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) == hipSuccess;
+    }
+    void prepare(size_t count) {
+        std::lock_guard<std::mutex> lk(mu);
+        while (entries.size() < count && entries.size() < kMax) {
+            Aux a;
+            if (!create(&a)) return;
+            entries.push_back(a);       // key == nullptr: free
+        }
+    }
+    // the helper of caller stream `st` (nullptr if none could be created)
+    Aux* get(hipStream_t st) {
+        std::lock_guard<std::mutex> lk(mu);
+        Aux* lru = nullptr;
+        for (Aux& a : entries) {
+            if (a.key == st && a.used) { a.used = ++tick; return &a; }
+            if (!lru || a.used < lru->used) lru = &a;
+        }
+        if (entries.size() < kMax && !(lru && lru->used == 0)) {       // no free entry yet: make one
+            Aux a;
+            if (create(&a)) { entries.push_back(a); lru = &entries.back(); }
+        }
+        if (!lru) return nullptr;
+        lru->key = st;
+        lru->used = ++tick;
+        return lru;
+    }
+    void destroy() {
+        for (Aux& a : entries) {
+            if (a.stream) (void)hipStreamDestroy(a.stream);
+            if (a.ev_fork) (void)hipEventDestroy(a.ev_fork);
+            if (a.ev_join) (void)hipEventDestroy(a.ev_join);
+        }
+        entries.clear();
+    }
+};
+
+// Process-wide tuning / A-B switches of the library (adaf_set_global_option / adaf_get_global_option in include/adafocus.h; defaults = the plan
 // every number in DESIGN.md is measured with).  They replace the environment variables of earlier rounds: tests flip them in-process.
 struct AdafOptions {
-    int conv_lean = 1;            // "conv_lean": scalar-base DMA / VALU-free K loops of the conv engine (conv_gemm.hip LEAN kernels)
-    double pm_fill = 0.96;        // "pm_fill": position-major tiles when the tap fill is below this fraction
     int conv_pool = 1;            // "conv_pool": global average pool in the last conv3's epilogue
-    int resize_lds_kb = 20;       // "resize_lds_kb": staged rows per block of the resampling gather
-    int mb_wave = 1;              // "mb_wave": wave-private MBConv kernels of the MobileNetV2 glancer
     int mb_strip = 1;             // "mb_strip": strip-walking forms of the glancer's front kernels (mbstrip.hip, round 6); 0 = the wave-private tiles
-    int dw3_variant = 4;          // "dw3_variant": thread tile of the stand-alone depthwise 3x3 (0: 4x2, 1: 2x2, 2: 4x1, 3: 7x2, 4: 4x4)
     int mbv2_chunk = 512;         // "mbv2_chunk": frames per chunk of the MobileNetV2 forward
     int latency_rows = 1536;      // "latency_rows": GEMM rows up to which a new trunk sends convs to the small-batch form
     int latency_linear_rows = 128;  // "latency_linear_rows": the same for adaf_linear / GRU projections
@@ -45,7 +95,6 @@ struct AdafOptions {
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
     int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)
     int split_stage1_f32 = 1;     // "split_stage1_f32": the split-bf16 trunk takes the fp32 pipe's fused stage-1 launches (api.hip run_trunk)
-    int gru_barrier = 1;          // "gru_barrier": 1 = XCD-hierarchical grid barrier of the persistent GRU scan, 0 = one counter per step
     int gru_graph_persistent = 0; // "gru_graph_persistent": 1 = a stream capture keeps the persistent GRU scan (the caller guarantees exclusive use of the device
                                   // while the graph replays); 0 = captures take the launch-per-step form, which has no grid barrier to starve
     int gru_scan_slices = 2;      // "gru_scan_slices": clip slices a persistent GRU scan may be cut into (1 | 2; gru_scan.hip)

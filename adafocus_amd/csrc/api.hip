@@ -76,16 +76,16 @@ AdafOptions& adaf_options() {
 }
 
 namespace {
-struct OptKey { const char* name; int kind; double lo, hi; };      // kind: index into the switch of opt_ref
-const OptKey kOptKeys[] = {{"conv_lean", 0, 0, 2}, {"pm_fill", 1, 0, 1}, {"conv_pool", 2, 0, 1}, {"resize_lds_kb", 3, 4, 120},
-                           {"mb_wave", 4, 0, 1}, {"dw3_variant", 5, 0, 4}, {"mbv2_chunk", 6, 1, 1 << 20}, {"latency_rows", 7, 0, 1 << 30},
-                           {"latency_linear_rows", 8, 0, 1 << 30}, {"effnet_plan", 9, 0, 511}, {"effnet_chunk", 10, 1, 1 << 20}, {"gru_scan_slices", 11, 1, 2},
-                           {"effnet_fused_blocks", 12, 0, 4294967295.0}, {"stem_rows", 13, 0, 2}, {"split_stage1_f32", 14, 0, 1}, {"gru_barrier", 15, 0, 1}, {"mb_strip", 16, 0, 1}, {"gru_graph_persistent", 17, 0, 1}};
-const OptKey* find_opt(const char* key) {
-    if (!key) return nullptr;
-    for (const OptKey& k : kOptKeys)
-        if (!strcmp(k.name, key)) return &k;
-    return nullptr;
+struct OptKey { const char* name; double lo, hi; };
+// (round 6: the switches that measured as no-gain and had no user are gone -- conv_lean, pm_fill, resize_lds_kb, mb_wave, dw3_variant, gru_barrier)
+const OptKey kOptKeys[] = {{"conv_pool", 0, 1}, {"mb_strip", 0, 1}, {"mbv2_chunk", 1, 1 << 20}, {"latency_rows", 0, 1 << 30}, {"latency_linear_rows", 0, 1 << 30},
+                           {"effnet_plan", 0, 511}, {"effnet_chunk", 1, 1 << 20}, {"gru_scan_slices", 1, 2}, {"effnet_fused_blocks", 0, 4294967295.0},
+                           {"stem_rows", 0, 2}, {"split_stage1_f32", 0, 1}, {"gru_graph_persistent", 0, 1}};
+int find_opt(const char* key) {
+    if (!key) return -1;
+    for (size_t i = 0; i < sizeof(kOptKeys) / sizeof(kOptKeys[0]); ++i)
+        if (!strcmp(kOptKeys[i].name, key)) return (int)i;
+    return -1;
 }
 }  // namespace
 
@@ -145,57 +145,43 @@ int adaf_set_conv_pos_major(adaf_handle* h, int on) {
     h->conv_pos_major = on < 0 || on > 2 ? 1 : on;    // 2: position-major rows WITHOUT tap skipping (experiments)
     return ADAF_OK;
 }
-int adaf_set_option(adaf_handle* h, const char* key, double value) {
-    const OptKey* k = find_opt(key);
-    if (!k) return fail(h, ADAF_E_BADARG, "set_option: unknown key '%s'", key ? key : "(null)");
-    if (!(value >= k->lo && value <= k->hi)) return fail(h, ADAF_E_BADARG, "set_option: %s = %g is outside [%g, %g]", key, value, k->lo, k->hi);
+int adaf_set_global_option(const char* key, double value) {
+    const int k = find_opt(key);
+    if (k < 0 || !(value >= kOptKeys[k].lo && value <= kOptKeys[k].hi)) return ADAF_E_BADARG;
     AdafOptions& o = adaf_options();
-    switch (k->kind) {
-        case 0: o.conv_lean = (int)value; break;
-        case 1: o.pm_fill = value; break;
-        case 2: o.conv_pool = (int)value; break;
-        case 3: o.resize_lds_kb = (int)value; break;
-        case 4: o.mb_wave = (int)value; break;
-        case 5: o.dw3_variant = (int)value; break;
-        case 6: o.mbv2_chunk = (int)value; break;
-        case 7: o.latency_rows = (int)value; break;
-        case 8: o.latency_linear_rows = (int)value; break;
-        case 9: o.effnet_plan = (unsigned)value; break;
-        case 11: o.gru_scan_slices = (int)value; break;
-        case 12: o.effnet_fused_blocks = (unsigned)value; break;
-        case 13: o.stem_rows = (int)value; break;
-        case 14: o.split_stage1_f32 = (int)value; break;
-        case 15: o.gru_barrier = (int)value; break;
-        case 16: o.mb_strip = (int)value; break;
-        case 17: o.gru_graph_persistent = (int)value; break;
-        default: o.effnet_chunk = (int)value; break;
+    switch (k) {
+        case 0: o.conv_pool = (int)value; break;
+        case 1: o.mb_strip = (int)value; break;
+        case 2: o.mbv2_chunk = (int)value; break;
+        case 3: o.latency_rows = (int)value; break;
+        case 4: o.latency_linear_rows = (int)value; break;
+        case 5: o.effnet_plan = (unsigned)value; break;
+        case 6: o.effnet_chunk = (int)value; break;
+        case 7: o.gru_scan_slices = (int)value; break;
+        case 8: o.effnet_fused_blocks = (unsigned)value; break;
+        case 9: o.stem_rows = (int)value; break;
+        case 10: o.split_stage1_f32 = (int)value; break;
+        default: o.gru_graph_persistent = (int)value; break;
     }
     return ADAF_OK;
 }
 
-double adaf_get_option(const char* key) {
-    const OptKey* k = find_opt(key);
-    if (!k) return __builtin_nan("");
+double adaf_get_global_option(const char* key) {
     const AdafOptions& o = adaf_options();
-    switch (k->kind) {
-        case 0: return o.conv_lean;
-        case 1: return o.pm_fill;
-        case 2: return o.conv_pool;
-        case 3: return o.resize_lds_kb;
-        case 4: return o.mb_wave;
-        case 5: return o.dw3_variant;
-        case 6: return o.mbv2_chunk;
-        case 7: return o.latency_rows;
-        case 8: return o.latency_linear_rows;
-        case 9: return o.effnet_plan;
-        case 11: return o.gru_scan_slices;
-        case 12: return o.effnet_fused_blocks;
-        case 13: return o.stem_rows;
-        case 14: return o.split_stage1_f32;
-        case 15: return o.gru_barrier;
-        case 16: return o.mb_strip;
-        case 17: return o.gru_graph_persistent;
-        default: return o.effnet_chunk;
+    switch (find_opt(key)) {
+        case 0: return o.conv_pool;
+        case 1: return o.mb_strip;
+        case 2: return o.mbv2_chunk;
+        case 3: return o.latency_rows;
+        case 4: return o.latency_linear_rows;
+        case 5: return o.effnet_plan;
+        case 6: return o.effnet_chunk;
+        case 7: return o.gru_scan_slices;
+        case 8: return o.effnet_fused_blocks;
+        case 9: return o.stem_rows;
+        case 10: return o.split_stage1_f32;
+        case 11: return o.gru_graph_persistent;
+        default: return __builtin_nan("");
     }
 }
 
@@ -920,7 +906,9 @@ int adaf_resnet50_forward_frames(adaf_resnet50* net, const float* frames, int fr
     if (n_frames % frames_per_action) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: n_frames %% frames_per_action != 0");
     const int per_set = n_frames / frames_per_action;
     if (n_actions % per_set) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: n_actions=%d is not a multiple of n_frames / frames_per_action=%d", n_actions, per_set);
-    if (height != width) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: square frames only (get_patch scales both axes by H - P)");
+    // (get_patch takes its size from the frames' HEIGHT and scales both axes by H - P, ACT/models/utils.py:40-42: frames wider than high work as in
+    //  adaf_crop_gather_f32 -- x is clamped to W - P; narrower ones would read past a row)
+    if (width < height) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: width %d < height %d (get_patch scales both axes by H - P)", width, height);
     if (patch > height || patch < 32) return fail(h, ADAF_E_BADARG, "resnet50 forward_frames: patch %d outside [32, %d]", patch, height);
     if (!aligned16(frames)) return fail(h, ADAF_E_LAYOUT, "resnet50 forward_frames: frames must be 16-byte aligned");
     FrameSrc src{frames, frames_layout == ADAF_LAYOUT_NHWC4, n_frames, height, width, action_yx, frames_per_action};

@@ -1581,8 +1581,9 @@ struct TileShape { int bm, bn; float eff; };
 const TileShape kTiles[ADAF_CONV_TILES + 1] = {
     {0, 0, 0.f}, {128, 128, 1.00f}, {128, 64, 1.02f}, {64, 64, 0.98f}, {64, 128, 0.99f}};
 
-// option "conv_lean": 0 keeps the builtin-DMA K loop and the general epilogue (A/B measurements); 2 = lean forms for position-major tiles only
-static int conv_lean_enabled() { return adaf_options().conv_lean; }
+// (the lean K loop / epilogue forms were an option, "conv_lean", while they were measured against the forms they replace -- tools/lean_ab.py, rounds 3-5;
+//  the general forms remain as the fallback for operands beyond the scalar-base DMA's 4 GB reach and for edge tiles)
+static constexpr int conv_lean_enabled() { return 1; }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int FLAGS>
 void launch_cfg(ConvArgs a, bool dense, hipStream_t s) {
@@ -1629,8 +1630,8 @@ static double conv_tap_fill(const ConvArgs& a) {
     return (double)(axis(a.OH, a.H, a.KH) * axis(a.OW, a.W, a.KW)) / ((double)a.OH * a.OW * a.KH * a.KW);
 }
 
-// position-major tiles are used when less than this share of the filter taps touches the image (option "pm_fill", experiments)
-static double conv_pm_fill_threshold() { return adaf_options().pm_fill; }
+// position-major tiles are used when less than this share of the filter taps touches the image
+static constexpr double conv_pm_fill_threshold() { return 0.96; }
 
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EMU = 0, bool BSP = false>
 void launch_glds(ConvArgs a, bool dense, hipStream_t s) {

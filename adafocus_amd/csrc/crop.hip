@@ -362,7 +362,7 @@ static hipError_t launch_resize_mode(const float* frames, int nf, int C, int H, 
                                      int size_default, int fpa, int P, float* out, int32_t* coords, hipStream_t s) {
     const int smax = sizes ? H : (size_default < H ? size_default : H);
     size_t lds = 0;
-    const size_t budget = (size_t)adaf_options().resize_lds_kb * 1024;
+    const size_t budget = (size_t)20 * 1024;      // staged rows per block of the resampling gather
     // (20 KB of staged source rows per block: measured against 12 / 32 / 60 KB on 1024 frames -- 3.5 / 3.8 / 3.4 TB/s at S = 128 / 192 /
     // mixed vs 3.1 / 2.2 / 1.9 with 60 KB: seven resident blocks per CU hide each other's load -> interpolate -> store phases)
     const int rbr = resize_rows_per_block(IN4 ? 4 : C, smax, P, budget, &lds);

@@ -1889,8 +1889,7 @@ struct adaf_effnet {
     // Two patch chunks travel through the network side by side (ADAF_EF_PLAN_PAIR_CHUNKS; the second on a library-owned stream forked from
     // and joined to the caller's stream by events, one helper per caller stream -- as adaf_mobilenetv2 does): the launches of the 9 x 9 and
     // 5 x 5 stages, the SE gates and every launch's ramp and tail leave room that a neighbour fills.
-    struct Aux { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
-    std::map<hipStream_t, Aux> aux;
+    AdafAuxPool aux;        // (adaf_internal.h: LRU over caller streams, mutex-guarded)
     // Every derived weight buffer (packed filters, folded BN, SE matrices, B fragments) is carved out of a few large slabs: a
     // launch of the whole-block kernel reads ~14 of them, and as separate small hipMalloc()s each sat in pages of its own.
     std::vector<void*> slabs;
@@ -2059,11 +2058,7 @@ int adaf_effnet_create(adaf_handle* h, float width_coefficient, float depth_coef
 int adaf_effnet_destroy(adaf_effnet* net) {
     if (!net) return ADAF_OK;
     for (void* p : net->slabs) (void)hipFree(p);
-    for (auto& kv : net->aux) {
-        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
-        if (kv.second.ev_fork) (void)hipEventDestroy(kv.second.ev_fork);
-        if (kv.second.ev_join) (void)hipEventDestroy(kv.second.ev_join);
-    }
+    net->aux.destroy();
     delete net;
     return ADAF_OK;
 }
@@ -2222,6 +2217,7 @@ int adaf_effnet_finalize(adaf_effnet* net, void* stream) {
     }
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return efail(h, ADAF_E_LAUNCH, "effnet finalize: %s", hipGetErrorString(e));
+    net->aux.prepare(4);        // helper streams exist before the first forward (which may be captured into a HIP graph)
     net->finalized = true;
     return ADAF_OK;
 }
@@ -2362,18 +2358,8 @@ int adaf_effnet_forward(adaf_effnet* net, const float* frames_nhwc4, int n, int 
         }
         return ADAF_OK;
     };
-    // (a 17th caller stream gets no helper: its chunks simply follow one another on its own stream -- same results)
-    const bool pair = (adaf_options().effnet_plan & ADAF_EF_PLAN_PAIR_CHUNKS) != 0 && n > chunk && (net->aux.count(st) || net->aux.size() < 16);
-    adaf_effnet::Aux* ax = nullptr;
-    if (pair) {
-        ax = &net->aux[st];
-        if (!ax->stream) {
-            if (hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ax->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ax->ev_join, hipEventDisableTiming) != hipSuccess)
-                return efail(h, ADAF_E_NOMEM, "effnet: could not create the second-chunk stream");
-        }
-    }
+    AdafAuxPool::Aux* ax = ((adaf_options().effnet_plan & ADAF_EF_PLAN_PAIR_CHUNKS) != 0 && n > chunk) ? net->aux.get(st) : nullptr;
+    const bool pair = ax != nullptr;
     char* base0 = static_cast<char*>(ws);
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int nc = (n - f0) < chunk ? (n - f0) : chunk;

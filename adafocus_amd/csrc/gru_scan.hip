@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     const unsigned members = (unsigned)((NBLK + 7 - g8) >> 3);
                     const unsigned old = __hip_atomic_fetch_add(rec + (1 + g8) * a.bpad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (old == members - 1u) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        // acquire + release: the other members' writes (ordered before their relaxed arrival by their own release fences) must
+                        // happen-before this leader's arrival on the top counter, which is what the other groups' leaders synchronise with
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                         __hip_atomic_fetch_add(rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         while (__hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(NBLK < 8 ? NBLK : 8)) {
                             __builtin_amdgcn_s_sleep(1);
@@ -272,9 +274,9 @@ hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, co
     if (groups > 1 && (size_t)groups * (steps + 1) > bar_words) groups = 1;
     if ((size_t)(steps + 1) > bar_words) return hipErrorInvalidValue;
     // XCD-hierarchical barrier records (17 words per step) at a pitch of 16 words (64 bytes) when the buffer has the room, packed
-    // otherwise, the single counter per step when even that does not fit (option "gru_barrier" = 0: always the single counter)
+    // otherwise, the single counter per step when even that does not fit
     const size_t recs = (size_t)(groups < 1 ? 1 : groups) * (steps + 1) * 17;
-    const int bpad = !adaf_options().gru_barrier ? 0 : recs * 16 <= bar_words ? 16 : recs <= bar_words ? 1 : 0;
+    const int bpad = recs * 16 <= bar_words ? 16 : recs <= bar_words ? 1 : 0;
     const size_t nzero = bpad ? recs * bpad : (size_t)(groups < 1 ? 1 : groups) * (steps + 1);
     GruScanArgs a;
     a.bpad = bpad;

@@ -860,11 +860,9 @@ static void launch_expand_dw_w(MbFuseArgs a, hipStream_t s) {
     hipLaunchKernelGGL((mb_expand_dw_w_kernel<S, CIN>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
 }
 
-// ADAF_MB_WAVE=0 keeps the block-cooperative kernel (A/B measurements)
-static bool mb_wave_enabled() {
-    const bool on = adaf_options().mb_wave != 0;
-    return on;
-}
+// (the wave-private kernels were an option, "mb_wave", while they were measured against the block-cooperative ones, rounds 2-5; the latter remain
+//  as the fallback for hidden widths beyond the LDS-resident tap table)
+static constexpr bool mb_wave_enabled() { return true; }
 
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s) {
     if (mb_wave_enabled() && a.hid <= 192) {

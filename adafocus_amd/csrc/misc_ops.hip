@@ -371,16 +371,11 @@ void adaf_launch_dwconv3x3(const float* x, int n, int h, int w, int c, int strid
     const float lo = act == ADAF_ACT_NONE ? -__builtin_inff() : 0.f;
     const float hi = act == ADAF_ACT_RELU6 ? 6.f : __builtin_inff();
     // thread tile at stride 1: 4 x 4 outputs share 6 x 6 input chunks (2.25 loads per output; measured on the glancer's maps at
-    // 512 frames: 4x2 (3 loads per output, round 2's shape, still selectable with ADAF_DW3_VARIANT=0) 3.7-4.4 TB/s, 2x2 3.2-4.2, 4x1 3.0-3.6, 7x2 3.8-4.5,
+    // 512 frames: 4x2 (3 loads per output, round 2's shape) 3.7-4.4 TB/s, 2x2 3.2-4.2, 4x1 3.0-3.6, 7x2 3.8-4.5,
     // 4x4 4.3-4.9 -- fewer, fatter threads with 36 independent loads in flight each win although 14 = 3.5 x 4 wastes an eighth of them)
-    const int var = adaf_options().dw3_variant;
-    if (stride == 1 && var == 4) {
+    if (stride == 1) {
         const long long total = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4) * (c / 4);
         hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 4>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt, scale, bias, lo, hi, o);
-    } else if (stride == 1) {   // 4 x 2 outputs share 6 input columns x 4 input rows (24 loads for 8 outputs instead of 36)
-        const long long total = (long long)n * ((oh + 1) / 2) * ((ow + 3) / 4) * (c / 4);
-        hipLaunchKernelGGL((dwconv3x3_kernel<4, 1, 2>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,
-                           scale, bias, lo, hi, o);
     } else {             // 2 outputs share 5 input columns (more would spill the tap registers)
         const long long total = (long long)n * oh * ((ow + 1) / 2) * (c / 4);
         hipLaunchKernelGGL((dwconv3x3_kernel<2, 2, 1>), dim3(blocks_for(total)), dim3(256), 0, s, x, n, h, w, c / 4, oh, ow, wt,

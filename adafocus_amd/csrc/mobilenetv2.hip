@@ -20,7 +20,6 @@ struct MbConv {
     int cin, cout, k, stride, groups;
     int cin_pad;
     float* w = nullptr;
-    void* w16 = nullptr;   // the same filter bank in fp16 (dense convs, ADAF_DTYPE_F16 mode)
     float* scale = nullptr;
     float* bias = nullptr;
 };
@@ -38,15 +37,13 @@ struct adaf_mobilenetv2 {
     int stem = 0, head = 0;
     bool fuse = true;       // expand -> depthwise in one kernel where the shape allows (mbconv.hip)
     bool whole = true;      // ... and the whole stride-1 block (expand -> depthwise -> project + identity) where that shape allows
-    int dtype = ADAF_DTYPE_F32;   // storage type of activations and 1x1 weights
     bool finalized = false;
     // Two frame chunks travel through the network side by side (the second on this library-owned stream, forked from and
     // joined to the caller's stream by events -- still fully asynchronous): the tail's launches are 30-100 us each and
     // leave the device half empty on their own; a neighbour fills the ramps and tails.
     // One helper stream + event pair PER CALLER STREAM: forwards issued from different streams (pipelined batches,
     // bench --streams) must not serialise their second chunks on one shared helper.
-    struct Aux { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
-    std::map<hipStream_t, Aux> aux;
+    AdafAuxPool aux;        // (adaf_internal.h: LRU over caller streams, mutex-guarded)
     bool pair = true;
 };
 
@@ -149,23 +146,6 @@ int run_conv(adaf_mobilenetv2* net, const MbConv& L, const float* in, int n, int
     return adaf_launch_conv_gemm(a, 0, net->h->cus, st) > 0 ? ADAF_OK : ADAF_E_LAUNCH;
 }
 
-// half-precision storage: in16 -> fp16 x / w (L.w16), else the fp32 operands with an fp16 store (stem); out16 selects the store
-int run_conv16(adaf_mobilenetv2* net, const MbConv& L, const void* in, bool in16, int n, int hh, int ww, int act, const void* res16,
-               void* out, bool out16, hipStream_t st) {
-    ConvArgs a;
-    memset(&a, 0, sizeof(a));
-    const int oh = cdiv_out(hh, L.k, L.stride, L.k / 2), ow = cdiv_out(ww, L.k, L.stride, L.k / 2);
-    a.x = static_cast<const float*>(in); a.w = in16 ? static_cast<const float*>(L.w16) : L.w;
-    a.scale = L.scale; a.bias = L.bias; a.res = static_cast<const float*>(res16); a.out = static_cast<float*>(out);
-    a.M = n * oh * ow; a.N = L.cout; a.K = L.k * L.k * L.cin_pad;
-    a.cin = L.cin_pad; a.H = hh; a.W = ww; a.OH = oh; a.OW = ow; a.KH = a.KW = L.k; a.stride = L.stride; a.pad = L.k / 2;
-    a.ldx = L.cin_pad; a.ldo = L.cout; a.ldr = L.cout; a.act = act;
-    a.zeros = net->h->zeros;
-    a.vec_epi = (L.cout % 4 == 0) ? 1 : 0;
-    a.in16 = in16; a.out16 = out16; a.res16 = res16 != nullptr;
-    return adaf_launch_conv_gemm(a, 0, net->h->cus, st) > 0 ? ADAF_OK : ADAF_E_LAUNCH;
-}
-
 }  // namespace
 
 extern "C" {
@@ -181,14 +161,9 @@ int adaf_mobilenetv2_create(adaf_handle* h, adaf_mobilenetv2** out) {
 
 int adaf_mobilenetv2_destroy(adaf_mobilenetv2* net) {
     if (!net) return ADAF_OK;
-    for (auto& kv : net->aux) {
-        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
-        if (kv.second.ev_fork) (void)hipEventDestroy(kv.second.ev_fork);
-        if (kv.second.ev_join) (void)hipEventDestroy(kv.second.ev_join);
-    }
+    net->aux.destroy();
     for (auto& L : net->convs) {
         if (L.w) (void)hipFree(L.w);
-        if (L.w16) (void)hipFree(L.w16);
         if (L.scale) (void)hipFree(L.scale);
         if (L.bias) (void)hipFree(L.bias);
     }
@@ -201,14 +176,6 @@ int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on) {
     net->fuse = (on & 1) != 0;
     net->pair = (on & 4) == 0;     // bit 2 set: one frame chunk at a time (A/B)
     net->whole = (on & 8) == 0;    // bit 3 set: expand -> depthwise kernel + project launch instead of the whole-block kernel (A/B)
-    return ADAF_OK;
-}
-
-int adaf_mobilenetv2_set_dtype(adaf_mobilenetv2* net, int dtype) {
-    if (!net) return ADAF_E_BADARG;
-    if (dtype != ADAF_DTYPE_F32 && dtype != ADAF_DTYPE_F16) return mfail(net->h, ADAF_E_BADARG, "mobilenetv2: unknown dtype %d", dtype);
-    if (dtype != net->dtype) net->finalized = false;
-    net->dtype = dtype;
     return ADAF_OK;
 }
 
@@ -247,14 +214,11 @@ int adaf_mobilenetv2_finalize(adaf_mobilenetv2* net, void* stream) {
         if (!L.bias && hipMalloc(reinterpret_cast<void**>(&L.bias), L.cout * sizeof(float)) != hipSuccess) return mfail(h, ADAF_E_NOMEM, "mobilenetv2: hipMalloc");
         if (dw) adaf_launch_pack_dw_weight(w, L.cout, L.w, st);
         else adaf_launch_pack_weight(w, L.cout, L.cin, L.k, L.k, L.cin_pad, L.w, st);
-        if (!dw && L.k == 1 && net->dtype == ADAF_DTYPE_F16) {
-            if (!L.w16 && hipMalloc(&L.w16, wn * sizeof(unsigned short)) != hipSuccess) return mfail(h, ADAF_E_NOMEM, "mobilenetv2: hipMalloc");
-            adaf_launch_pack_weight_f16(w, L.cout, L.cin, 1, 1, L.cin_pad, L.w16, st);
-        }
         adaf_launch_fold_bn(g, b, m, v, 1e-5f, L.cout, L.scale, L.bias, st);
     }
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return mfail(h, ADAF_E_LAUNCH, "mobilenetv2 finalize: %s", hipGetErrorString(e));
+    net->aux.prepare(4);        // helper streams exist before the first forward (which may be captured into a HIP graph)
     net->finalized = true;
     return ADAF_OK;
 }
@@ -286,45 +250,6 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
     float* bufB = bufA + (size_t)chunk * io;
     float* bufE = bufB + (size_t)chunk * io;
     float* bufD = bufE + (size_t)chunk * ex;
-
-    if (net->dtype == ADAF_DTYPE_F16) {
-        // ---- half-precision storage: same launch plan, unfused, buffers hold fp16 (the byte budget above is generous)
-        if (tsm_segments > 0) return mfail(h, ADAF_E_BADARG, "mobilenetv2: the fp16 mode has no temporal shift");
-        for (int f0 = 0; f0 < n; f0 += chunk) {
-            const int nc = (n - f0) < chunk ? (n - f0) : chunk;
-            int hw = cdiv_out(size, 3, 2, 1);
-            int rc;
-            void* cur = bufA;
-            void* nxt = bufB;
-            if ((rc = run_conv16(net, net->convs[net->stem], frames_nhwc4 + (size_t)f0 * size * size * 4, false, nc, size, size,
-                                 ADAF_ACT_RELU6, nullptr, cur, true, st)))
-                return mfail(h, rc, "mobilenetv2: stem launch (fp16 store)");
-            for (const MbBlock& b : net->blocks) {
-                const int hid = b.inp * b.t;
-                const bool residual = b.stride == 1 && b.inp == b.oup;
-                const void* dw_in = cur;
-                if (b.expand >= 0) {
-                    if ((rc = run_conv16(net, net->convs[b.expand], cur, true, nc, hw, hw, ADAF_ACT_RELU6, nullptr, bufE, true, st)))
-                        return mfail(h, rc, "mobilenetv2: expand launch (fp16)");
-                    dw_in = bufE;
-                }
-                const MbConv& D = net->convs[b.dw];
-                adaf_launch_dwconv3x3_f16(dw_in, nc, hw, hw, hid, b.stride, D.w, D.scale, D.bias, ADAF_ACT_RELU6, bufD, st);
-                const int ohw = cdiv_out(hw, 3, b.stride, 1);
-                if ((rc = run_conv16(net, net->convs[b.project], bufD, true, nc, ohw, ohw, ADAF_ACT_NONE, residual ? cur : nullptr, nxt,
-                                     true, st)))
-                    return mfail(h, rc, "mobilenetv2: project launch (fp16)");
-                void* t = cur; cur = nxt; nxt = t;
-                hw = ohw;
-            }
-            float* fm = featmap + (size_t)f0 * hw * hw * 1280;
-            if ((rc = run_conv16(net, net->convs[net->head], cur, true, nc, hw, hw, ADAF_ACT_RELU6, nullptr, fm, false, st)))
-                return mfail(h, rc, "mobilenetv2: head launch (fp16 operands, fp32 store)");
-            if (featvec) adaf_launch_avgpool(fm, nc, hw * hw, 1280, featvec + (size_t)f0 * ldvec, ldvec, st);
-        }
-        hipError_t e16 = hipGetLastError();
-        return e16 == hipSuccess ? ADAF_OK : mfail(h, ADAF_E_LAUNCH, "mobilenetv2 forward (fp16): %s", hipGetErrorString(e16));
-    }
 
     // one chunk of frames through the whole network on stream `st` with its own quarter of the workspace
     auto run_chunk = [&](int f0, int nc, float* bufA, float* bufB, float* bufE, float* bufD, hipStream_t st) -> int {
@@ -408,18 +333,8 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
         return ADAF_OK;
     };
     const size_t per_chunk = (size_t)chunk * (2 * io + ex + dws);
-    // (a 17th caller stream gets no helper: its chunks follow one another on its own stream -- same results)
-    const bool pair = net->pair && n > chunk && (net->aux.count(st) || net->aux.size() < 16);
-    adaf_mobilenetv2::Aux* ax = nullptr;
-    if (pair) {
-        ax = &net->aux[st];
-        if (!ax->stream) {
-            if (hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ax->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ax->ev_join, hipEventDisableTiming) != hipSuccess)
-                return mfail(h, ADAF_E_NOMEM, "mobilenetv2: could not create the second-chunk stream");
-        }
-    }
+    AdafAuxPool::Aux* ax = (net->pair && n > chunk) ? net->aux.get(st) : nullptr;
+    const bool pair = ax != nullptr;
     float* base2 = static_cast<float*>(ws) + per_chunk;
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int nc = (n - f0) < chunk ? (n - f0) : chunk;

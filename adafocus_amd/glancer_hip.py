@@ -63,7 +63,6 @@ class GlancerEngine:
         self._net, self._sig = None, None
         self.fusion = True      # expand -> depthwise fused where the shape allows (adaf_mobilenetv2_set_fusion)
         self.fused_tail = False  # whole inverted-residual blocks of the 14^2 / 7^2 maps in one kernel (not built)
-        self.dtype = "f32"       # "f16": half-precision storage of activations and 1x1 weights (N2)
 
     def sync(self):
         sd = {k: v for k, v in self.module.state_dict().items()
@@ -71,11 +70,10 @@ class GlancerEngine:
         dev = next(iter(sd.values())).device
         if dev.type != "cuda":
             raise RuntimeError("adafocus_amd glancer runs on MI355X only; move the module to the GPU (.cuda())")
-        sig = tuple((v.data_ptr(), v._version) for v in sd.values()) + (self.dtype,)
+        sig = tuple((v.data_ptr(), v._version) for v in sd.values())
         if self._net is None or self._net.device != dev or sig != self._sig:
             if self._net is None or self._net.device != dev:
                 self._net = hip_ops.MobileNetV2Net(dev)
-            self._net.set_dtype(self.dtype)
             self._net.load(neutral_params(sd, self.variant))
             self._sig = sig
         self._net.set_fusion(self.fusion)

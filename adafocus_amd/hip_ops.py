@@ -483,12 +483,6 @@ class MobileNetV2Net:
         # expand -> depthwise kernel + project launch instead of the whole-block kernel of b3 / b5 / b6 (A/B switches)
         L.check(self._lib.adaf_mobilenetv2_set_fusion(self._net, int(on)), self._h)
 
-    def set_dtype(self, dtype):
-        """"f32" (default) or "f16": activations and 1x1 weights stored as fp16, fp32 accumulate (include/adafocus.h N2).
-        Call before load()."""
-        code = {"f32": DTYPE_F32, "f16": DTYPE_F16}.get(dtype, dtype)
-        L.check(self._lib.adaf_mobilenetv2_set_dtype(self._net, int(code)), self._h)
-
     def forward(self, frames_nhwc4, tsm_segments=0, tsm_div=8, want_vec=True):
         """(N,S,S,4) -> featmap (N,S/32,S/32,1280) NHWC, featvec (N,1280) or None."""
         L.need_gpu_f32(frames_nhwc4)

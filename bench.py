@@ -919,7 +919,6 @@ def main():
         if world == 1 and not a.skip_extras:
             eargs = act_args(t, p, b)
             extra("next_rows", "evaluate_loop", lambda: X.evaluate_loop_row(dev, model, eargs, b, t))
-            extra("also", "glancer_f16_storage", lambda: X.glancer_f16_row(dev, model, b, t, streams))
             extra("also", "validate_sth_loop_T8_P128", lambda: X.validate_sth_row(dev, b))
             extra("also", "sth_shipped_T8_12_P144", lambda: X.sth_shipped_row(dev, b, streams))
         if world == 1 and not a.skip_extras and (t, p) == (16, 96):

@@ -341,88 +341,6 @@ def _events_ms(fn, iters=5, warm=3):
     return e0.elapsed_time(e1) / iters, out
 
 
-def glancer_f16_row(dev, model, b, t, streams):
-    """Rows a10 / f2: the glancer with fp16 STORAGE of activations and 1x1 weights (adaf_mobilenetv2_set_dtype: MFMA products on the
-    f16 pipe with fp32 accumulation, depthwise taps in fp32 from fp16 maps) -- what the switch buys (ms per B*T frames) and what it
-    costs end to end on BASELINE config 1 / the headline (ActivityNet model: how many of the policy's arg-max choices survive, max |dlogit|)
-    and config 4 (Something-Something: crop origin shift in pixels, max |dlogit|).  Random-init weights amplify a perturbation ~1000x
-    through the 52 layers (tests/test_hip_parity_r2.py::test_mobilenetv2_f16_storage_vs_g5_golden), so the cost shown is a worst case."""
-    from adafocus_amd import synth
-    from adafocus_amd.gfv_net_sth import GFV as GFV_STH
-    from adafocus_amd.transforms import ingest_uint8
-    out = {}
-    eng = model.glancer.net._engine
-    u8 = torch.randint(0, 256, (b, 224, 224, t * 3), device=dev, dtype=torch.uint8)
-    with torch.no_grad():
-        fr4 = ingest_uint8(u8, t)
-        ms32, _ = _events_ms(lambda: model.glancer.net.features_from_nhwc4(fr4), 3)
-        lg32, _, _, idx32 = [v.clone() if torch.is_tensor(v) else v for v in model.offline_forward_nhwc4(fr4, b, t)]
-        full32, _ = _events_ms(lambda: model.offline_forward_nhwc4(fr4, b, t), 3)
-        eng.dtype = "f16"
-        try:
-            ms16, _ = _events_ms(lambda: model.glancer.net.features_from_nhwc4(fr4), 3)
-            lg16, _, _, idx16 = [v.clone() if torch.is_tensor(v) else v for v in model.offline_forward_nhwc4(fr4, b, t)]
-            full16, _ = _events_ms(lambda: model.offline_forward_nhwc4(fr4, b, t), 3)
-        finally:
-            eng.dtype = "f32"
-            model.glancer.net.features_from_nhwc4(fr4[:t])            # re-sync the fp32 plan
-    same = (idx16 == idx32)
-    clip_same = same.view(b, t).all(1)
-    lg32v, lg16v = lg32.view(b, t, -1), lg16.view(b, t, -1)
-    out["act_T%d_P%d" % (t, model.patch_size)] = {
-        "glancer_ms_f32": round(ms32, 3), "glancer_ms_f16_storage": round(ms16, 3), "speedup": round(ms32 / ms16, 3),
-        "full_forward_clips_per_s_f32": round(b / full32 * 1e3, 1), "full_forward_clips_per_s_f16_glancer": round(b / full16 * 1e3, 1),
-        "policy_argmax_agreement": round(float(same.float().mean()), 4), "clips_with_all_actions_equal": int(clip_same.sum()),
-        "max_abs_logit_diff": float((lg16 - lg32).abs().max()),
-        "max_abs_logit_diff_clips_with_equal_actions": float((lg16v[clip_same] - lg32v[clip_same]).abs().max()) if bool(clip_same.any()) else None,
-        "logit_scale": float(lg32.abs().max())}
-    del u8, fr4
-    out["note"] = ("adaf_mobilenetv2_set_dtype(f16): activations and 1x1 weights stored in fp16 (fp32 accumulation, fp32 depthwise arithmetic); the "
-                   "local CNN, policy and classifier stay fp32.  Random-init weights: a worst case for the cost columns (DESIGN 3.4)")
-    try:
-        out["sth_T8_P128"] = _glancer_f16_sth(dev, b)
-    except Exception as exc:      # the fp16 plan has no temporal shift (csrc/mobilenetv2.hip): say so instead of losing the ActivityNet row
-        out["sth_T8_P128"] = {"unsupported": repr(exc)[:200]}
-    return out
-
-
-def _glancer_f16_sth(dev, b):
-    from adafocus_amd.gfv_net_sth import GFV as GFV_STH
-    from adafocus_amd.transforms import ingest_uint8
-    out = {}
-    # config 4: Something-Something (TSM glancer, continuous policy; the glancer's logits are ADDED to the output)
-    a = sth_args(b, 8, 128)
-    m = GFV_STH(a).eval()
-    m.focuser.net.base_model = torch.nn.Sequential(*list(m.focuser.net.base_model.children())[:-1])
-    m.load_state_dict(synth_model_state(m, 1007), strict=True)
-    m = m.to(dev)
-    gu = torch.randint(0, 256, (b, 224, 224, 24), dtype=torch.uint8, device=dev)
-    fu = torch.randint(0, 256, (b, 224, 224, 24), dtype=torch.uint8, device=dev)
-
-    def fwd():
-        g4 = ingest_uint8(gu, 8, m.input_mean, m.input_std)
-        f4 = ingest_uint8(fu, 8, m.input_mean, m.input_std)
-        fm4, glog = m.glance_nhwc4(g4, b)
-        act = m.focuser.policy.policy_old.act_nhwc(fm4, b, 8)
-        return m.action_stage2_nhwc4(f4, fm4, glog, 0, a, with_baseline=False)[0], act
-    with torch.no_grad():
-        g4 = ingest_uint8(gu, 8, m.input_mean, m.input_std)
-        s32, _ = _events_ms(lambda: m.glance_nhwc4(g4, b), 3)
-        p32, a32 = [v.clone() for v in fwd()]
-        m.glancer.net._engine.dtype = "f16"
-        s16, _ = _events_ms(lambda: m.glance_nhwc4(g4, b), 3)
-        p16, a16 = [v.clone() for v in fwd()]
-        m.glancer.net._engine.dtype = "f32"
-    px = ((a16 - a32).abs() * (224 - 128))
-    same_origin = (torch.floor(a16 * 96) == torch.floor(a32 * 96)).all(1)
-    out["sth_T8_P128"] = {"glancer_ms_f32": round(s32, 3), "glancer_ms_f16_storage": round(s16, 3), "speedup": round(s32 / s16, 3),
-                          "max_action_shift_px": float(px.max()), "clips_with_equal_crop_origin": int(same_origin.sum()), "clips": b,
-                          "max_abs_logit_diff": float((p16 - p32).abs().max()),
-                          "max_abs_logit_diff_clips_with_equal_origin": float((p16[same_origin] - p32[same_origin]).abs().max()) if bool(same_origin.any()) else None,
-                          "logit_scale": float(p32.abs().max())}
-    return out["sth_T8_P128"]
-
-
 def split_bf16_row(dev, model, frames, gvec, actions, b, t, p, streams, steps, step_fn):
     """`also.split_bf16`: the SAME hot path with the local CNN's convolutions on the bf16 matrix pipe -- every fp32 operand split
     exactly into three bf16 parts, the six products of magnitude >= 2^-24 |xy| accumulated in fp32 (ADAF_MATH_F32_SPLIT_BF16;

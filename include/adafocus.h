@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ADAF_VERSION 302
+#define ADAF_VERSION 303
 
 enum {
     ADAF_OK = 0,
@@ -72,13 +72,16 @@ int adaf_gru_scan_timeouts(adaf_handle* h, unsigned* count_out);
  * multiply zero padding are skipped for the whole tile (40 % of the products of a 3x3 conv on a 3x3 map, 21 % on 6x6).
  * Bit-identical to the row-major tiles (a skipped slice contributes exact zeros).  Default on; off for A/B and tests. */
 int adaf_set_conv_pos_major(adaf_handle* h, int on);
-/* Process-wide tuning / A-B switches (they replace the ADAF_* environment variables of earlier rounds; the defaults are the plan
- * every reported number is measured with, INTEGRATION.md lists them).  Keys:
- *   "conv_lean" 0|1, "pm_fill" 0..1, "conv_pool" 0|1, "resize_lds_kb", "mb_wave" 0|1, "dw3_variant" 0..4, "mbv2_chunk",
- *   "latency_rows", "latency_linear_rows", "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk", "gru_scan_slices" 1|2,
- *   "effnet_fused_blocks" (bit b = MBConv block b may use the fused expand + depthwise launch).
- * adaf_set_option returns ADAF_E_BADARG for an unknown key or a value out of range; adaf_get_option returns the current value
- * (NaN for an unknown key).  Not thread-safe against concurrent launches: set options between forwards. */
+/* Process-wide tuning / A-B switches: GLOBAL state of the library (not of a handle: the kernels' launchers read them), hence no handle in the
+ * signature.  The defaults are the plan every reported number is measured with; INTEGRATION.md lists them.  Keys:
+ *   "conv_pool" 0|1, "mb_strip" 0|1 (strip-walking front kernels of the glancer), "mbv2_chunk", "latency_rows", "latency_linear_rows",
+ *   "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk", "gru_scan_slices" 1|2, "effnet_fused_blocks" (bit b = MBConv block b may use the fused
+ *   expand + depthwise launch), "stem_rows" 0|1|2, "split_stage1_f32" 0|1 (see adaf_resnet50_set_math), "gru_graph_persistent" 0|1 (1 = a
+ *   stream capture keeps the persistent GRU scan; default 0: captured scans take the launch-per-step form, which has no grid barrier).
+ * adaf_set_global_option returns ADAF_E_BADARG for an unknown key or a value out of range; adaf_get_global_option returns the current value
+ * (NaN for an unknown key).  Not thread-safe against concurrent launches: set options between forwards.
+ * (Round 6 removed the switches that had measured as no-gain and had no user: conv_lean, pm_fill, resize_lds_kb, mb_wave, dw3_variant,
+ *  gru_barrier, and adaf_mobilenetv2_set_dtype.) */
 enum {
     ADAF_EF_PLAN_WHOLE_BLOCK = 1,    /* whole-image MBConv kernels where a block is eligible (see adaf_effnet_set_fusion) */
     ADAF_EF_PLAN_TINY_DW = 2,        /* register-resident depthwise kernel for maps up to 5 x 5 */
@@ -90,8 +93,8 @@ enum {
     ADAF_EF_PLAN_HEAD_POOL = 128,    /* fp16 storage, pooled features only: the global average pool in the head conv's epilogue (no fp32 map) */
     ADAF_EF_PLAN_PAIR_CHUNKS = 256   /* two chunks of patches side by side on two streams (a batch of >= 512 patches that fits one chunk: two halves) */
 };
-int adaf_set_option(adaf_handle* h, const char* key, double value);
-double adaf_get_option(const char* key);
+int adaf_set_global_option(const char* key, double value);
+double adaf_get_global_option(const char* key);
 
 
 /* ---- a1: patch gather -------------------------------------------------------------------
@@ -345,10 +348,6 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
  * kernel where cout <= 32 and hidden <= 192 (b3, b5, b6).  bit 2 (value 4): one frame chunk at a time instead of two side by
  * side.  0 = the three-launch form.  Every combination is bit-identical (tests, A/B). */
 int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
-/* ADAF_DTYPE_F16: the whole network with fp16 activations and 1x1 weights in HBM (see N2 above; the 3x3 stem reads the
- * fp32 frames and stores fp16, the 1280-channel head stores fp32 for the consumers downstream; no temporal shift, no
- * fused expand -> depthwise kernels in this mode).  Takes effect at the next finalize(). */
-int adaf_mobilenetv2_set_dtype(adaf_mobilenetv2* net, int dtype);
 
 /* ---- N2 / BASELINE config 5: EfficientNet (MBConv with squeeze-and-excite) as the local CNN --------------------------
  * PARITY UNPINNED: the reference has no EfficientNet on a live path.  It names the third-party package

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(lib, name), name
     lib.adaf_version.restype = ctypes.c_int
-    assert lib.adaf_version() == 302      # 302: adaf_resnet50_forward_frames, adaf_resnet50_set_shift_place (round 5)
+    assert lib.adaf_version() == 303      # 303: adaf_set_global_option / adaf_get_global_option replace adaf_set_option / adaf_get_option, adaf_mobilenetv2_set_dtype removed (round 6)
 
 
 def test_loader_declares_prototypes():

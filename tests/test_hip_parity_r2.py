@@ -485,9 +485,10 @@ def test_dwconv_f16_and_casts(dev, ops):
     assert torch.equal(ops.cast(ops.cast(v, torch.float16), torch.float32).cpu(), v.cpu().half().float())
 
 
-def test_mobilenetv2_f16_storage_vs_g5_golden(dev, ops):
-    """The MobileNetV2 blocks and the whole network of G5 (generated by the real reference in fp32) with activations and 1x1
-    weights stored as fp16: error of a storage format with 11 significant bits carried through up to 52 layers."""
+def test_mobilenetv2_blocks_from_f16_entry_points_vs_g5_golden(dev, ops):
+    """Single MobileNetV2 blocks of G5 (generated by the real reference in fp32) assembled from the fp16-storage entry points
+    (adaf_conv2d_bn_act_f16, adaf_dwconv3x3_bn_act_f16: the building blocks config 5 runs on).  The glancer itself has no fp16 mode any
+    more (round 6: adaf_mobilenetv2_set_dtype measured 1.01x and cost 15 % of the policy's arg-max choices)."""
     from adafocus_amd.mobilenet import mobilenet_v2
     g = golden("g5_mbv2_act")
     mb = mobilenet_v2().eval()
@@ -496,20 +497,8 @@ def test_mobilenetv2_f16_storage_vs_g5_golden(dev, ops):
     mb = mb.to(dev)
     xc = rnd((2, 3, 64, 64), 53).to(dev)
     fm32, fv32 = mb.features_nhwc(xc)
-    fm32, fv32 = fm32.clone(), fv32.clone()
-    mb._engine.dtype = "f16"
-    fm16, fv16 = mb.features_nhwc(xc)
-    assert fm16.dtype == torch.float32 and not torch.equal(fm16, fm32)           # the fp16 plan really ran
     ref_fm = torch.from_numpy(g["fm"]).permute(0, 2, 3, 1)
-    scale = float(ref_fm.abs().max())
     assert (fm32.cpu() - ref_fm).abs().max().item() < 1e-3
-    # This random-weight network amplifies perturbations ~1000x end to end (its fp32 run ends 4e-4 away from the reference
-    # on rounding errors of 6e-8), so the 5e-4 storage rounding of fp16 shows up as a few per cent at the far end
-    # (measured: rel. rms 3.1e-2, max 0.59 on a range of 6); the single blocks below are the per-layer statement.
-    assert (fm16.cpu() - ref_fm).abs().max().item() < 0.2 * scale
-    assert (fv16.cpu() - torch.from_numpy(g["fv"])).abs().max().item() < 0.1 * scale
-    rel = ((fm16.cpu() - ref_fm).pow(2).mean().sqrt() / ref_fm.pow(2).mean().sqrt()).item()
-    assert rel < 6e-2, rel
     # single inverted-residual blocks (t = 6, stride 1 with identity; t = 6, stride 2) assembled from the fp16 entry points
     sd = {k: v.to(dev) for k, v in mb.state_dict().items()}
     xb = rnd((2, 24, 16, 16), 52)
@@ -885,16 +874,3 @@ def test_device_mismatch_is_refused(dev, ops):
         ops.crop_gather(x, torch.zeros((1, 2), device="cuda:1"), 32)
 
 
-@pytest.mark.gpu
-def test_conv_lean_forms_bit_identical_to_builtin_forms():
-    """The VALU-free K loop (scalar-base LDS-DMA, clamped rows) and the lean epilogue (saddr accesses, packed fma/add, med3)
-    against the builtin-DMA K loop and the general epilogue they replace (library option "conv_lean" = 0): same digests on
-    interior, ragged, position-major and sub-tile launches, default tile and forced 128x128 / 128x64 / 64x64."""
-    from adafocus_amd import _lib
-    from tests.helpers import load_tool
-    tool = load_tool("lean_ab")
-    with _lib.option("conv_lean", 1):
-        lean = tool.digests()
-    with _lib.option("conv_lean", 0):
-        builtin = tool.digests()
-    assert len(lean) == 9 * 4 and lean == builtin
