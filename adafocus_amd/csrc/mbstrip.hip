@@ -28,7 +28,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Ablation build (tools/exp/build_mbs_abl.sh, never the product library): MBS_ABL bits switch parts of the kernels OFF to see what each costs --
+// 1 the expand / stem MFMA chains, 2 the project MFMA chains, 4 the depthwise tap FMAs, 8 the ring reads of the taps, 16 the pixel loads.
+#ifndef MBS_ABL
+#define MBS_ABL 0
+#endif
+
 namespace {
+constexpr int ABL = MBS_ABL;
 
 // k offset (inside a 32-channel slice) that lane group g supplies as its q-th product of the 16x16x4 chain
 __device__ __forceinline__ int kq(int g, int q) { return 8 * (q >> 1) + (g >> 1) + 4 * (g & 1) + 2 * (q & 1); }
@@ -38,14 +45,33 @@ __device__ __forceinline__ int pos_of(int c) {
     return 8 * (((f & 1) << 1) | (f >> 2)) + 2 * (c >> 3) + second;
 }
 
+// "Touch-ahead": a one-dword load whose only purpose is to have the cache line on its way before the step that needs it asks for it.  A step's
+// pixels are requested one step ahead (the registers they land in are read by the current step's MFMAs until then), ~1.3 k cycles before their
+// use; lines that come from HBM take 4-5 k.  The result is kept in a register for two steps and then handed to an empty asm, so the compiler
+// neither drops the load nor waits for it early.
+__device__ __forceinline__ unsigned btouch(__amdgpu_buffer_rsrc_t r, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0); }
+__device__ __forceinline__ void bsink(unsigned v) { asm volatile("" : : "v"(v)); }
+
+__device__ __forceinline__ f32x4 ringr(const float* p) {      // a 16-byte read of the expanded-row ring
+    if (ABL & 8) return f32x4{1.f, 2.f, 3.f, 4.f};
+    return *reinterpret_cast<const f32x4*>(p);
+}
+
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    if (ABL & 16) return f32x4{1.f, 0.5f, 0.25f, 0.f};
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
 // acc += a * b on two packed fp32 lanes.  As inline asm because clang 22 UNPACKS a v_pk_fma_f32 that follows an MFMA into two v_fma_f32 ("to
 // co-issue with the MFMA"): on gfx950 nothing co-issues (tools/exp/mfma_valu_overlap.hip: MFMA + VALU time is additive, also inside one wave), so
 // the pair costs 9.6 instead of 6.6 cycles -- a third of the tap FMAs of these kernels were unpacked.  Same arithmetic, one rounding per lane.
-__device__ __forceinline__ void pkfma(f32x2& acc, f32x2 a, f32x2 b) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void pkfma(f32x2& acc, f32x2 a, f32x2 b) {
+#if MBS_ABL & 4
+    acc.x += a.x * 0.f + b.x * 0.f;     // (ablation: keeps the operands alive, costs one add)
+#else
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+}
 
 constexpr int SW_OW = 14;                    // output columns of a strip
 constexpr int SW_EP = 36;                    // floats per pixel of the ring (32 channels + 4: conflict-free 16-byte reads)
@@ -118,6 +144,10 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
     };
     fetch();
     __builtin_amdgcn_wave_barrier();
+    // touch-ahead, three steps: the four input rows a step adds (rows 4 s - 3 + 2 .. + 5 of step s's five), 16 x 64 B per row from the strip's first column
+    constexpr int PD = 3;
+    int toff = ((4 * PD - 1 + (lane >> 4)) * S + 2 * ox0 - 3) * 16 + (lane & 15) * 64;
+    unsigned tq[2] = {btouch(rsrc, toff - 8 * S * 16), btouch(rsrc, toff - 4 * S * 16)};
 
     const int nsteps = H1 / 2 + 1;
     // PAR = s & 1: the E rows 2 s - 1, 2 s of step s live in ring slots (3, 0) for even s and (1, 2) for odd s
@@ -136,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bs[kk][s4], acc, 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4) if (!(ABL & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bs[kk][s4], acc, 0, 0, 0);
         // BN + ReLU6; stem outputs outside the map are the depthwise conv's zero padding
         {
             const f32x2 sc2 = {ssc, ssc}, bi2 = {sbi, sbi};
@@ -152,6 +182,9 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
         // result above are, so past this point every MFMA that reads af[] has retired.
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nsteps) fetch();
+        bsink(tq[par]);
+        tq[par] = btouch(rsrc, toff);
+        toff += 4 * S * 16;
         __builtin_amdgcn_sched_barrier(0);
         if (s == 0) {
             asm volatile("");
@@ -181,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float* p = erd + slot[e] * SW_ROWF + kx * SW_EP;
-                    const f32x4 va = *reinterpret_cast<const f32x4*>(p), vb = *reinterpret_cast<const f32x4*>(p + 4);
+                    const f32x4 va = ringr(p), vb = ringr(p + 4);
                     const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
                     if (e < 3) {
 #pragma unroll
@@ -202,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
             // ---- project 32 -> 16 + BN: C[cout][pixel] = sum_k Wp[cout][k] D[pixel][k]; this lane gets couts 4 g .. 4 g + 3 of pixel n
             f32x4 p0 = zero4, p1 = zero4;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 8 && !(ABL & 2); ++q) {
                 p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d0[q], p0, 0, 0, 0);
                 p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d1[q], p1, 0, 0, 0);
             }
@@ -220,6 +253,8 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
         step(std::integral_constant<int, 0>{}, s);
         if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
     }
+    bsink(tq[0]);
+    bsink(tq[1]);
 }
 
 
@@ -325,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
     load_bf(0);
     load_bn(0);
     fetch(0);
+    // touch-ahead (first chunk: the later chunks re-read the same pixels from the caches): every pixel's first dword, two steps ahead
+    unsigned tq[2] = {btouch(rsrc, voff0 + rstep), btouch(rsrc, voff0 + 2 * rstep)};
     for (int c = 0; c < nchunks; ++c) {
         const float* tc = tw + c * 4 * SW_TAPF;
         auto step = [&](auto SC) {
@@ -337,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4) if (!(ABL & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
             {
                 const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
 #pragma unroll
@@ -354,6 +391,10 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
                 load_bf(c + 1);
                 load_bn(c + 1);
                 fetch(0);
+            }
+            if (c == 0 && s + 3 < NST) {
+                bsink(tq[(s + 1) & 1]);
+                tq[(s + 1) & 1] = btouch(rsrc, voff0 + (s + 3) * rstep);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s == 0) {
@@ -392,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float* p = erd + slot[e] * SW_ROWF + kx * SW_EP;
-                        const f32x4 va = *reinterpret_cast<const f32x4*>(p), vb = *reinterpret_cast<const f32x4*>(p + 4);
+                        const f32x4 va = ringr(p), vb = ringr(p + 4);
                         const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
                         if (e < 3) {
 #pragma unroll
@@ -421,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
                     d1[2 * i] = __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f); d1[2 * i + 1] = __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f);
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < 8 && !(ABL & 2); ++q) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         P[s - 1][0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[m][q], d0[q], P[s - 1][0][m], 0, 0, 0);
@@ -437,6 +478,8 @@ __global__ __launch_bounds__(256, 2) void mb_block_s_kernel(const MbFuseArgs a) 
         if (nsteps > 4) step(std::integral_constant<int, 4>{});
         __builtin_amdgcn_wave_barrier();
     }
+    bsink(tq[0]);
+    bsink(tq[1]);
     // ---- project BN (+ identity), 16-byte stores: this lane holds output channels 16 m + 4 g .. + 3 of pixel (row, ox0 + n)
     if (n < SW_OW) {
 #pragma unroll
@@ -566,6 +609,9 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
     load_bf(0);
     load_bn(0);
     fetch(0);
+    // touch-ahead (first chunk): lanes 0-31 the first dword of row A's pixels, lanes 32-63 of row B's, two steps ahead
+    const int tbase = voff0 - 16 * half + half * rband;
+    unsigned tq[2] = {btouch(rsrc, tbase + rstep), btouch(rsrc, tbase + 2 * rstep)};
     for (int c = 0; c < nchunks; ++c) {
         const float* tc = tw + c * 4 * SW_TAPF;
         // the chunk's taps and depthwise affine: 8 channels x (9 + 2) of this lane's k group, from the table
@@ -586,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
+                    for (int s4 = 0; s4 < 4; ++s4) if (!(ABL & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
                 const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
@@ -614,6 +660,10 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
                 load_bn(c + 1);
                 fetch(0);
             }
+            if (c == 0 && s + 3 < NST) {
+                bsink(tq[(s + 1) & 1]);
+                tq[(s + 1) & 1] = btouch(rsrc, tbase + (s + 3) * rstep);
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
             if constexpr (s > 0) {
@@ -626,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float* p = erd + slot[ky] * S2_ROWF + (kx == 1 ? 17 : kx == 2 ? 1 : 0) * SW_EP;
-                        const f32x4 va = *reinterpret_cast<const f32x4*>(p), vb = *reinterpret_cast<const f32x4*>(p + 4);
+                        const f32x4 va = ringr(p), vb = ringr(p + 4);
                         const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) pkfma(s0[i], v[i], tap[ky * 3 + kx][i]);
@@ -643,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
                     d0[2 * i] = __builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f); d0[2 * i + 1] = __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f);
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < 8 && !(ABL & 2); ++q) {
                     P[s - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0][q], d0[q], P[s - 1][0], 0, 0, 0);
                     P[s - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[1][q], d0[q], P[s - 1][1], 0, 0, 0);
                 }
@@ -656,6 +706,8 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
         if (nsteps > 4) step(std::integral_constant<int, 4>{});
         __builtin_amdgcn_wave_barrier();
     }
+    bsink(tq[0]);
+    bsink(tq[1]);
     if (n < SW_OW) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {

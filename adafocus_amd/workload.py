@@ -236,6 +236,21 @@ def effnet_block_bytes_per_frame(name="efficientnet-b3", size=144, elem=2):
     return b_
 
 
+def effnet_structural_bytes_per_frame(name="efficientnet-b3", size=144, elem=2, lds_bytes=160 * 1024):
+    """A REACHABLE floor for a squeeze-and-excite network (round 6): the block-level bytes of
+    effnet_block_bytes_per_frame + the round trip of the depthwise output of every block whose depthwise map of ONE image does not fit
+    one CU's LDS (ohw^2 x hid x elem > 160 KB).  The gate multiplies the depthwise map by a function of its global average, so the
+    project conv cannot start before the whole map exists: where the map cannot wait on chip it has to be written and read back once.
+    That is structural, whatever the kernels do; the block-level figure (4.06 MB per 144^2 patch in fp16 storage) is the floor of a
+    network WITHOUT the gate.  B3 at 144^2, fp16 storage: blocks 0-8 (72^2 ... 18^2 maps) exceed the LDS."""
+    c0, blocks, ch = effnet_blocks(name, size)
+    b_ = effnet_block_bytes_per_frame(name, size, elem)
+    for b in blocks:
+        if b["ohw"] ** 2 * b["hid"] * elem > lds_bytes:
+            b_ += 2 * b["ohw"] ** 2 * b["hid"] * elem
+    return b_
+
+
 def effnet_bytes_per_frame(name="efficientnet-b3", size=144, elem=2, fused=True):
     """HBM bytes per frame of the launch plan of csrc/effnet.hip + csrc/mbconv_whole.hip that RUNS (activation inputs + outputs of every
     launch; the 12 M parameters are shared by >= 1024 frames per launch and ignored): patch in (fp32 x 4 lanes), stem out; per block

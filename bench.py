@@ -111,10 +111,16 @@ def config5_row(dev, b, streams, frames, steps=30):
         elem = 2 if dtype == "f16" else 4
         by = float(workload.effnet_block_bytes_per_frame("efficientnet-b3", p, elem)) * b * t      # block-level algorithmic bytes
         plan = float(workload.effnet_bytes_per_frame("efficientnet-b3", p, elem)) * b * t            # in + out of every launch that runs
+        struct_by = float(workload.effnet_structural_bytes_per_frame("efficientnet-b3", p, elem)) * b * t
         out[dtype + "_storage"] = {
             "clips_per_s": round(steps * b / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
             "local_cnn": {"bound": "hbm", "ms": round(cnn_ms, 3), "achieved": round(by / cnn_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(by / cnn_ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_patch": int(by / (b * t)),
+                          "structural_bytes_per_patch": int(struct_by / (b * t)), "structural_frac": round(struct_by / cnn_ms / 1e6 / HBM_PEAK_GBS, 4),
+                          "structural_bytes_are": "algorithmic_bytes_per_patch (the floor of a network WITHOUT squeeze-and-excite) + one write and one read of the "
+                                                  "depthwise map of every block whose map of one image exceeds a CU's 160 KB of LDS (the gate needs the whole "
+                                                  "map's average before the project conv can start): the floor an SE network can reach "
+                                                  "(workload.effnet_structural_bytes_per_frame)",
                           "plan_bytes_per_patch": int(plan / (b * t)), "plan_gbs": round(plan / cnn_ms / 1e6, 1),
                           "plan_frac": round(plan / cnn_ms / 1e6 / HBM_PEAK_GBS, 4),
                           "traffic_bytes_per_patch": load_effnet_traffic(dtype, b * t, p),
