@@ -68,10 +68,22 @@ EXTRA_R5 = {   # round 5 (tools/profile_r5.sh)
     "effnet_f16_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB; x2 for wide coalesced reads on gfx950)",
     "effnet_f16_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB)",
 }
+EXTRA_R6 = {   # round 6 (tools/profile_r6.sh)
+    "glancer_trace": "rocprofv3 --kernel-trace --stats -- python tools/glancer_probe.py 1024   (MobileNetV2 glancer, 1024 frames of 224^2, strip-walking front kernels of csrc/mbstrip.hip; 2 warm-up + 3 timed forwards; two 512-frame chunks side by side on two streams)",
+    "glancer_trace_serial": "rocprofv3 --kernel-trace --stats -- python tools/glancer_probe.py 1024 5   (the same forward with chunk pairing off: every kernel alone on the device)",
+    "glancer_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/glancer_probe.py 1024   (KB; x2 for wide coalesced reads on gfx950, MI355X_MICROARCH.md)",
+    "glancer_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/glancer_probe.py 1024   (KB)",
+    "glancer_sq": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python tools/glancer_probe.py 1024 5",
+    "split_trace": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 4 --skip-extras --streams 1 --cpu-baseline 0 --math split_bf16   (the opt-in arithmetic: also.split_bf16)",
+    "split_mfma": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0 --math split_bf16",
+    "split_lds": "rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_INSTS_MFMA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -- python bench.py --steps 4 --warmup 2 --skip-extras --profile-steps 1 --streams 1 --cpu-baseline 0 --math split_bf16",
+}
 if tag >= "r4":
     EXTRA = EXTRA_R4
 if tag >= "r5":
     EXTRA = EXTRA_R5
+if tag >= "r6":
+    EXTRA = EXTRA_R6
 
 
 def all_kernels_sum(path, counter, once_per_forward):
@@ -134,7 +146,7 @@ if os.path.exists(ef_f) and os.path.exists(ef_w):
     print("effnet traffic: %.2f MB / patch over %d forwards" % (per_patch / 1e6, nf))
 gl_f, gl_w = os.path.join(PROF, "%s_glancer_fetch.md" % tag), os.path.join(PROF, "%s_glancer_write.md" % tag)
 if os.path.exists(gl_f) and os.path.exists(gl_w):
-    fs, nf = all_kernels_sum(gl_f, "FETCH_SIZE", "mb_stem_b1")
+    fs, nf = all_kernels_sum(gl_f, "FETCH_SIZE", "mb_stem_b1")       # (matches mb_stem_b1_w_kernel and, round 6, mb_stem_b1_s_kernel)
     ws, nw = all_kernels_sum(gl_w, "WRITE_SIZE", "mb_stem_b1")
     # (the stem + block-1 kernel runs once per 512-frame chunk: two dispatches per 1024-frame forward)
     per_frame = int((2 * fs / max(nf, 1) + ws / max(nw, 1)) * 1024 / 512)
