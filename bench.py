@@ -191,7 +191,7 @@ def load_effnet_traffic(dtype, patches, p):
 def load_glancer_traffic(frames):
     """HBM bytes per frame of the glancer from the committed rocprofv3 PMC passes (profiles/r<N>_glancer_traffic.json: separate FETCH_SIZE /
     WRITE_SIZE runs of tools/glancer_probe.py, tools/publish_profiles.py); null when not collected for this frame count."""
-    for tag in ("r5", "r4"):
+    for tag in ("r6", "r5", "r4"):
         path = os.path.join(ROOT, "profiles", "%s_glancer_traffic.json" % tag)
         if os.path.exists(path):
             try:
@@ -206,7 +206,7 @@ def load_glancer_traffic(frames):
 def load_traffic(t, p, b):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r<N>_traffic.json, tools/profile_bench.sh +
     tools/publish_profiles.py; newest round first); only reported when it was collected on this very workload."""
-    for tag in ("r5", "r4", "r3", "r2"):
+    for tag in ("r6", "r5", "r4", "r3", "r2"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)))
             w = d["workload"]

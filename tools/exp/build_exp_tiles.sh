@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../../adafocus_amd/csrc"
 mkdir -p exp_build
-for f in api conv_gemm conv_lat crop misc_ops mobilenetv2 mbconv gru_scan stem effnet mbconv_whole; do
+for f in api conv_gemm conv_lat crop misc_ops mobilenetv2 mbconv gru_scan stem effnet mbconv_whole mbstrip; do
   extra=""
   case $f in mbconv_whole|effnet) extra="-fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-inline-asm -DADAF_EXP_TILES $extra -c $f.hip -o exp_build/$f.o &
