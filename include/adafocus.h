@@ -289,7 +289,7 @@ int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
  *     upwards (below that the three separate launches are faster: small batches; on = 2: always);
  *   - the global average pool (ACT/models/resnet.py:222-223) in the epilogue of the last conv3 when whole images fill its
  *     128-row tiles (3x3 / 4x4 / 5x5 final maps): the 2048-channel map is never written (conv_gemm.hip conv_epilogue_pool).
- * Results are bit-identical to the unfused launches (same k order in every product).  ADAF_MATH_F32 only. */
+ * Results are bit-identical to the unfused launches (same k order in every product).  ADAF_MATH_F32, and the fp32-pipe layers of the hybrid ADAF_MATH_F32_SPLIT_BF16 plan (see adaf_resnet50_set_math). */
 int adaf_resnet50_set_fusion(adaf_resnet50* net, int on);
 /* Small batches (BASELINE config 1 is B = 2, T = 8: 16 patches).  A conv launch whose GEMM has at most `rows` output pixels
  * (default 1536, env ADAF_LATENCY_ROWS; 0 = never) runs on the small-batch form (tile id 95 of adaf_conv_params.tile) instead
@@ -314,7 +314,12 @@ int adaf_resnet50_set_shift_place(adaf_resnet50* net, int place);
  *                            nearest: h = bf16(x), m = bf16(x-h), l = x-h-m) and x*y is accumulated in fp32 from the
  *                            six bf16 products of magnitude >= 2^-24 |xy| on v_mfma_f32_32x32x16_bf16.  Inputs, outputs,
  *                            weights and the accumulator stay fp32; error against fp64: per convolution not larger than
- *                            the default's, whole trunk 5.9e-7 vs 3.8e-7 rms.  The stem keeps the default. */
+ *                            the default's, whole trunk 5.9e-7 vs 3.8e-7 rms.  The plan is HYBRID (round 5): the stem and
+ *                            convolutions 1-11 (layer1.* and layer2.0.conv1 -- HBM-bound whatever the matrix pipe) stay on the fp32
+ *                            pipe, the rest runs the six-product form; the global option "split_stage1_f32" = 0 puts every conv but
+ *                            the stem on split tiles (NOT bit-identical to the default hybrid plan, both fp32-accurate; results of
+ *                            split_bf16 callers changed by <= 2e-5 when the hybrid plan became the default).  adaf_resnet50_set_fusion
+ *                            applies to the fp32-pipe launches of either mode. */
 enum { ADAF_MATH_F32 = 0, ADAF_MATH_F32_SPLIT_BF16 = 1 };
 int adaf_resnet50_set_math(adaf_resnet50* net, int mode);
 
