@@ -190,6 +190,8 @@ bool adaf_mb_stem_b1_strip_ok(int S, int H1);                      // mbstrip.hi
 void adaf_launch_mb_stem_b1_strip(MbStemArgs a, hipStream_t s);
 bool adaf_mb_block_strip_ok(int cin, int hid, int cout, int stride, int h, int w);
 void adaf_launch_mb_block_strip(MbFuseArgs a, hipStream_t s);
+bool adaf_mb_expand_dw_strip_ok(int cin, int hid, int stride, int h, int w);     // expand -> depthwise on 14-column strips (64 / 96 input channels)
+void adaf_launch_mb_expand_dw_strip(MbFuseArgs a, hipStream_t s);
 bool adaf_mb_expand_dw_ok(int cin, int hid, int hw);
 void adaf_launch_mb_expand_dw(MbFuseArgs a, int stride, hipStream_t s);
 bool adaf_mb_block_ok(int cin, int hid, int cout, int stride, int hw);

@@ -701,6 +701,189 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Expand 1x1 (+ BN + ReLU6) -> depthwise 3x3 (+ BN + ReLU6) of the stride-1 blocks on 14 x 14 maps (b8-b13 of MobileNetV2 at 224^2: 64 / 96 input
+// channels, 384 / 576 hidden): the 6x-expanded map -- 44 % of such a block's HBM bytes, written by a short-K GEMM the conv engine runs at a
+// third of its rate (K = 64: two slices per tile, the tile's prologue and epilogue are most of its time) -- never exists.  A wave walks a
+// whole 14-column strip of a frame top to bottom, once per chunk of 32 hidden channels (chunk loop outside: the chunk's filter rows stay in
+// registers for the 8 steps); there is no project conv behind the taps here (its 64 / 96 x 384 / 576 accumulators would not fit a wave: it
+// stays on the engine), so a depthwise lane is (column n, channel octet cq = lane >> 4) with 8 CONSECUTIVE channels -- natural channel order
+// in the ring, two 16-byte stores per output row -- and nothing lives across the chunks.  Same products in the same order as the engine's
+// 1x1 conv (k slices of 32, a lane's 16-byte fragment) and dwconv3x3_kernel: bit-identical to the two launches.
+constexpr int XD_MAXCH = 18;                 // chunks (hid <= 576)
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs a) {
+    constexpr int KK = CIN / 8;
+    __shared__ __attribute__((aligned(16))) float Eall[4][SW_RING];
+    __shared__ __attribute__((aligned(16))) float Tall[XD_MAXCH * 4 * SW_TAPF];      // [chunk][octet][9 taps | scale | bias][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hid = a.hid, nchunks = hid >> 5;
+    for (int idx = tid; idx < nchunks * 4 * SW_TAPF; idx += 256) {
+        const int q = idx & 7, t = (idx >> 3) % 11, cg = idx / SW_TAPF;
+        const int ch = 8 * cg + q;                       // (32 (cg >> 2) + 8 (cg & 3) + q)
+        Tall[idx] = t < 9 ? a.wd[(size_t)t * hid + ch] : t == 9 ? a.sd[ch] : a.bd[ch];
+    }
+    float* Ew = Eall[wave];
+    for (int i = lane; i < SW_RING; i += 64) Ew[i] = 0.f;
+    __syncthreads();
+    // a work item = (strip, chunk group): nothing lives across the chunks, so the hidden channels are also cut over the waves -- a 14 x 14 map is ONE
+    // strip per frame, 512 waves for a 512-frame chunk would leave three quarters of the wave slots empty.  The waves of a block take the groups
+    // of one strip: they read the same pixels at about the same time.
+    const int nstrips = a.tiles_x, ngroups = a.tiles_y;
+    int strip = blockIdx.x * 4 + wave;
+    if (strip >= a.n * nstrips * ngroups) return;
+    const int cgrp = strip % ngroups;
+    strip /= ngroups;
+    const int c_lo = (nchunks * cgrp) / ngroups, c_hi = (nchunks * (cgrp + 1)) / ngroups;
+    const int img = strip / nstrips, sx = strip - img * nstrips;
+    const int ox0 = sx * SW_OW;
+    const bool left = sx == 0, right = sx == nstrips - 1;
+    const int H = a.H, W = a.W;
+    const int nsteps = H / 2 + 1;
+
+    // ---- expand GEMM roles: A row p = lane & 31 = (er = p >> 4, ec = p & 15) is input pixel (2 s - 1 + er, ox0 - 1 + ec), k = 8 kk + 4 half ..
+    const int half = lane >> 5, nl = lane & 31;
+    const int er = nl >> 4, ec = nl & 15;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)img * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+    const int voff0 = (((er - 1) * W + ox0 - 1 + ec) * CIN + 4 * half) * 4;
+    const int rstep = 2 * W * CIN * 4;
+    float* ewr = Ew + (4 * half) * SW_EP + nl;              // natural channel order in the ring
+
+    // ---- depthwise roles: (output column n, channel octet cq)
+    const int n = lane & 15, cq = lane >> 4;
+    const float* erd = Ew + n * SW_EP + 8 * cq;
+    const float* tw = Tall + cq * SW_TAPF;
+    float* obase = a.out + (((size_t)img * H - 2) * W + ox0 + n) * hid + 8 * cq;       // row 2 s - 2 at step s
+    const bool ostore = n < SW_OW;
+
+    f32x4 bf[KK], af[KK];
+    float esc, ebi;
+    auto load_bf = [&](int c) {
+        const int nch = 32 * c + nl;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = *reinterpret_cast<const f32x4*>(a.we + (size_t)nch * CIN + 8 * kk + 4 * half);
+        esc = a.se[nch];
+        ebi = a.be[nch];
+    };
+    auto fetch = [&](int s) {
+        const int vo = voff0 + s * rstep;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) af[kk] = bload(rsrc, vo + 32 * kk);
+    };
+    load_bf(c_lo);
+    fetch(0);
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float* tc = tw + c * 4 * SW_TAPF;
+        float* optr = obase + 32 * c;
+        auto step = [&](auto PAR, int s) {
+            constexpr int par = decltype(PAR)::value;
+            constexpr int SL0 = par ? 1 : 3, SL1 = par ? 2 : 0;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) if (!(ABL & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][s4], bf[kk][s4], acc, 0, 0, 0);
+            {
+                const f32x2 sc2 = {esc, esc}, bi2 = {ebi, ebi};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, sc2, bi2);
+                    acc[r] = __builtin_amdgcn_fmed3f(v.x, 0.f, 6.f);
+                    acc[r + 1] = __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f);
+                }
+            }
+            // (the chain has retired -- its result was read: the landing registers of the next requests are free; see the stem kernel)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < nsteps) fetch(s + 1);
+            else if (c + 1 < c_hi) {
+                load_bf(c + 1);
+                fetch(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) {
+                asm volatile("");
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] = 0.f;           // expanded row -1
+            }
+            if (s == nsteps - 1) {
+                asm volatile("");
+#pragma unroll
+                for (int r = 8; r < 16; ++r) acc[r] = 0.f;          // expanded row H
+            }
+            if (left) { asm volatile(""); if (half == 0) { acc[0] = 0.f; acc[8] = 0.f; } }      // expanded column -1
+            if (right) { asm volatile(""); if (half == 1) { acc[7] = 0.f; acc[15] = 0.f; } }    // expanded column W
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ewr[(r < 8 ? SL0 : SL1) * SW_ROWF + ((r & 3) + 8 * ((r >> 2) & 1)) * SW_EP] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+            if (s > 0) {
+                constexpr int slot[4] = {par ? 3 : 1, par ? 0 : 2, SL0, SL1};
+                f32x2 s0[4], s1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s0[i] = f32x2{0.f, 0.f}; s1[i] = f32x2{0.f, 0.f}; }
+                f32x2 tprev[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 tcur[3][4];
+                    if (e < 3) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const f32x4 ta = *reinterpret_cast<const f32x4*>(tc + (e * 3 + kx) * 8), tb = *reinterpret_cast<const f32x4*>(tc + (e * 3 + kx) * 8 + 4);
+                            tcur[kx][0] = f32x2{ta.x, ta.y}; tcur[kx][1] = f32x2{ta.z, ta.w}; tcur[kx][2] = f32x2{tb.x, tb.y}; tcur[kx][3] = f32x2{tb.z, tb.w};
+                        }
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* p = erd + slot[e] * SW_ROWF + kx * SW_EP;
+                        const f32x4 va = ringr(p), vb = ringr(p + 4);
+                        const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
+                        if (e < 3) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pkfma(s0[i], v[i], tcur[kx][i]);
+                        }
+                        if (e > 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pkfma(s1[i], v[i], tprev[kx][i]);
+                        }
+                    }
+                    if (e < 3) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) tprev[kx][i] = tcur[kx][i];
+                    }
+                }
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(tc + 72), sb = *reinterpret_cast<const f32x4*>(tc + 76);
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(tc + 80), bb = *reinterpret_cast<const f32x4*>(tc + 84);
+                const f32x2 dsc[4] = {{sa.x, sa.y}, {sa.z, sa.w}, {sb.x, sb.y}, {sb.z, sb.w}}, dbi[4] = {{ba.x, ba.y}, {ba.z, ba.w}, {bb.x, bb.y}, {bb.z, bb.w}};
+                float d0[8], d1[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 r0 = __builtin_elementwise_fma(s0[i], dsc[i], dbi[i]), r1 = __builtin_elementwise_fma(s1[i], dsc[i], dbi[i]);
+                    d0[2 * i] = __builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f); d0[2 * i + 1] = __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f);
+                    d1[2 * i] = __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f); d1[2 * i + 1] = __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f);
+                }
+                if (ostore) {
+                    float* o = optr + (size_t)(2 * s) * W * hid;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{d0[0], d0[1], d0[2], d0[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{d0[4], d0[5], d0[6], d0[7]};
+                    *reinterpret_cast<f32x4*>(o + (size_t)W * hid) = f32x4{d1[0], d1[1], d1[2], d1[3]};
+                    *reinterpret_cast<f32x4*>(o + (size_t)W * hid + 4) = f32x4{d1[4], d1[5], d1[6], d1[7]};
+                }
+            }
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            step(std::integral_constant<int, 0>{}, s);
+            if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 bool adaf_mb_stem_b1_strip_ok(int S, int H1) { return adaf_options().mb_strip != 0 && S == 2 * H1 && H1 % SW_OW == 0 && H1 >= SW_OW; }
@@ -736,4 +919,19 @@ void adaf_launch_mb_block_strip(MbFuseArgs a, hipStream_t s) {
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
     if (a.cin == 24) hipLaunchKernelGGL((mb_block_s_kernel<24>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((mb_block_s_kernel<32>), grid, block, 0, s, a);
+}
+
+// expand -> depthwise of the stride-1 blocks with 64 / 96 input channels on maps whose side is a multiple of 14 (b8-b13 at 224^2 frames)
+bool adaf_mb_expand_dw_strip_ok(int cin, int hid, int stride, int h, int w) {
+    return adaf_options().mb_strip != 0 && stride == 1 && (cin == 64 || cin == 96) && hid % 32 == 0 && hid <= 32 * XD_MAXCH && h == w && w % SW_OW == 0 &&
+           h % 2 == 0;
+}
+
+void adaf_launch_mb_expand_dw_strip(MbFuseArgs a, hipStream_t s) {
+    a.tiles_x = a.W / SW_OW;
+    a.tiles_y = a.hid / 32 >= 4 ? 4 : 1;     // four chunk groups (12 chunks: 3 each; 18: 5, 4, 5, 4): 2048 waves per 512 frames = the device's wave slots once
+    const long long items = (long long)a.n * a.tiles_x * a.tiles_y;
+    const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+    if (a.cin == 64) hipLaunchKernelGGL((mb_expand_dw_s_kernel<64>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((mb_expand_dw_s_kernel<96>), grid, block, 0, s, a);
 }

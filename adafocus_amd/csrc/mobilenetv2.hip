@@ -283,6 +283,9 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
                 const MbConv& E = net->convs[b.expand];
                 const bool tsm = tsm_segments > 0 && residual;      // STH/models/gfv_net.py:238-241
                 fused = net->fuse && adaf_mb_expand_dw_ok(b.inp, hid, hw);
+                // the 14 x 14 blocks (64 / 96 input channels): expand -> depthwise on strips (mbstrip.hip), the project conv stays on the engine
+                const bool strip_xd = net->fuse && net->whole && !fused && adaf_mb_expand_dw_strip_ok(b.inp, hid, b.stride, hw, hw);
+                if (strip_xd) fused = true;
                 const float* ein = cur;
                 int fused_T = 0;
                 if (tsm) {
@@ -311,7 +314,8 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
                         hw = fa.OH;
                         continue;
                     }
-                    adaf_launch_mb_expand_dw(fa, b.stride, st);
+                    if (strip_xd) adaf_launch_mb_expand_dw_strip(fa, st);
+                    else adaf_launch_mb_expand_dw(fa, b.stride, st);
                 } else {
                     if ((rc = run_conv(net, E, ein, nc, hw, hw, ADAF_ACT_RELU6, nullptr, bufE, fused_T, tsm_div, st)))
                         return mfail(h, rc, "mobilenetv2: expand launch");

@@ -31,11 +31,12 @@ def _frames(dev, n, size, seed):
 
 def test_strip_kernels_bit_identical_to_tiles_and_to_the_three_launch_plan(dev):
     """Strips need maps whose side is a multiple of 14 (stem output; 28 for the stride-2 blocks): 224^2 takes every strip kernel (stem + b1,
-    b2 .. b6), 56 / 84 / 140 / 168 some of them with edge strips only, partial last row segments (28 / 8, 42 / 8) and ragged strides, 200 and
-    120 none (the tile kernels).  Every plan must produce the same feature map, bit for bit: strips, tiles, tiles without the whole-block
+    b2 .. b6, expand -> depthwise of b8 .. b13 on 14^2 maps), 448^2 the same with several strips per map everywhere (28^2 maps for b8 .. b13:
+    left and right edge strips), 56 / 84 / 140 / 168 some of them with edge strips only, partial last row segments (28 / 8, 42 / 8) and ragged
+    strides, 200 and 120 none (the tile kernels).  Every plan must produce the same feature map, bit for bit: strips, tiles, tiles without the whole-block
     kernels, the unfused three launches."""
     net = _glancer(dev)
-    for n, size in ((5, 224), (3, 56), (2, 84), (3, 140), (2, 168), (3, 200), (4, 120), (520, 56)):
+    for n, size in ((5, 224), (3, 56), (2, 84), (3, 140), (2, 168), (2, 448), (3, 200), (4, 120), (520, 56)):
         x4 = _frames(dev, n, size, 600 + size)
         outs = []
         with torch.no_grad():

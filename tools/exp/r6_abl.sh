@@ -1,7 +1,7 @@
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for k in 0 1 2 3 4 12 7 15 31; do
+for k in ${ABLS:-0 1 2 3 4 12 7 15 31}; do
   if [ $k = 0 ]; then unset ADAF_LIB; else export ADAF_LIB=$R/adafocus_amd/csrc/exp_build/libadafocus_hip_abl$k.so; fi
   rm -rf /tmp/abl_$k
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$k -- python $R/tools/glancer_probe.py 1024 5 > /tmp/abl_$k.log 2>&1
