@@ -90,7 +90,8 @@ def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_bl
     whole_blocks=True (with fused): the stride-1 blocks with cin, cout <= 32 on maps >= 28^2 (b3, b5, b6) run expand ->
     depthwise -> project + identity in one kernel (mb_block_w_kernel): block input in (and once more as the identity), output out.
     strips=True (round 6, csrc/mbstrip.hip; maps whose output side is a multiple of 14): the stride-2 blocks with 16 / 24 input channels
-    (b2, b4) are whole-block launches too -- their depthwise map and the project launch's read of it are gone."""
+    (b2, b4) are whole-block launches too -- their depthwise map and the project launch's read of it are gone -- and the stride-1 blocks with
+    64 / 96 input channels (b8-b13) run expand -> depthwise in one launch (no expanded map in HBM)."""
     hw = _out(size, 3, 2, 1)
     elems = size * size * 4                                  # pixel-major NHWC4 frames, read once
     first = True
@@ -108,6 +109,9 @@ def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_bl
             last = b
             continue
         pair_fused = fused and b["inp"] <= 32 and b["hw"] >= 28
+        # round 6: expand -> depthwise on strips for the stride-1 blocks with 64 / 96 input channels on maps whose side is a multiple of 14 (b8-b13 at 224^2)
+        if fused and whole_blocks and strips and b["stride"] == 1 and b["inp"] in (64, 96) and b["hw"] % 14 == 0 and hid <= 576:
+            pair_fused = True
         s2_whole = strips and b["stride"] == 2 and b["inp"] in (16, 24) and b["ohw"] % 14 == 0
         if pair_fused and whole_blocks and (b["stride"] == 1 or s2_whole) and b["oup"] <= 32 and hid <= 192:
             elems += hin * b["inp"] + hout * b["oup"] + (hout * b["oup"] if res else 0)
