@@ -69,3 +69,25 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["config"]["global_batch"] == 32
     assert len(r["per_rank_clips_per_s"]) == 2 and min(r["per_rank_clips_per_s"]) > 0
     assert r["value"] > 0 and "roofline" in r
+
+
+def test_workload_byte_and_flop_figures():
+    """The per-unit figures bench.py prices rooflines with (adafocus_amd/workload.py): known values and the orderings that
+    must hold between the denominators reported side by side."""
+    from adafocus_amd import workload as w
+    assert w.crop_bytes_per_patch(96) == 221184 and w.crop_bytes_per_patch(128) == 393216          # 2 C P^2 4
+    assert abs(w.hot_path_flops_per_clip(16, 96) / 1e9 - 24.46) < 0.05 and abs(w.hot_path_flops_per_clip(8, 96) / 1e9 - 12.23) < 0.05
+    assert abs(w.mobilenetv2_macs_per_frame(224) / 1e9 - 0.2995) < 0.002
+    # glancer: block-level floor <= the plan that runs (strips: round 6) <= the wave-private plan <= the three-launch plan
+    block = w.mobilenetv2_block_bytes_per_frame(224)
+    strips = w.mobilenetv2_bytes_per_frame(224, strips=True)
+    tiles = w.mobilenetv2_bytes_per_frame(224, strips=False)
+    unfused = w.mobilenetv2_bytes_per_frame(224, fused=False)
+    assert block < strips < tiles < unfused and abs(block / 1e6 - 9.51) < 0.01 and abs(tiles / 1e6 - 22.18) < 0.01 and abs(strips / 1e6 - 14.66) < 0.01
+    # frames whose maps are not multiples of 14 take no strip kernel: same bytes either way
+    assert w.mobilenetv2_bytes_per_frame(200, strips=True) == w.mobilenetv2_bytes_per_frame(200, strips=False)
+    # config 5: the structural floor of a squeeze-and-excite network sits between the block-level bytes and the launch plan's
+    blk = w.effnet_block_bytes_per_frame("efficientnet-b3", 144, 2)
+    struct = w.effnet_structural_bytes_per_frame("efficientnet-b3", 144, 2)
+    plan = w.effnet_bytes_per_frame("efficientnet-b3", 144, 2)
+    assert blk < struct < plan and abs(blk / 1e6 - 4.06) < 0.01 and abs(struct / 1e6 - 8.87) < 0.01
