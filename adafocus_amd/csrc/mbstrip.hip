@@ -929,7 +929,16 @@ bool adaf_mb_expand_dw_strip_ok(int cin, int hid, int stride, int h, int w) {
 
 void adaf_launch_mb_expand_dw_strip(MbFuseArgs a, hipStream_t s) {
     a.tiles_x = a.W / SW_OW;
-    a.tiles_y = a.hid / 32 >= 4 ? 4 : 1;     // four chunk groups (12 chunks: 3 each; 18: 5, 4, 5, 4): 2048 waves per 512 frames = the device's wave slots once
+    // chunk groups: enough waves to fill the device's 2048 wave slots (two per SIMD) once -- 512 frames: four groups (12 chunks: 3 each; 18: 5, 4, 5, 4);
+    // fewer frames (the Something-Something glancer's 256-frame half chunks, small batches): more, smaller groups, down to one chunk per wave
+    const int nchunks = a.hid / 32;
+    int groups = nchunks >= 4 ? 4 : 1;
+    while ((long long)a.n * a.tiles_x * groups < 2048 && groups < nchunks) {
+        int g = groups + 1;
+        while (g < nchunks && nchunks % g) ++g;      // next divisor of the chunk count: equal groups
+        groups = g;
+    }
+    a.tiles_y = groups;
     const long long items = (long long)a.n * a.tiles_x * a.tiles_y;
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
     if (a.cin == 64) hipLaunchKernelGGL((mb_expand_dw_s_kernel<64>), grid, block, 0, s, a);
