@@ -351,7 +351,11 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
  * (the 6x-expanded map stays on chip) for the blocks whose shape allows it (cin % 8 == 0, cin <= 32, map >= 28^2: b2..b7 at
  * 224^2); and, unless bit 3 (value 8) is set, the WHOLE stride-1 block (expand -> depthwise -> project + identity) in one
  * kernel where cout <= 32 and hidden <= 192 (b3, b5, b6).  bit 2 (value 4): one frame chunk at a time instead of two side by
- * side.  0 = the three-launch form.  Every combination is bit-identical (tests, A/B). */
+ * side.  0 = the three-launch form.  Every combination is bit-identical (tests, A/B).
+ * Round 6 (global option "mb_strip", default 1; frames whose stem output side is a multiple of 14, e.g. 224^2): the fused kernels are STRIP-WALKING
+ * forms (csrc/mbstrip.hip) -- stem + block 1, the whole blocks b2 .. b6 INCLUDING the stride-2 ones with their project conv, and expand -> depthwise
+ * of the 14 x 14 blocks b8 .. b13 (bit 3 set: b2 .. b6 and b8 .. b13 fall back to the wave-private kernels / separate launches).  Same bits as every
+ * other combination. */
 int adaf_mobilenetv2_set_fusion(adaf_mobilenetv2* net, int on);
 
 /* ---- N2 / BASELINE config 5: EfficientNet (MBConv with squeeze-and-excite) as the local CNN --------------------------
