@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
     for (int q = 0; q < 8; ++q) wp[q] = a.wp[n * 32 + kq(g, q)];
     const f32x4 psc = *reinterpret_cast<const f32x4*>(a.sp + 4 * g), pbi = *reinterpret_cast<const f32x4*>(a.bp + 4 * g);
     const float* erd = Ew + n * SW_EP + 8 * g;
-    float* optr = a.out + (((size_t)img * H1 - 2) * H1 + ox0 + n) * 16 + 4 * g;       // row 2 s - 2 at step s
+    float* const orow0 = a.out + ((size_t)img * H1 * H1 + ox0 + n) * 16 + 4 * g;      // output row 0 of this lane's column
     const bool ostore = n < SW_OW;
 
     f32x4 af[5];
@@ -231,11 +231,11 @@ __global__ __launch_bounds__(256, 2) void mb_stem_b1_s_kernel(const MbStemArgs a
                 f32x4 o0, o1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { o0[i] = fmaf(p0[i], psc[i], pbi[i]) + 0.f; o1[i] = fmaf(p1[i], psc[i], pbi[i]) + 0.f; }
+                float* optr = orow0 + (size_t)(2 * s - 2) * H1 * 16;
                 *reinterpret_cast<f32x4*>(optr) = o0;
                 *reinterpret_cast<f32x4*>(optr + (size_t)H1 * 16) = o1;
             }
         }
-        optr += (size_t)2 * H1 * 16;
     };
     for (int s = 0; s < nsteps; s += 2) {
         step(std::integral_constant<int, 0>{}, s);
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs
     const int n = lane & 15, cq = lane >> 4;
     const float* erd = Ew + n * SW_EP + 8 * cq;
     const float* tw = Tall + cq * SW_TAPF;
-    float* obase = a.out + (((size_t)img * H - 2) * W + ox0 + n) * hid + 8 * cq;       // row 2 s - 2 at step s
+    float* const obase = a.out + ((size_t)img * H * W + ox0 + n) * hid + 8 * cq;       // output row 0 of this lane's column
     const bool ostore = n < SW_OW;
 
     f32x4 bf[KK], af[KK];
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs
                     d1[2 * i] = __builtin_amdgcn_fmed3f(r1.x, 0.f, 6.f); d1[2 * i + 1] = __builtin_amdgcn_fmed3f(r1.y, 0.f, 6.f);
                 }
                 if (ostore) {
-                    float* o = optr + (size_t)(2 * s) * W * hid;
+                    float* o = optr + (size_t)(2 * s - 2) * W * hid;
                     *reinterpret_cast<f32x4*>(o) = f32x4{d0[0], d0[1], d0[2], d0[3]};
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{d0[4], d0[5], d0[6], d0[7]};
                     *reinterpret_cast<f32x4*>(o + (size_t)W * hid) = f32x4{d1[0], d1[1], d1[2], d1[3]};
