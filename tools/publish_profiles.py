@@ -68,7 +68,9 @@ EXTRA_R5 = {   # round 5 (tools/profile_r5.sh)
     "effnet_f16_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB; x2 for wide coalesced reads on gfx950)",
     "effnet_f16_write": "rocprofv3 --pmc WRITE_SIZE -- python tools/effnet_probe.py 1024 144 5 f16   (KB)",
 }
-EXTRA_R6 = {   # round 6 (tools/profile_r6.sh)
+EXTRA_R6 = {   # round 6 (tools/profile_r6.sh; the full-forward traces: tools/exp/r6_fullfwd.sh)
+    "fullfwd_trace_serial": "rocprofv3 --kernel-trace -- python tools/fullfwd_probe.py serial 10, condensed by tools/overlap_report.py   (full forward from uint8 clips, B = 64, T = 16, P = 96: ingest + glancer + policy + hot path on ONE stream; 20.9 ms per batch = 3.06 k clips/s on that box)",
+    "fullfwd_trace_2streams": "rocprofv3 --kernel-trace -- python tools/fullfwd_probe.py two 10, condensed by tools/overlap_report.py   (the same work through GFV.offline_forward_pipelined; 21.1 ms)",
     "glancer_trace": "rocprofv3 --kernel-trace --stats -- python tools/glancer_probe.py 1024   (MobileNetV2 glancer, 1024 frames of 224^2, strip-walking front kernels of csrc/mbstrip.hip; 2 warm-up + 3 timed forwards; two 512-frame chunks side by side on two streams)",
     "glancer_trace_serial": "rocprofv3 --kernel-trace --stats -- python tools/glancer_probe.py 1024 5   (the same forward with chunk pairing off: every kernel alone on the device)",
     "glancer_fetch": "rocprofv3 --pmc FETCH_SIZE -- python tools/glancer_probe.py 1024   (KB; x2 for wide coalesced reads on gfx950, MI355X_MICROARCH.md)",
