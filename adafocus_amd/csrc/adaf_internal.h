@@ -95,6 +95,7 @@ struct AdafOptions {
     int effnet_chunk = 1024;      // "effnet_chunk": frames per chunk of the EfficientNet forward
     int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)
     int split_stage1_f32 = 1;     // "split_stage1_f32": the split-bf16 trunk takes the fp32 pipe's fused stage-1 launches (api.hip run_trunk)
+    int split_lean = 1;           // "split_lean": the split tiles' K loop with scalar-base DMA (conv_gemm.hip launch_glds; 0 = the pointer-per-lane form, A/B)
     int gru_graph_persistent = 0; // "gru_graph_persistent": 1 = a stream capture keeps the persistent GRU scan (the caller guarantees exclusive use of the device
                                   // while the graph replays); 0 = captures take the launch-per-step form, which has no grid barrier to starve
     int gru_scan_slices = 2;      // "gru_scan_slices": clip slices a persistent GRU scan may be cut into (1 | 2; gru_scan.hip)
@@ -233,10 +234,15 @@ bool adaf_launch_mbconv_whole(const void* x, int n, int hw, int stride, int cin,
 int adaf_gru_scan_blocks_per_cu();
 bool adaf_gru_scan_persistent_ok(int batch, int hidden, int classes, int resident_blocks);
 int adaf_gru_scan_groups(int batch, int resident_blocks);
+struct AdafGruScanPlan {
+    int groups;      // slices the scan is cut into (0: the barrier buffer is too small for a persistent scan)
+    int bpad;        // pitch of the XCD-hierarchical barrier records in words (16 or 1), 0 = one counter per step
+    size_t nzero;    // words of the barrier buffer the launch clears
+};
+AdafGruScanPlan adaf_gru_scan_plan(int batch, int steps, size_t bar_words, int resident_blocks);
 hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
-                                           unsigned* bar, size_t bar_words, int batch, int steps, const float* fcw, const float* fcb,
-                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, int groups,
-                                           hipStream_t s);
+                                           unsigned* bar, const AdafGruScanPlan& plan, int batch, int steps, const float* fcw, const float* fcb,
+                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, hipStream_t s);
 
 // conv_gemm.hip
 int adaf_launch_conv_gemm(const ConvArgs& a, int tile, int cus, hipStream_t s);  // returns chosen tile (>0) or <0

@@ -80,7 +80,7 @@ struct OptKey { const char* name; double lo, hi; };
 // (round 6: the switches that measured as no-gain and had no user are gone -- conv_lean, pm_fill, resize_lds_kb, mb_wave, dw3_variant, gru_barrier)
 const OptKey kOptKeys[] = {{"conv_pool", 0, 1}, {"mb_strip", 0, 1}, {"mbv2_chunk", 1, 1 << 20}, {"latency_rows", 0, 1 << 30}, {"latency_linear_rows", 0, 1 << 30},
                            {"effnet_plan", 0, 511}, {"effnet_chunk", 1, 1 << 20}, {"gru_scan_slices", 1, 2}, {"effnet_fused_blocks", 0, 4294967295.0},
-                           {"stem_rows", 0, 2}, {"split_stage1_f32", 0, 1}, {"gru_graph_persistent", 0, 1}};
+                           {"stem_rows", 0, 2}, {"split_stage1_f32", 0, 1}, {"gru_graph_persistent", 0, 1}, {"split_lean", 0, 1}};
 int find_opt(const char* key) {
     if (!key) return -1;
     for (size_t i = 0; i < sizeof(kOptKeys) / sizeof(kOptKeys[0]); ++i)
@@ -161,7 +161,8 @@ int adaf_set_global_option(const char* key, double value) {
         case 8: o.effnet_fused_blocks = (unsigned)value; break;
         case 9: o.stem_rows = (int)value; break;
         case 10: o.split_stage1_f32 = (int)value; break;
-        default: o.gru_graph_persistent = (int)value; break;
+        case 11: o.gru_graph_persistent = (int)value; break;
+        default: o.split_lean = (int)value; break;
     }
     return ADAF_OK;
 }
@@ -181,6 +182,7 @@ double adaf_get_global_option(const char* key) {
         case 9: return o.stem_rows;
         case 10: return o.split_stage1_f32;
         case 11: return o.gru_graph_persistent;
+        case 12: return o.split_lean;
         default: return __builtin_nan("");
     }
 }
@@ -1050,16 +1052,16 @@ static int gru_scan(adaf_handle* h, const float* x, int ldx, int batch, int step
         adaf_gru_scan_persistent_ok(batch, hidden, fc_w ? classes : 0, h->scan_resident)) {
         // the whole recurrence (+ classifier) in one kernel; `gh` only lends its first steps+1 words to the grid barrier
         // a scan cut into two slices (batch > 32) takes two sets of blocks, i.e. two of the slots the resident-block budget is made of
-        const int groups = (2 * steps + 2 <= batch * 3 * hidden) ? adaf_gru_scan_groups(batch, h->scan_resident) : 1;
-        const int need = groups > h->scan_slots ? h->scan_slots : groups;
+        const AdafGruScanPlan plan = adaf_gru_scan_plan(batch, steps, (size_t)batch * 3 * hidden, h->scan_resident);
+        const int need = plan.groups > h->scan_slots ? h->scan_slots : plan.groups;
         int slots[2] = {h->scan_next, (h->scan_next + 1) % h->scan_slots};
         if (!capturing) {
             h->scan_next = (h->scan_next + need) % h->scan_slots;
             for (int i = 0; i < need; ++i)
                 if (h->scan_used[slots[i]]) (void)hipStreamWaitEvent(st, h->scan_done[slots[i]], 0);   // the scans that held these slots have finished
         }
-        hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), (size_t)batch * 3 * hidden, batch, steps, fc_w,
-                                                       fc_b, logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, groups, st);
+        hipError_t e = adaf_launch_gru_scan_persistent(gi, w_hh, b_hh, h0, hs, reinterpret_cast<unsigned*>(gh), plan, batch, steps, fc_w, fc_b,
+                                                       logits_all, last, classes, h->gru_persistent == 2, h->scan_timeouts, st);
         if (e != hipSuccess) return hip_fail(h, e, "gru scan launch");
         if (!capturing) {
             for (int i = 0; i < need; ++i) {

@@ -28,6 +28,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// Ablation builds of the split tiles' production schedule (tools/exp/build_cg_abl.sh; the results are garbage, the TIME is the measurement):
+// 1 = no activation split (raw bits go to the MFMAs), 2 = no wait for the DMA before the slice barrier, 4 = no DMA inside the K loop,
+// 8 = no epilogue, 16 = no MFMAs.  The product is built with 0.
+#ifndef CG_ABL
+#define CG_ABL 0
+#endif
+
 namespace {
 
 // ---- fp32 operands on the bf16 matrix pipe (opt-in "split" tiles) -----------------------------------
@@ -570,7 +577,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM == 128 && BN == 128 && WGM * WG
 void conv_gemm_glds_kernel(const ConvArgs a) {
     static_assert(!POOL || (DENSE && !SPECIAL && ((LEAN && DT == 0) || (!LEAN && DT == 4))), "pooled epilogue: the lean dense fp32 kernel, or the dense fp16-operand kernel with fp32 features");
     static_assert(!PM || (!DENSE && (EMU == 0 || BSP) && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe, or split tiles with pre-split weights");
-    static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && EMU == 0 && !BSP && PIPE == 1), "lean K loop: plain fp32-pipe launches");
+    static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && PIPE == 1 && ((EMU == 0 && !BSP) || (EMU != 0 && BSP))),
+                  "lean K loop: plain fp32-pipe launches, or split tiles with pre-split weights");
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int AI = BM / (8 * NW);                                   // DMA instructions per wave per slice
@@ -687,7 +695,8 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
             const int plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2);
             const int n = n0 + row;
             const int q = ((lane & 3) ^ ((row >> 2) & 3)) * 8;   // bf16 elements
-            qb[j] = q; vb[j] = 0;
+            qb[j] = q;
+            vb[j] = (unsigned)((((size_t)plane * a.N + (n < a.N ? n : 0)) * a.K + q) * 2);   // LEAN: byte offset inside the bf16 planes
             if (n < a.N) {
                 pb[j] = reinterpret_cast<const float*>(a.wsp + ((size_t)plane * a.N + n) * a.K + q);
                 step_b[j] = 16;   // 32 bf16 = 16 floats per slice
@@ -753,8 +762,9 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
     };
     auto issue_one = [&](int q, int buf) {
         if (LEAN) {
-            if (q < BI)
-                lean_dma(a.w + (PM ? nx_koff : nx_kt * 32), vb[q], smem + buf * STAGE + BM * 32 + (wave + q * NW) * 8 * 32);
+            if (q < BI)     // (pre-split weights: a slice is 32 bf16 = 16 floats of a plane row)
+                lean_dma(BSP ? reinterpret_cast<const float*>(a.wsp) + (PM ? nx_koff >> 1 : nx_kt * 16) : a.w + (PM ? nx_koff : nx_kt * 32), vb[q],
+                         smem + buf * STAGE + BM * 32 + (wave + q * NW) * 8 * 32);
             else
                 lean_dma(PM ? lean_a + nx_toff : lean_a + nx_kt * 32, va[q - BI], smem + buf * STAGE + (wave + (q - BI) * NW) * 8 * 32);
             return;
@@ -846,14 +856,24 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
             constexpr bool dma = decltype(dma_tag)::value;
             u32x4 ap[3][TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) split3(ar[sb][i][0], ar[sb][i][1], ap[0][i], ap[1][i], ap[2][i]);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (CG_ABL & 1) {
+                    ap[0][i] = __builtin_bit_cast(u32x4, ar[sb][i][0]); ap[1][i] = __builtin_bit_cast(u32x4, ar[sb][i][1]); ap[2][i] = ap[0][i];
+                } else
+                    split3(ar[sb][i][0], ar[sb][i][1], ap[0][i], ap[1][i], ap[2][i]);
+            }
 #pragma unroll
             for (int t = 9 - EMU; t < 9; ++t) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(ap[TA[t]][i], bq[sb][TB[t]][j], acc[i][j]);
-                if (dma) {
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (CG_ABL & 16) {
+                            if (t == 8) acc[i][j][0] += __uint_as_float(ap[TA[t]][i].x ^ bq[sb][TB[t]][j].x);
+                        } else
+                            acc[i][j] = mfma_bf16(ap[TA[t]][i], bq[sb][TB[t]][j], acc[i][j]);
+                    }
+                if (dma && !(CG_ABL & 4)) {
                     const int g = t - (9 - EMU);
 #pragma unroll
                     for (int q = 0; q < NI; ++q)
@@ -880,7 +900,8 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
             mm(0, std::false_type{}, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (has1) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of slice k+1 landed, own reads of slice k done
+                if constexpr (CG_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA of slice k+1 landed, own reads of slice k done
                 __builtin_amdgcn_s_barrier();                                   // T_k
                 rd(0, smem + ((k + 1) & 1) * STAGE, 0);
                 if (has2) prep(k + 2);
@@ -893,6 +914,17 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         if (nk > 1) { body(k, std::true_type{}, std::false_type{}); ++k; }
         body(k, std::false_type{}, std::false_type{});
         __syncthreads();
+        if constexpr (CG_ABL & 8) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+            if (sacc == 12345.678f) a.out[0] = sacc;
+            return;
+        }
         if (PM) conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave, a.OH * a.OW, pm_p, a.pm_images);
         else conv_epilogue<TM, TN>(a, smem, acc, m0, n0, wm, wn, lane, wave);
         return;
@@ -1641,6 +1673,11 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
     // the lean K loop addresses rows with 32-bit byte offsets from a scalar base
     const bool lean = conv_lean_enabled() && (size_t)a.M * a.ldx * 4 < 0xffffff00ull && (size_t)a.N * a.K * 4 < 0xffffff00ull &&
                       (dense || (size_t)a.H * a.W * a.ldx * (size_t)(a.OH * a.OW > 0 ? a.M / (a.OH * a.OW) : 0) * 4 < 0xffffff00ull);
+    // split tiles (the 128 x 128 tile of four 32 x 128 waves, the one the split plan uses): the lean K loop with the pre-split planes
+    // addressed from a scalar base -- no pointer arithmetic on the vector ALU the split itself needs (CG_ABL 4: the DMA issue was 8 % of the
+    // split convs' time)
+    constexpr bool kLeanSplit = PIPE == 1 && EMU == 6 && BSP && BM == 128 && BN == 128 && WGM == 4 && WGN == 1;
+    const bool lean_split = kLeanSplit && lean && a.wsp && adaf_options().split_lean && (size_t)3 * a.N * a.K * 2 < 0xffffff00ull;
     if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
         // position-major tiles with padding-tap skipping: when enough images share a pixel position to fill the tile
         // rows and at least 4 % of the products are padding
@@ -1670,11 +1707,27 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
             a.pm_images = images;
             a.pm_groups = (images + BM - 1) / BM;
             a.nblocks = ohw * a.pm_groups * a.tiles_n;
+            if constexpr (kLeanSplit)
+                if (lean_split && a.pm_allow != 2) {
+                    hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 6, true, 0, true, true>), dim3(a.nblocks),
+                                       dim3(64 * WGM * WGN), 0, s, a);
+                    return;
+                }
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, false, 1, false, 6, true, 0, true>), dim3(a.nblocks), dim3(64 * WGM * WGN), 0, s, a);
             return;
         }
     }
     const bool special = a.tsm_T > 0 || (a.K & 31);
+    if constexpr (kLeanSplit) {
+        // the split tile's dense form (and ResNet's strided 1x1 downsample convs as a row gather) with the lean K loop
+        const bool strided1x1 = !dense && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride > 1 && a.tsm_T == 0 && (a.K & 31) == 0 &&
+                                (size_t)a.H * a.W * a.ldx * (size_t)(a.OH * a.OW > 0 ? a.M / (a.OH * a.OW) : 0) * 4 < 0xffffff00ull;
+        if ((dense || strided1x1) && !special && lean_split) {
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, false, 6, true, 0, false, true>), dim3(a.nblocks),
+                               dim3(64 * WGM * WGN), 0, s, a);
+            return;
+        }
+    }
     if constexpr (PIPE == 1 && EMU == 0 && !BSP) {
         // (64x64 tiles keep the builtin form: measured equal at K = 1024 and 7 % slower at K = 2048, cout 512 -- stage 4's conv1)
         // a strided 1x1 conv without padding (ResNet's downsample branch) is the same GEMM with a row gather: lean form only

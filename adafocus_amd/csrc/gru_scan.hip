@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // a plain store is only guaranteed to reach them through the end-of-kernel write-back, which a graph replay need not do between
 // two of its nodes.
 __global__ void zero_words_kernel(unsigned* p, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(p + i, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __hip_atomic_store(p + i, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int kH = 1024, kJB = 8, kGrid = kH / kJB;
@@ -266,27 +267,38 @@ int adaf_gru_scan_groups(int batch, int resident_blocks) {
     return (adaf_options().gru_scan_slices >= 2 && batch > 32 && resident_blocks >= 2 * kGrid) ? 2 : 1;
 }
 
-hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
-                                           unsigned* bar, size_t bar_words, int batch, int steps, const float* fcw, const float* fcb,
-                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, int groups,
-                                           hipStream_t s) {
-    // `bar` lends groups * (steps + 1) words to the grid barriers: the launcher checks the capacity itself (it used to trust the caller)
-    if (groups > 1 && (size_t)groups * (steps + 1) > bar_words) groups = 1;
-    if ((size_t)(steps + 1) > bar_words) return hipErrorInvalidValue;
+// The one place that decides how a scan uses its barrier buffer of `bar_words` words: how many slices (each with its own grid of kGrid
+// blocks and its own barrier records), which record layout, and how many words to clear.  gru_scan() in api.hip reserves its scan slots from
+// the same plan, so the slot accounting and the launch cannot disagree.  groups == 0: the buffer cannot hold even the single counters.
+AdafGruScanPlan adaf_gru_scan_plan(int batch, int steps, size_t bar_words, int resident_blocks) {
+    AdafGruScanPlan p{0, 0, 0};
+    if ((size_t)(steps + 1) > bar_words) return p;
+    p.groups = adaf_gru_scan_groups(batch, resident_blocks);
+    if (p.groups > 1 && (size_t)p.groups * (steps + 1) > bar_words) p.groups = 1;
     // XCD-hierarchical barrier records (17 words per step) at a pitch of 16 words (64 bytes) when the buffer has the room, packed
     // otherwise, the single counter per step when even that does not fit
-    const size_t recs = (size_t)(groups < 1 ? 1 : groups) * (steps + 1) * 17;
-    const int bpad = recs * 16 <= bar_words ? 16 : recs <= bar_words ? 1 : 0;
-    const size_t nzero = bpad ? recs * bpad : (size_t)(groups < 1 ? 1 : groups) * (steps + 1);
+    const size_t recs = (size_t)p.groups * (steps + 1) * 17;
+    p.bpad = recs * 16 <= bar_words ? 16 : recs <= bar_words ? 1 : 0;
+    p.nzero = p.bpad ? recs * p.bpad : (size_t)p.groups * (steps + 1);
+    return p;
+}
+
+hipError_t adaf_launch_gru_scan_persistent(const float* gi, const float* whh, const float* bhh, const float* h0, float* hs,
+                                           unsigned* bar, const AdafGruScanPlan& plan, int batch, int steps, const float* fcw, const float* fcb,
+                                           float* logits, float* last, int classes, bool cooperative, unsigned* timeouts, hipStream_t s) {
+    if (plan.groups < 1) return hipErrorInvalidValue;
+    const int groups = plan.groups, bpad = plan.bpad;
+    const size_t nzero = plan.nzero;
     GruScanArgs a;
     a.bpad = bpad;
     a.timeouts = timeouts;
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.h0 = h0; a.hs = hs; a.bar = bar; a.B = batch; a.T = steps;
     a.fcw = fcw; a.fcb = fcb; a.logits = logits; a.last = last; a.C = fcw ? classes : 0;
     a.cpb = fcw ? (classes + kGrid - 1) / kGrid : 0;
-    a.groups = groups < 1 ? 1 : groups;
+    a.groups = groups;
     a.bg = a.groups == 1 ? batch : ((batch + a.groups - 1) / a.groups + 31) / 32 * 32;      // whole m-tiles per slice
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(nzero > 256 ? 1024 : 64), 0, s, bar, (int)nzero);
+    const int zthreads = nzero > 256 ? 256 : 64;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nzero + zthreads - 1) / zthreads)), dim3(zthreads), 0, s, bar, (int)nzero);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (cooperative) {

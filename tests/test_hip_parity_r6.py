@@ -86,3 +86,29 @@ def test_sth_glancer_with_temporal_shift_on_strips(dev):
     gl.net._engine.fusion = True
     for fm, logit in outs[1:]:
         assert torch.equal(fm, outs[0][0]) and torch.equal(logit, outs[0][1])
+
+
+@pytest.mark.parametrize("n,p", [(8, 96), (160, 96), (130, 128)])
+def test_split_tiles_lean_k_loop_bit_identical(dev, n, p):
+    """The split tiles' K loop with the pre-split planes addressed from a scalar base (conv_gemm.hip launch_glds, option "split_lean") against
+    the pointer-per-lane form: the same DMA into the same LDS image, so the features must be equal bit for bit -- ragged row tiles (8 patches),
+    position-major tiles with a partial image group (160 = 128 + 32, 130 = 128 + 2) and the strided downsample convs included.
+    ACT/models/resnet.py:94-114,170-192."""
+    from adafocus_amd.resnet import resnet50
+    net = resnet50(num_classes=200).eval()
+    net.load_state_dict(synth_sd("ACT", 1007, "focuser.net.", keep_prefix=False), strict=True)
+    net = net.to(dev)
+    net.set_math("split_bf16")
+    x = rnd((n, 3, p, p), 900 + n).to(dev)
+    outs = []
+    with torch.no_grad():
+        for lean in (1, 0, 1):
+            with L.option("split_lean", lean):
+                outs.append(net.get_featvec(x).clone())
+        with L.option("split_lean", 1), L.option("split_stage1_f32", 0):      # every conv on the split tiles (64-channel stage 1 too)
+            all_lean = net.get_featvec(x).clone()
+        with L.option("split_lean", 0), L.option("split_stage1_f32", 0):
+            all_ptr = net.get_featvec(x).clone()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(all_lean, all_ptr)
