@@ -88,7 +88,7 @@ def test_sth_glancer_with_temporal_shift_on_strips(dev):
         assert torch.equal(fm, outs[0][0]) and torch.equal(logit, outs[0][1])
 
 
-@pytest.mark.parametrize("n,p", [(8, 96), (160, 96), (130, 128)])
+@pytest.mark.parametrize("n,p", [(8, 96), (160, 96), (130, 128), (129, 144)])
 def test_split_tiles_lean_k_loop_bit_identical(dev, n, p):
     """The split tiles' K loop with the pre-split planes addressed from a scalar base (conv_gemm.hip launch_glds, option "split_lean") against
     the pointer-per-lane form: the same DMA into the same LDS image, so the features must be equal bit for bit -- ragged row tiles (8 patches),
