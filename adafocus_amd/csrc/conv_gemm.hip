@@ -30,7 +30,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Ablation builds of the split tiles' production schedule (tools/exp/build_cg_abl.sh; the results are garbage, the TIME is the measurement):
 // 1 = no activation split (raw bits go to the MFMAs), 2 = no wait for the DMA before the slice barrier, 4 = no DMA inside the K loop,
-// 8 = no epilogue, 16 = no MFMAs.  The product is built with 0.
+// 8 = no epilogue, 16 = no MFMAs; 32 = (lean kernels of BOTH pipes) every tile reads the same 1024 activation rows, i.e. activations from L2:
+// what a launch would cost if its input never came from HBM -- the ceiling of fusing it behind its producer.  The product is built with 0.
 #ifndef CG_ABL
 #define CG_ABL 0
 #endif
@@ -656,6 +657,7 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
                 const int oy = rem / a.OW, ox = rem - oy * a.OW;
                 r = (img * a.H + oy * a.stride) * a.W + ox * a.stride;
             }
+            if constexpr ((CG_ABL & 32) != 0) r &= 1023;      // ablation: the activation rows of every tile come from the same 1024 rows (L2-resident)
             va[j] = (unsigned)(((size_t)r * (PM ? (size_t)a.H * a.W : (size_t)1) * a.ldx + qa[j]) * 4);
         } else if (DENSE) {
             if (ok) { pa[j] = a.x + (size_t)mm * a.ldx + qa[j]; step_a[j] = 32; }
