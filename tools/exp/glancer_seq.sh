@@ -3,7 +3,7 @@ set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/gseq
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/gseq -- python $R/tools/glancer_probe.py 1024 5 > /tmp/gseq.log 2>&1
+timeout 300 env ${ADAF_LIB:+ADAF_LIB=$ADAF_LIB} rocprofv3 --kernel-trace --output-format csv -d /tmp/gseq -- python $R/tools/glancer_probe.py 1024 5 > /tmp/gseq.log 2>&1
 f=$(find /tmp/gseq -name '*kernel_trace.csv' | head -1)
 python - "$f" > $OUT/r6_glancer_seq.txt <<'PY'
 import csv, sys, re
