@@ -243,14 +243,15 @@ class _Prefetcher:
 
 @torch.no_grad()
 def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
-    """Stage-3 evaluation loop of ACT/main_dist.py:307-422 (arguments, behaviour and return value: `_validate` below), run with the
-    host's intra-op thread team capped (`_HostThreads`)."""
+    """Evaluation loop of ACT/main_dist.py:307-422 for `args.train_stage` 3 (default; the documented evaluate command) or 2 (the policy's MDP
+    step by step) -- arguments, behaviour and return value: `_validate` below --, run with the host's intra-op thread team capped (`_HostThreads`)."""
     with _HostThreads():
         return _validate(dataset, model, criterion, args, rank, world, batch_size, device, quiet)
 
 
 def _validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
-    """Stage-3 evaluation (main_dist.py:307-422, branch :367-371) over this rank's shard of `dataset`
+    """Stage-3 evaluation (main_dist.py:307-422, branch :367-371; `args.train_stage == 2`: branch :343-366 through GFV.one_step_act, fp32 clips
+    only, with the per-step mAP lines of :411-418) over this rank's shard of `dataset`
     (indexable -> (images, target (L,) int64) with images either the reference's normalised fp32 ``(T*3,H,W)`` clip or
     the loader's stacked uint8 ``(H,W,T*3)`` clip, which is normalised on the GPU -- row f1).  Every rank returns the
     metrics of the WHOLE set: logits and targets are all-gathered once at the end.  The next batch is staged and copied
@@ -291,10 +292,41 @@ def _validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None,
             finish(pending)
         pending = (bi, b, loss, acc1, acc5)
 
+    stage = int(getattr(args, "train_stage", 3))
+    if stage not in (2, 3):
+        raise NotImplementedError("validate: train_stage %d (stages 0 and 1 evaluate the backbones alone / the stage-1 forward: out of scope)" % stage)
     for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
         target_full = target_full.to(dev)      # already there (and asynchronous) on the GPU path
         target = target_full[:, 0]
         b = images.shape[0]
+        if stage == 2:
+            # main_dist.py:343-366: the policy's MDP step by step through GFV.one_step_act(training=False); `pred` is the last step's
+            # last_out, the loss the last step's, every step's prediction is kept for the per-step mAP lines.  (The reference also evaluates
+            # get_reward() per step here and drops the result; nothing observable depends on it.)
+            if images.dtype == torch.uint8:
+                raise NotImplementedError("validate(train_stage=2) takes the reference's normalised fp32 (T*3,H,W) clips")
+            t = args.num_segments
+            g = getattr(args, "glance_size", images.shape[-1])
+            scan = images
+            if g != images.shape[-1]:
+                from . import hip_ops
+                scan = hip_ops.resize_nearest(images.reshape(-1, 1, images.shape[2], images.shape[3]), g).view(b, -1, g, g)
+            fmap, fvec = model.glance(scan)
+            frames = images.view(b, t, 3, images.shape[2], images.shape[3])
+            local = []
+            for s in range(t):
+                output, pred, _, _, _ = model.one_step_act(frames[:, s], fmap[:, s], fvec[:, s], restart_batch=(s == 0), training=False)
+                local.append(pred)
+            stage_next()
+            loss = criterion(output, target)
+            acc1, acc5 = accuracy(pred, target, topk=(1, 5))
+            preds.append(pred)
+            step_logits.append(torch.stack(local, 1))          # (B, T, C)
+            targets.append(target_full)
+            if pending is not None:
+                finish(pending)
+            pending = (bi, b, loss, acc1, acc5)
+            continue
         if images.dtype == torch.uint8:
             # the model's own two-stream pipeline: this batch's ingest + glancer + policy overlap the previous batch's
             # hot path; its scores are enqueued one batch late so the consumer stream never stalls the front half
@@ -341,6 +373,14 @@ def _validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None,
     if rank == 0 and not quiet:
         print(summary)
     logs.append(summary + "\n")
+    if stage == 2:         # main_dist.py:411-418: the prediction after every step of the MDP
+        all_steps = gather_variable(torch.cat(step_logits) if step_logits else torch.zeros((0, args.num_segments, ncls), device=dev)).cpu()
+        for i in range(args.num_segments):
+            m_i, _ = cal_map(all_steps[:, i, :], all_tgt if getattr(args, "dataset", "actnet") == "fcvid" else all_tgt[:, 0:1])
+            line = "mAP @ time step {step}: {mAP:.5f}\n".format(mAP=float(m_i), step=i)
+            logs.append(line)
+            if rank == 0 and not quiet:
+                print(line)
     return acc1[0].item(), acc5[0].item(), mean_ap.avg, logs
 
 

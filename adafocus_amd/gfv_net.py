@@ -15,10 +15,13 @@ execution plan of ``GFV.forward(one_step=True)`` (gfv_net.py:95-133):
              patches whose avgpool writes straight into the GRU input matrix -> HIP GRU + FC
 
 which reproduces the reference logits.  Training branches (stage 0-2 forward
-modes, reward baselines, PPO update) are out of scope and raise.
+modes, PPO update) are out of scope and raise.  ``GFV.one_step_act(training=False)`` -- the body of the
+stage-2 VALIDATION loop (ACT/main_dist.py:346-362), reward baseline included -- keeps the reference's
+per-step structure on the same HIP ops (round 6, pinned by G15).
 """
 import math
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -230,8 +233,34 @@ class GFV(nn.Module):
         fm, fv = self.glancer(input_prime.reshape(b * t, 3, hh, ww))
         return fm.unflatten(0, (b, t)), fv.view(b, t, -1)
 
-    def one_step_act(self, *a, **k):
-        raise NotImplementedError("one_step_act is the stage-2 (PPO) training loop body: out of scope")
+    @torch.no_grad()
+    def one_step_act(self, img, global_feat_map, global_feat, restart_batch=False, training=True):
+        """One step of the stage-2 loop (gfv_net.py:160-210).  training=False is the VALIDATION branch of ACT/main_dist.py:346-362:
+        policy step -> crop -> local CNN -> concat with the glancer vector -> one GRU + FC step, plus the reward baseline's logits from
+        the classifier's CURRENT state (`test_single_forward`, gfv_net.py:448-457) -- for reward = 'random' a random crop per clip
+        (`Focuser.random_patching`; origins drawn like utils.py:31-32, from numpy's global generator), for 'padding' | 'prev' | 'conf'
+        zeros in place of the local feature.  Returns (logits (B,C), last_out (B,C), None, standard action (B,2), baseline logits (B,C)).
+        training=True is the PPO roll-out of stage-2 TRAINING (memory of log-probabilities, sampled actions): out of scope."""
+        if training:
+            raise NotImplementedError("one_step_act(training=True) is the stage-2 (PPO) training loop body: out of scope")
+        b = img.shape[0]
+        local_feat, pack = self.focuser(input=img, state=global_feat_map, restart_batch=restart_batch, training=False)
+        patch_size_list, action_list = pack if pack is not None else (None, None)
+        local_feat = local_feat.view(b, -1)
+        if self.rew == "random":
+            base_local = self.focuser.random_patching(img)[0].view(b, -1)
+        elif self.rew in ("padding", "prev", "conf"):
+            base_local = torch.zeros_like(local_feat)
+        else:
+            raise NotImplementedError("reward %r" % (self.rew,))
+        if self.with_glancer:
+            feature = torch.cat([global_feat, local_feat], dim=1)
+            baseline_feature = torch.cat([global_feat, base_local], dim=1)
+        else:
+            feature, baseline_feature = local_feat, base_local
+        baseline_logits, _ = self.classifier.test_single_forward(baseline_feature.unsqueeze(1), reset=restart_batch)
+        logits, last_out = self.classifier.single_forward(feature.unsqueeze(1), reset=restart_batch)
+        return logits, last_out, patch_size_list, action_list, baseline_logits
 
     def train_mode(self, args):
         raise NotImplementedError("training modes are out of scope; use .eval()")
@@ -379,6 +408,22 @@ class Focuser(nn.Module):
         feat = self.net.features_nhwc4(get_patch_nhwc4(imgs, standard_action, self.patch_size))
         return feat.view(imgs.shape[0], -1, 1, 1), (None, standard_action)
 
+    def random_patching(self, imgs):
+        """gfv_net.py:334-336: the local CNN's feature of one random crop per image -- the reward baseline of the stage-2 loop.
+        The origins are drawn exactly like utils.py:24-35 (`np.random.randint(0, H - P)` for y, then for x, image by image; none at
+        H == P), so a seeded numpy generator reproduces the reference's crops; the crop itself is the batched HIP gather."""
+        n, hh = imgs.shape[0], imgs.shape[2]
+        span = hh - self.patch_size
+        act = np.zeros((n, 2), dtype=np.float64)
+        if span > 0:
+            for i in range(n):
+                act[i, 0] = np.random.randint(0, span)
+                act[i, 1] = np.random.randint(0, imgs.shape[3] - self.patch_size)
+            act = (act + 0.5) / span          # floor(a * (H - P)) (utils.py:42) lands on the drawn integer whatever the rounding
+        action = torch.from_numpy(act.astype(np.float32)).to(imgs.device)
+        feat = self.net.features_nhwc4(get_patch_nhwc4(imgs, action, self.patch_size))
+        return feat.view(n, -1, 1, 1), None
+
     def predict(self, input):
         return self.net(input)
 
@@ -441,3 +486,35 @@ class RecurrentClassifier(nn.Module):
         g = self.gru
         return hip_ops.gru_cls_forward(feature, g.weight_ih_l0.detach(), g.weight_hh_l0.detach(), g.bias_ih_l0.detach(),
                                        g.bias_hh_l0.detach(), self.fc.weight.detach(), self.fc.bias.detach())
+
+    def _steps_from(self, feature, hx):
+        """GRU over feature (B,t,F) from the hidden state hx ((1,B,H) or None = zeros) + FC on every step: (logits (B*t,C), last (B,C),
+        final hidden (1,B,H))."""
+        if self.training:
+            raise RuntimeError("RecurrentClassifier: eval mode only (dropout must be the identity)")
+        g = self.gru
+        b, t, _ = feature.shape
+        hs = hip_ops.gru_seq_forward(feature, g.weight_ih_l0.detach(), g.weight_hh_l0.detach(), g.bias_ih_l0.detach(), g.bias_hh_l0.detach(),
+                                     h0=None if hx is None else hx[0])
+        logits = hip_ops.linear(hs.reshape(b * t, -1), self.fc.weight.detach(), self.fc.bias.detach())
+        return logits, logits.view(b, t, -1)[:, -1, :].reshape(b, -1), hs[:, -1].unsqueeze(0).contiguous()
+
+    def _state(self, reset, b):
+        if reset:
+            self.hx = None                       # (the reference stores explicit zeros, gfv_net.py:439-440; None = the scan's zero state)
+        elif not hasattr(self, "hx"):
+            raise RuntimeError("RecurrentClassifier: no hidden state yet -- the first step needs reset=True")
+        elif self.hx is not None and self.hx.shape[1] != b:
+            raise RuntimeError("RecurrentClassifier: batch %d after a state of batch %d without reset" % (b, self.hx.shape[1]))
+        return self.hx
+
+    def single_forward(self, feature, reset=False, gpu=0):
+        """gfv_net.py:437-446: advance the stored hidden state `hx` over feature (B,t,F)."""
+        logits, last, self.hx = self._steps_from(feature, self._state(reset, feature.shape[0]))
+        return logits, last
+
+    def test_single_forward(self, feature, reset=False, gpu=0):
+        """gfv_net.py:448-457: the same step(s) from the stored state WITHOUT storing the result (the reward baseline)."""
+        hx = self._state(reset, feature.shape[0])
+        logits, last, _ = self._steps_from(feature, hx)
+        return logits, last

@@ -354,6 +354,37 @@ def act_forward(sd, images, scan, patch_size, action_dim=49, forced_action_idx=N
     return out + (torch.stack(gaps, 1),) if return_gap else out
 
 
+def act_one_step_eval(sd, img, glancer_map, glancer_vec, state, patch_size, action_dim=49, reward="random", crop_origin=None):
+    """GFV.one_step_act(img, map, vec, restart_batch, training=False) -- ACT/models/gfv_net.py:160-210, the body of the stage-2 VALIDATION
+    loop (ACT/main_dist.py:346-362), with the classifier's step functions (gfv_net.py:437-457): `test_single_forward` runs the baseline
+    feature through the GRU from the CURRENT hidden state without storing the result, `single_forward` advances it.
+    img (B,3,H,W), glancer_map (B,1280,h,w), glancer_vec (B,1280); `state` = {} at restart_batch (the zero states of ppo.py:69-70 and
+    gfv_net.py:439-440) and is updated in place.  reward: 'random' -> the baseline's local feature comes from one crop per clip at
+    `crop_origin` (B,2) integer (y, x) (utils.py:24-35 draws them with np.random.randint); 'padding' | 'prev' | 'conf' -> zeros.
+    Returns (logits (B,C), last_out (B,C), None, standard action (B,2), baseline logits (B,C))."""
+    b = img.shape[0]
+    pol = "focuser.policy.policy_old."
+    if "policy_h" not in state:
+        state["policy_h"] = img.new_zeros(b, sd[pol + "gru.weight_hh_l0"].shape[1])
+        state["hx"] = img.new_zeros(b, sd["classifier.gru.weight_hh_l0"].shape[1])
+    idx, state["policy_h"] = policy_act_discrete(sd, pol, glancer_map, state["policy_h"])
+    action = standard_actions(action_dim)[idx]
+    local = resnet50_trunk(sd, "focuser.net.", get_patch(img, action, patch_size)).view(b, -1)
+    if reward == "random":
+        crops = torch.stack([img[i, :, int(y):int(y) + patch_size, int(x):int(x) + patch_size] for i, (y, x) in enumerate(crop_origin)])
+        base_local = resnet50_trunk(sd, "focuser.net.", crops).view(b, -1)
+    elif reward in ("padding", "prev", "conf"):
+        base_local = torch.zeros_like(local)
+    else:
+        raise NotImplementedError(reward)
+    w = _gru_params(sd, "classifier.gru.")
+    fcw, fcb = sd["classifier.fc.weight"], sd["classifier.fc.bias"]
+    base_logits = F.linear(gru_cell(torch.cat([glancer_vec, base_local], 1), state["hx"], *w), fcw, fcb)
+    state["hx"] = gru_cell(torch.cat([glancer_vec, local], 1), state["hx"], *w)
+    logits = F.linear(state["hx"], fcw, fcb)
+    return logits, logits, None, action, base_logits
+
+
 def act_hot_path(sd, frames_nchw, glancer_vec, actions, patch_size):
     """The benchmarked slice of act_forward: batched crop -> local CNN -> concat -> GRU+FC.
     frames (B*T,3,H,W); glancer_vec (B,T,1280); actions (B*T,2)."""

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -100,6 +101,59 @@ def test_validate_sharded_equals_single_process():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     for r in range(2):
         assert np.allclose(ret[r], single[:3], atol=1e-4), (ret[r], single[:3])
+
+
+class _Stage2Args(_Args):
+    train_stage = 2
+
+
+class _FakeStage2(_FakeModel):
+    """The per-step surface of the stage-2 validation branch (ACT/main_dist.py:343-366): the prediction sharpens with every step and depends
+    on the steps seen since restart_batch."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def glance(self, scan):
+        b = scan.shape[0]
+        t = scan.shape[1] // 3
+        return scan.reshape(b, t, 3, 4, 4), scan.reshape(b, t, -1).mean(2, keepdim=True)
+
+    def one_step_act(self, img, fmap, fvec, restart_batch=False, training=True):
+        assert not training and img.shape[1:] == (3, 4, 4) and fmap.shape[1:] == (3, 4, 4) and fvec.shape[1:] == (1,)
+        if restart_batch:
+            self.acc, self.n = torch.zeros_like(fvec), 0
+        self.calls.append(bool(restart_batch))
+        self.acc, self.n = self.acc + img.reshape(img.shape[0], -1).mean(1, keepdim=True), self.n + 1
+        logits = torch.sin(self.acc / self.n * 37.0 + self.w * 5.0) * self.n
+        return logits, logits, None, torch.zeros(img.shape[0], 2), torch.zeros_like(logits)
+
+
+def test_validate_stage2_walks_the_mdp_step_by_step():
+    """args.train_stage = 2 (ACT/main_dist.py:343-366, 411-418): glance once, one_step_act per frame with restart_batch on the first, metrics
+    from the last step's prediction, a 'mAP @ time step' line per step -- against a hand-rolled loop over the same stand-in."""
+    data, model, args = _Data(21), _FakeStage2(), _Stage2Args()
+    top1, top5, m_ap, logs = E.validate(data, model, torch.nn.CrossEntropyLoss(), args, quiet=True)
+    nb = (21 + args.batch_size - 1) // args.batch_size
+    assert model.calls == ([True] + [False] * (args.num_segments - 1)) * nb
+    ref = _FakeStage2()
+    fm, fv = ref.glance(data.x)
+    fr = data.x.view(21, args.num_segments, 3, 4, 4)
+    steps = [ref.one_step_act(fr[:, s], fm[:, s], fv[:, s], restart_batch=(s == 0), training=False)[1] for s in range(args.num_segments)]
+    acc1, acc5 = E.accuracy(steps[-1], data.y[:, 0], topk=(1, 5))
+    want_map, _ = E.cal_map(steps[-1], data.y[:, 0:1])
+    assert abs(top1 - acc1[0].item()) < 1e-4 and abs(top5 - acc5[0].item()) < 1e-4 and abs(m_ap - float(want_map)) < 1e-4
+    lines = [ln for ln in logs if ln.startswith("mAP @ time step")]
+    assert len(lines) == args.num_segments
+    for i, ln in enumerate(lines):
+        want, _ = E.cal_map(steps[i], data.y[:, 0:1])
+        assert ln == "mAP @ time step {step}: {mAP:.5f}\n".format(mAP=float(want), step=i)
+
+    class _S1(_Args):
+        train_stage = 1
+    with pytest.raises(NotImplementedError):
+        E.validate(data, model, torch.nn.CrossEntropyLoss(), _S1(), quiet=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -874,3 +874,78 @@ def test_device_mismatch_is_refused(dev, ops):
         ops.crop_gather(x, torch.zeros((1, 2), device="cuda:1"), 32)
 
 
+
+
+@pytest.mark.parametrize("rew", ["random", "prev"])
+def test_one_step_act_validation_branch_golden(dev, rew):
+    """GFV.one_step_act(training=False): the stage-2 validation loop body (ACT/main_dist.py:346-362, ACT/models/gfv_net.py:160-210,437-457) with
+    the reference's per-step signature, against the reference's own outputs (G15, tools/gen_golden_r6.py).  reward = 'random': the baseline's
+    crops are drawn from numpy's global generator exactly like the reference's (utils.py:31-32), so the same seed gives the same crops; 'prev':
+    zeros beside the glancer vector.  The policy's arg-max margins are stored in the fixture (>= 2e-3), so actions compare unconditionally."""
+    g = golden("g15_one_step_act")
+    assert g["%s_policy_argmax_gap" % rew].min() >= 2e-3
+    m, _ = _act_model(dev, reward=rew)
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=5)).to(dev)
+    fr5 = frames.view(2, 8, 3, 224, 224)
+    state = np.random.get_state()
+    np.random.seed(int(g["np_seed"][0]))
+    try:
+        with torch.no_grad():
+            fm, fv = m.glance(frames)
+            for s in range(int(g["steps"][0])):
+                logits, last, psl, action, base = m.one_step_act(fr5[:, s], fm[:, s], fv[:, s], restart_batch=(s == 0), training=False)
+                assert psl is None and logits.shape == (2, 200) and last.shape == (2, 200) and base.shape == (2, 200)
+                assert np.array_equal(action.cpu().numpy(), g["%s_action_%d" % (rew, s)]), s
+                assert np.abs(logits.cpu().numpy() - g["%s_logits_%d" % (rew, s)]).max() < TOL, s
+                assert np.abs(last.cpu().numpy() - g["%s_last_%d" % (rew, s)]).max() < TOL, s
+                assert np.abs(base.cpu().numpy() - g["%s_baseline_%d" % (rew, s)]).max() < TOL, s
+            assert m.classifier.hx.shape == (1, 2, 1024)
+            with pytest.raises(NotImplementedError):
+                m.one_step_act(fr5[:, 0], fm[:, 0], fv[:, 0], restart_batch=True, training=True)
+    finally:
+        np.random.set_state(state)
+
+
+def test_one_step_act_steps_equal_the_offline_forward(dev):
+    """T one_step_act steps from restart_batch reproduce the batched offline forward's per-step logits (the restructuring of SURVEY §0.4
+    changes the execution plan, not the result), and the classifier's step functions refuse a step without a state."""
+    from adafocus_amd.gfv_net import RecurrentClassifier
+    m, _ = _act_model(dev, reward="prev")
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=9)).to(dev)
+    fr5 = frames.view(2, 8, 3, 224, 224)
+    with torch.no_grad():
+        ref_logits, ref_last = m.offline_forward(frames, frames)[:2]
+        fm, fv = m.glance(frames)
+        outs = []
+        for s in range(8):
+            logits, last, _, _, _ = m.one_step_act(fr5[:, s], fm[:, s], fv[:, s], restart_batch=(s == 0), training=False)
+            outs.append(logits)
+        assert (torch.stack(outs, 1).reshape(16, -1) - ref_logits).abs().max().item() < 1e-4
+        assert (last - ref_last).abs().max().item() < 1e-4
+    c = RecurrentClassifier(seq_len=8, input_dim=64, batch_size=2, hidden_dim=1024, num_classes=10, dropout=0.5).eval().to(dev)
+    with pytest.raises(RuntimeError):
+        c.single_forward(torch.zeros((2, 1, 64), device=dev), reset=False)
+
+
+def test_validate_stage2_loop_on_the_hip_model(dev):
+    """evaluate.validate with args.train_stage = 2 (ACT/main_dist.py:343-366): the MDP step by step through one_step_act on the HIP ops.  In eval
+    mode the policy never sees local features, so the last step's prediction -- hence every metric -- equals the stage-3 loop's; the per-step
+    mAP lines are there; glance_size != input_size goes through the nearest resize like the stage-3 branch."""
+    from adafocus_amd import evaluate as E
+    frames = torch.from_numpy(synth.synth_frames(3, 8, 224, seed=31))
+    labels = torch.tensor([[3], [150], [42]], dtype=torch.int64)
+
+    class DS:
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            return frames[i], labels[i]
+    for gs in (224, 160):
+        m, _ = _act_model(dev, glance_size=gs, reward="prev")
+        a3, a2 = _act_args(glance_size=gs), _act_args(glance_size=gs, train_stage=2)
+        with torch.no_grad():
+            r3 = E.validate(DS(), m, torch.nn.CrossEntropyLoss(), a3, quiet=True)
+            r2 = E.validate(DS(), m, torch.nn.CrossEntropyLoss(), a2, quiet=True)
+        assert r2[:3] == pytest.approx(r3[:3], abs=1e-4)
+        assert sum(ln.startswith("mAP @ time step") for ln in r2[3]) == 8 and not any(ln.startswith("mAP @ time step") for ln in r3[3])

@@ -186,3 +186,25 @@ def test_g14_shift_place_block():
         other = O.resnet50_trunk(csd, "n.base_model.", x, 4, 8, shift_place="blockres").flatten(1)
     np.testing.assert_allclose(feat.numpy(), g["feat"], rtol=1e-4, atol=1e-4)
     assert (other - feat).abs().max().item() > 1e-2            # the two placements are different networks
+
+
+def test_g15_one_step_act_validation_branch():
+    """The stage-2 validation loop body, GFV.one_step_act(training=False) (ACT/models/gfv_net.py:160-210, ACT/main_dist.py:346-362), for
+    both baseline kinds: the oracle's restatement against the reference's own outputs (tools/gen_golden_r6.py)."""
+    g = golden("g15_one_step_act")
+    sd = synth_sd("ACT", 1007)
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=5))
+    fr5 = frames.view(2, 8, 3, 224, 224)
+    with torch.no_grad():
+        fm, fv = O.glancer_act(sd, "glancer.net.", frames.view(16, 3, 224, 224))
+        fm, fv = fm.view(2, 8, *fm.shape[1:]), fv.view(2, 8, -1)
+        for rew in ("random", "prev"):
+            state = {}
+            for s in range(int(g["steps"][0])):
+                org = g["random_origins"][s] if rew == "random" else None
+                logits, last, psl, action, base = O.act_one_step_eval(sd, fr5[:, s], fm[:, s], fv[:, s], state, 96, reward=rew, crop_origin=org)
+                assert psl is None
+                assert np.array_equal(action.numpy(), g["%s_action_%d" % (rew, s)]), (rew, s)
+                np.testing.assert_allclose(logits.numpy(), g["%s_logits_%d" % (rew, s)], rtol=1e-4, atol=2e-5)
+                np.testing.assert_allclose(last.numpy(), g["%s_last_%d" % (rew, s)], rtol=1e-4, atol=2e-5)
+                np.testing.assert_allclose(base.numpy(), g["%s_baseline_%d" % (rew, s)], rtol=1e-4, atol=2e-5)
