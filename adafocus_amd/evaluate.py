@@ -243,8 +243,8 @@ class _Prefetcher:
 
 @torch.no_grad()
 def validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None, device=None, quiet=False):
-    """Evaluation loop of ACT/main_dist.py:307-422 for `args.train_stage` 3 (default; the documented evaluate command) or 2 (the policy's MDP
-    step by step) -- arguments, behaviour and return value: `_validate` below --, run with the host's intra-op thread team capped (`_HostThreads`)."""
+    """Evaluation loop of ACT/main_dist.py:307-422 for `args.train_stage` 3 (default; the documented evaluate command), 2 (the policy's MDP
+    step by step), 1 (the stage-1 forward) or 0 (a backbone's own classifier) -- arguments, behaviour and return value: `_validate` below --, run with the host's intra-op thread team capped (`_HostThreads`)."""
     with _HostThreads():
         return _validate(dataset, model, criterion, args, rank, world, batch_size, device, quiet)
 
@@ -293,12 +293,39 @@ def _validate(dataset, model, criterion, args, rank=0, world=1, batch_size=None,
         pending = (bi, b, loss, acc1, acc5)
 
     stage = int(getattr(args, "train_stage", 3))
-    if stage not in (2, 3):
-        raise NotImplementedError("validate: train_stage %d (stages 0 and 1 evaluate the backbones alone / the stage-1 forward: out of scope)" % stage)
+    if stage not in (0, 1, 2, 3):
+        raise NotImplementedError("validate: train_stage %d" % stage)
     for bi, images, target_full, stage_next in _Prefetcher(dataset, start, stop, bs, dev):
         target_full = target_full.to(dev)      # already there (and asynchronous) on the GPU path
         target = target_full[:, 0]
         b = images.shape[0]
+        if stage in (0, 1):
+            # main_dist.py:334-340 (stage 1: the stage-1 forward in eval mode -- glancer + focuser over all frames at once + classifier) and
+            # :372-376 (stage 0: one backbone's own classifier on the glancer-sized frames, averaged over the frames)
+            if images.dtype == torch.uint8:
+                raise NotImplementedError("validate(train_stage=%d) takes the reference's normalised fp32 (T*3,H,W) clips" % stage)
+            g = getattr(args, "glance_size", images.shape[-1])
+            scan = images
+            if g != images.shape[-1]:
+                from . import hip_ops
+                scan = hip_ops.resize_nearest(images.reshape(-1, 1, images.shape[2], images.shape[3]), g).view(b, -1, g, g)
+            if stage == 0:
+                pred = model(input=scan, scan=None, glancer=args.pretrain_glancer, backbone_pred=True, one_step=False).mean(1)
+                loss = criterion(pred, target)
+            else:
+                output, pred = model(input=images, scan=scan, training=False, backbone_pred=False, one_step=False)
+                if getattr(args, "consensus", "gru") == "gru":
+                    loss = criterion(output, target.view(b, -1).expand(b, args.num_segments).reshape(-1))
+                else:
+                    loss = criterion(output, target)
+            stage_next()
+            acc1, acc5 = accuracy(pred, target, topk=(1, 5))
+            preds.append(pred)
+            targets.append(target_full)
+            if pending is not None:
+                finish(pending)
+            pending = (bi, b, loss, acc1, acc5)
+            continue
         if stage == 2:
             # main_dist.py:343-366: the policy's MDP step by step through GFV.one_step_act(training=False); `pred` is the last step's
             # last_out, the loss the last step's, every step's prediction is kept for the per-step mAP lines.  (The reference also evaluates

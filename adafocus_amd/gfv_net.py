@@ -85,12 +85,22 @@ class GFV(nn.Module):
             x2 = x.view(b * (tc // 3), 3, hh, ww)
             net = self.glancer if kwargs.get("glancer") else self.focuser
             return net.predict(x2).view(b, tc // 3, -1)
-        if not kwargs.get("one_step"):
-            raise NotImplementedError("stage-1 training forward is out of scope (SURVEY.md §2 row 2)")
         if kwargs.get("training"):
-            raise NotImplementedError("only training=False (offline inference) is implemented")
+            raise NotImplementedError("only training=False (offline inference / validation) is implemented")
+        if not kwargs.get("one_step"):
+            # the stage-1 form (gfv_net.py:135-150) in eval mode, as validate() runs it at train_stage 1 (ACT/main_dist.py:334-340): glancer and
+            # focuser over all B*T frames at once -- random crops when the model was built with random_patch (the stage-1 configuration),
+            # else ONE policy step over the B*T frames as a batch, exactly as the reference's call does -- then the classifier
+            x, scan = kwargs["input"], kwargs["scan"]
+            b, tc, hh, ww = x.shape
+            t = tc // 3
+            with torch.no_grad():
+                fmap, fvec = self.glancer(scan.reshape(b * t, 3, scan.shape[2], scan.shape[3]))
+                local = self.focuser(input=x.reshape(b * t, 3, hh, ww), state=fmap, restart_batch=True, training=False)[0].view(b * t, -1)
+                feature = torch.cat([fvec, local], dim=1) if self.with_glancer else local
+                return self.classifier(feature.view(b, t, -1))
         if self.focuser.random:
-            raise NotImplementedError("random_patch=True is the stage-1 training configuration")
+            return None          # (gfv_net.py:108: the one_step form only has a body for a policy-driven focuser)
         return self.offline_forward(kwargs["input"], kwargs["scan"])[:2]
 
     @torch.no_grad()
@@ -400,8 +410,8 @@ class Focuser(nn.Module):
     def forward(self, *argv, **kwargs):
         """One focuser step with the reference's contract (gfv_net.py:316-331): returns
         (local feature (B,2048,1,1), (None, standard_action))."""
-        if self.random:
-            raise NotImplementedError("random patch sampling is a training-stage path")
+        if self.random:           # gfv_net.py:317-327: random crops, no policy, no action pack
+            return self.random_patching(kwargs["input"])
         action = self.policy.select_action(kwargs["state"], self.memory, kwargs["restart_batch"], kwargs["training"])
         standard_action, _ = self._get_standard_action(action)
         imgs = kwargs["input"]
@@ -409,20 +419,11 @@ class Focuser(nn.Module):
         return feat.view(imgs.shape[0], -1, 1, 1), (None, standard_action)
 
     def random_patching(self, imgs):
-        """gfv_net.py:334-336: the local CNN's feature of one random crop per image -- the reward baseline of the stage-2 loop.
-        The origins are drawn exactly like utils.py:24-35 (`np.random.randint(0, H - P)` for y, then for x, image by image; none at
-        H == P), so a seeded numpy generator reproduces the reference's crops; the crop itself is the batched HIP gather."""
-        n, hh = imgs.shape[0], imgs.shape[2]
-        span = hh - self.patch_size
-        act = np.zeros((n, 2), dtype=np.float64)
-        if span > 0:
-            for i in range(n):
-                act[i, 0] = np.random.randint(0, span)
-                act[i, 1] = np.random.randint(0, imgs.shape[3] - self.patch_size)
-            act = (act + 0.5) / span          # floor(a * (H - P)) (utils.py:42) lands on the drawn integer whatever the rounding
-        action = torch.from_numpy(act.astype(np.float32)).to(imgs.device)
+        """gfv_net.py:334-336: the local CNN's feature of one random crop per image -- the reward baseline of the stage-2 loop and the focuser of a
+        random_patch model.  Origins from `PatchSampler.random_actions` (the reference's draw order); the crop itself is the batched HIP gather."""
+        action = self.patch_sampler.random_actions(imgs)
         feat = self.net.features_nhwc4(get_patch_nhwc4(imgs, action, self.patch_size))
-        return feat.view(n, -1, 1, 1), None
+        return feat.view(imgs.shape[0], -1, 1, 1), None
 
     def predict(self, input):
         return self.net(input)
@@ -443,9 +444,28 @@ class PatchSampler(nn.Module):
 
     def sample(self, imgs, action=None):
         if self.random:
-            raise NotImplementedError("random cropping is a training-stage path")
+            return self.random_sample(imgs)
         assert action is not None
         return get_patch(imgs, action, self.size)
+
+    def random_actions(self, imgs):
+        """One crop origin per image drawn exactly like utils.py:24-35 (`np.random.randint(0, H - P)` for y, then for x, image by image; no draw
+        at H == P), returned as gather actions (origin + 0.5) / (H - P): floor(a * (H - P)) (utils.py:42) lands on the drawn integer whatever
+        the rounding.  A seeded numpy generator therefore reproduces the reference's crops."""
+        n, hh, ww = imgs.shape[0], imgs.shape[2], imgs.shape[3]
+        act = np.zeros((n, 2), dtype=np.float64)
+        if hh != self.size:
+            if hh != ww:
+                raise ValueError("random crops: square frames expected (the gather scales both axes by H - P, utils.py:40-42)")
+            for i in range(n):
+                act[i, 0] = np.random.randint(0, hh - self.size)
+                act[i, 1] = np.random.randint(0, ww - self.size)
+            act = (act + 0.5) / (hh - self.size)
+        return torch.from_numpy(act.astype(np.float32)).to(imgs.device)
+
+    def random_sample(self, imgs):
+        """gfv_net.py:376-381: a crop at a random position per image."""
+        return get_patch(imgs, self.random_actions(imgs), self.size)
 
     def forward(self, *argv, **kwargs):
         raise NotImplementedError

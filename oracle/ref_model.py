@@ -385,6 +385,25 @@ def act_one_step_eval(sd, img, glancer_map, glancer_vec, state, patch_size, acti
     return logits, logits, None, action, base_logits
 
 
+def act_stage1_eval(sd, images, scan, patch_size, action_dim=49, crop_origin=None):
+    """GFV.forward(one_step=False, training=False) -- ACT/models/gfv_net.py:135-150, the stage-1 form validate() runs at train_stage 1
+    (ACT/main_dist.py:334-340): glancer over all B*T frames, focuser over all B*T frames AT ONCE, classifier.
+    crop_origin (B*T,2) integer (y, x): a random_patch model (gfv_net.py:317-327 -> utils.py:24-35, one random crop per frame);
+    None: a policy model -- ONE ActorCritic.act step over the B*T frames as a batch from the zero hidden state."""
+    b, tc, hh, ww = images.shape
+    t = tc // 3
+    frames = images.view(b * t, 3, hh, ww)
+    fm, fv = glancer_act(sd, "glancer.net.", scan.reshape(b * t, 3, scan.shape[2], scan.shape[3]))
+    if crop_origin is not None:
+        patch = torch.stack([frames[i, :, int(y):int(y) + patch_size, int(x):int(x) + patch_size] for i, (y, x) in enumerate(crop_origin)])
+    else:
+        pol = "focuser.policy.policy_old."
+        idx, _ = policy_act_discrete(sd, pol, fm, images.new_zeros(b * t, sd[pol + "gru.weight_hh_l0"].shape[1]))
+        patch = get_patch(frames, standard_actions(action_dim)[idx], patch_size)
+    local = resnet50_trunk(sd, "focuser.net.", patch).view(b * t, -1)
+    return recurrent_classifier(sd, "classifier.", torch.cat([fv, local], dim=1).view(b, t, -1))
+
+
 def act_hot_path(sd, frames_nchw, glancer_vec, actions, patch_size):
     """The benchmarked slice of act_forward: batched crop -> local CNN -> concat -> GRU+FC.
     frames (B*T,3,H,W); glancer_vec (B,T,1280); actions (B*T,2)."""

@@ -150,10 +150,39 @@ def test_validate_stage2_walks_the_mdp_step_by_step():
         want, _ = E.cal_map(steps[i], data.y[:, 0:1])
         assert ln == "mAP @ time step {step}: {mAP:.5f}\n".format(mAP=float(want), step=i)
 
-    class _S1(_Args):
-        train_stage = 1
+    class _S4(_Args):
+        train_stage = 4
     with pytest.raises(NotImplementedError):
-        E.validate(data, model, torch.nn.CrossEntropyLoss(), _S1(), quiet=True)
+        E.validate(data, model, torch.nn.CrossEntropyLoss(), _S4(), quiet=True)
+
+
+def test_validate_stages_0_and_1_call_the_reference_forms():
+    """train_stage 1: model(input=, scan=, training=False, backbone_pred=False, one_step=False) (ACT/main_dist.py:334-340); train_stage 0:
+    model(input=scan, scan=None, glancer=args.pretrain_glancer, backbone_pred=True, one_step=False).mean(1) (:372-376)."""
+    seen = []
+
+    class M(_FakeModel):
+        def forward(self, **kw):
+            seen.append({k: (v if not torch.is_tensor(v) else tuple(v.shape)) for k, v in kw.items()})
+            if kw["backbone_pred"]:
+                b = kw["input"].shape[0]
+                return super().forward(input=kw["input"])[1][:, None, :].expand(b, _Args.num_segments, 10)
+            return super().forward(**kw)
+
+    class A1(_Args):
+        train_stage, consensus = 1, "gru"
+
+    class A0(_Args):
+        train_stage, pretrain_glancer = 0, True
+    data = _Data(9)
+    want = E.validate(data, _FakeModel(), torch.nn.CrossEntropyLoss(), _Args(), quiet=True)[:3]
+    r1 = E.validate(data, M(), torch.nn.CrossEntropyLoss(), A1(), quiet=True)[:3]
+    assert seen[0]["one_step"] is False and seen[0]["backbone_pred"] is False and seen[0]["training"] is False and seen[0]["scan"] == seen[0]["input"]
+    assert r1 == pytest.approx(want, abs=1e-4)
+    del seen[:]
+    r0 = E.validate(data, M(), torch.nn.CrossEntropyLoss(), A0(), quiet=True)[:3]
+    assert seen[0]["backbone_pred"] is True and seen[0]["glancer"] is True and seen[0]["scan"] is None and seen[0]["one_step"] is False
+    assert r0 == pytest.approx(want, abs=1e-4)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -949,3 +949,35 @@ def test_validate_stage2_loop_on_the_hip_model(dev):
             r2 = E.validate(DS(), m, torch.nn.CrossEntropyLoss(), a2, quiet=True)
         assert r2[:3] == pytest.approx(r3[:3], abs=1e-4)
         assert sum(ln.startswith("mAP @ time step") for ln in r2[3]) == 8 and not any(ln.startswith("mAP @ time step") for ln in r3[3])
+
+
+def test_stage1_form_in_eval_mode_golden(dev):
+    """GFV.forward(one_step=False, training=False) -- the stage-1 form validate() runs at train_stage 1 (ACT/models/gfv_net.py:135-150,
+    ACT/main_dist.py:334-340) -- against the reference (G15): a random_patch model with numpy seeded like the generator (same crops), and a
+    policy model (ONE policy step over the B*T frames as a batch; margins stored in the fixture).  PatchSampler's random branch too."""
+    g = golden("g15_one_step_act")
+    assert g["s1_policy_argmax_gap"].min() >= 2e-3
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=int(g["s1_seed_frames"][0]))).to(dev)
+    state = np.random.get_state()
+    try:
+        m, _ = _act_model(dev, random_patch=True)
+        assert m.focuser.policy is None
+        np.random.seed(int(g["np_seed"][0]) + 1)
+        with torch.no_grad():
+            lg, last = m(input=frames, scan=frames, training=False, backbone_pred=False, one_step=False)
+        assert np.abs(lg.cpu().numpy() - g["s1_random_logits"]).max() < TOL and np.abs(last.cpu().numpy() - g["s1_random_last"]).max() < TOL
+        # the sampler's random branch draws in the reference's order: same seed -> the recorded origins
+        np.random.seed(int(g["np_seed"][0]) + 1)
+        x = frames.view(16, 3, 224, 224)
+        crops = m.focuser.patch_sampler.sample(x)
+        for i, (y, xx) in enumerate(g["s1_random_origins"]):
+            assert torch.equal(crops[i], x[i, :, y:y + 96, xx:xx + 96]), i
+        assert m(input=frames, scan=frames, training=False, backbone_pred=False, one_step=True, gpu=0) is None      # (gfv_net.py:108: no body)
+        with pytest.raises(NotImplementedError):
+            m(input=frames, scan=frames, training=True, backbone_pred=False, one_step=False)
+        m, _ = _act_model(dev)
+        with torch.no_grad():
+            lg, last = m(input=frames, scan=frames, training=False, backbone_pred=False, one_step=False)
+        assert np.abs(lg.cpu().numpy() - g["s1_policy_logits"]).max() < TOL and np.abs(last.cpu().numpy() - g["s1_policy_last"]).max() < TOL
+    finally:
+        np.random.set_state(state)

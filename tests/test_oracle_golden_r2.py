@@ -208,3 +208,18 @@ def test_g15_one_step_act_validation_branch():
                 np.testing.assert_allclose(logits.numpy(), g["%s_logits_%d" % (rew, s)], rtol=1e-4, atol=2e-5)
                 np.testing.assert_allclose(last.numpy(), g["%s_last_%d" % (rew, s)], rtol=1e-4, atol=2e-5)
                 np.testing.assert_allclose(base.numpy(), g["%s_baseline_%d" % (rew, s)], rtol=1e-4, atol=2e-5)
+
+
+def test_g15_stage1_form_in_eval_mode():
+    """GFV.forward(one_step=False, training=False) (ACT/models/gfv_net.py:135-150) for a random_patch model (the recorded numpy crops) and for
+    a policy model (one policy step over the B*T frames): the oracle's restatement against the reference's outputs."""
+    g = golden("g15_one_step_act")
+    sd = synth_sd("ACT", 1007)
+    frames = torch.from_numpy(synth.synth_frames(2, 8, 224, seed=int(g["s1_seed_frames"][0])))
+    with torch.no_grad():
+        lg, last = O.act_stage1_eval(sd, frames, frames, 96, crop_origin=g["s1_random_origins"])
+        np.testing.assert_allclose(lg.numpy(), g["s1_random_logits"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(last.numpy(), g["s1_random_last"], rtol=1e-4, atol=2e-5)
+        lg, last = O.act_stage1_eval(sd, frames, frames, 96)
+        np.testing.assert_allclose(lg.numpy(), g["s1_policy_logits"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(last.numpy(), g["s1_policy_last"], rtol=1e-4, atol=2e-5)
