@@ -352,9 +352,15 @@ class PatchSampler(nn.Module):
 
     def sample(self, imgs, action=None):
         if self.random:
-            raise NotImplementedError("random cropping is a training-stage path")
+            return self.random_sample(imgs)
         assert action is not None
         return get_patch(imgs, action, self.size)
+
+    def random_sample(self, imgs):
+        """STH/models/gfv_net.py:455-474: one crop per image at an origin drawn like STH/models/utils.py's random_crop (np.random.randint for y,
+        then x; the draw and the (origin + 0.5) / (H - P) gather actions are the ActivityNet sampler's, adafocus_amd/gfv_net.py)."""
+        from .gfv_net import PatchSampler as _ActSampler
+        return get_patch(imgs, _ActSampler.random_actions(self, imgs), self.size)
 
     def forward(self, *argv, **kwargs):
         raise NotImplementedError("Policy driven patch sampler not implemented.")

@@ -981,3 +981,22 @@ def test_stage1_form_in_eval_mode_golden(dev):
         assert np.abs(lg.cpu().numpy() - g["s1_policy_logits"]).max() < TOL and np.abs(last.cpu().numpy() - g["s1_policy_last"]).max() < TOL
     finally:
         np.random.set_state(state)
+
+
+def test_sth_patch_sampler_random_branch(dev):
+    """STH/models/gfv_net.py:455-474: PatchSampler(random=True).sample crops every (B, 3T, H, W) clip at an origin drawn like the reference's
+    random_crop (np.random.randint for y, then x)."""
+    from adafocus_amd.gfv_net_sth import PatchSampler
+    x = rnd((3, 12, 224, 224), 77).to(dev)
+    ps = PatchSampler(128, True)
+    state = np.random.get_state()
+    try:
+        np.random.seed(99)
+        want = [(np.random.randint(0, 96), np.random.randint(0, 96)) for _ in range(3)]
+        np.random.seed(99)
+        got = ps.sample(x)
+    finally:
+        np.random.set_state(state)
+    assert got.shape == (3, 12, 128, 128)
+    for i, (y, xx) in enumerate(want):
+        assert torch.equal(got[i], x[i, :, y:y + 128, xx:xx + 128]), i
