@@ -96,6 +96,7 @@ struct AdafOptions {
     int stem_rows = 1;            // "stem_rows": stem + max-pool over whole-width strips walked down the image (stem.hip, round 5); 0 = the tile form, 2 = also below one image per CU (tests)
     int split_stage1_f32 = 1;     // "split_stage1_f32": the split-bf16 trunk takes the fp32 pipe's fused stage-1 launches (api.hip run_trunk)
     int split_lean = 1;           // "split_lean": the split tiles' K loop with scalar-base DMA (conv_gemm.hip launch_glds; 0 = the pointer-per-lane form, A/B)
+    int tsm_lean = 1;             // "tsm_lean": a conv1 with the fused temporal shift on the lean K loop (range-checked buffer DMA; conv_gemm.hip launch_glds; 0 = the per-lane select form, A/B)
     int gru_graph_persistent = 0; // "gru_graph_persistent": 1 = a stream capture keeps the persistent GRU scan (the caller guarantees exclusive use of the device
                                   // while the graph replays); 0 = captures take the launch-per-step form, which has no grid barrier to starve
     int gru_scan_slices = 2;      // "gru_scan_slices": clip slices a persistent GRU scan may be cut into (1 | 2; gru_scan.hip)

@@ -80,7 +80,7 @@ struct OptKey { const char* name; double lo, hi; };
 // (round 6: the switches that measured as no-gain and had no user are gone -- conv_lean, pm_fill, resize_lds_kb, mb_wave, dw3_variant, gru_barrier)
 const OptKey kOptKeys[] = {{"conv_pool", 0, 1}, {"mb_strip", 0, 1}, {"mbv2_chunk", 1, 1 << 20}, {"latency_rows", 0, 1 << 30}, {"latency_linear_rows", 0, 1 << 30},
                            {"effnet_plan", 0, 511}, {"effnet_chunk", 1, 1 << 20}, {"gru_scan_slices", 1, 2}, {"effnet_fused_blocks", 0, 4294967295.0},
-                           {"stem_rows", 0, 2}, {"split_stage1_f32", 0, 1}, {"gru_graph_persistent", 0, 1}, {"split_lean", 0, 1}};
+                           {"stem_rows", 0, 2}, {"split_stage1_f32", 0, 1}, {"gru_graph_persistent", 0, 1}, {"split_lean", 0, 1}, {"tsm_lean", 0, 1}};
 int find_opt(const char* key) {
     if (!key) return -1;
     for (size_t i = 0; i < sizeof(kOptKeys) / sizeof(kOptKeys[0]); ++i)
@@ -162,7 +162,8 @@ int adaf_set_global_option(const char* key, double value) {
         case 9: o.stem_rows = (int)value; break;
         case 10: o.split_stage1_f32 = (int)value; break;
         case 11: o.gru_graph_persistent = (int)value; break;
-        default: o.split_lean = (int)value; break;
+        case 12: o.split_lean = (int)value; break;
+        default: o.tsm_lean = (int)value; break;
     }
     return ADAF_OK;
 }
@@ -183,6 +184,7 @@ double adaf_get_global_option(const char* key) {
         case 10: return o.split_stage1_f32;
         case 11: return o.gru_graph_persistent;
         case 12: return o.split_lean;
+        case 13: return o.tsm_lean;
         default: return __builtin_nan("");
     }
 }

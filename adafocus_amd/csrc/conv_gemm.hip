@@ -578,8 +578,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM == 128 && BN == 128 && WGM * WG
 void conv_gemm_glds_kernel(const ConvArgs a) {
     static_assert(!POOL || (DENSE && !SPECIAL && ((LEAN && DT == 0) || (!LEAN && DT == 4))), "pooled epilogue: the lean dense fp32 kernel, or the dense fp16-operand kernel with fp32 features");
     static_assert(!PM || (!DENSE && (EMU == 0 || BSP) && PIPE == 1), "position-major tiles: k x k filters on the fp32 pipe, or split tiles with pre-split weights");
-    static_assert(!LEAN || ((DENSE || PM) && !SPECIAL && PIPE == 1 && ((EMU == 0 && !BSP) || (EMU != 0 && BSP))),
-                  "lean K loop: plain fp32-pipe launches, or split tiles with pre-split weights");
+    static_assert(!LEAN || ((DENSE || PM) && PIPE == 1 && ((EMU == 0 && !BSP) || (EMU != 0 && BSP)) &&
+                            (!SPECIAL || (DENSE && EMU == 0 && DT == 0 && !POOL))),
+                  "lean K loop: plain fp32-pipe launches, split tiles with pre-split weights, or (LEAN + SPECIAL) the fp32 pipe's temporally shifted conv1");
+    // LEAN + SPECIAL = the lean K loop for a conv1 with the fused temporal shift (K and the shifted fold multiples of 32, checked by the launcher):
+    // the activations are DMA-ed with the RANGE-CHECKED buffer form (buffer_load_dwordx4 ... lds), which writes ZEROS to LDS for a lane whose
+    // offset is out of range (tools/exp/buffer_load_lds_oob.hip) -- so the rows at clip ends get their zeros from a constant per-lane offset
+    // instead of a per-lane source select per slice: three constant offsets per row (own frame, next frame, previous frame), a wave-uniform
+    // choice per slice, the slice's position in the SGPR offset.
+    constexpr bool LTSM = LEAN && SPECIAL;
     constexpr int NW = WGM * WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int AI = BM / (8 * NW);                                   // DMA instructions per wave per slice
@@ -633,6 +640,7 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
     const int lr = lane >> 3;   // row within the 8-row group
     const int ls = lane & 7;    // LDS chunk slot
     unsigned va[AI], vb[BI];    // LEAN: constant per-lane byte offsets of the activation / weight rows
+    unsigned vnx[LTSM ? AI : 1], vpv[LTSM ? AI : 1];   // LTSM: the same row in the next / previous frame, or out of range at a clip end
     const float* lean_a = a.x;  // LEAN: wave-uniform base of the activation rows (PM: moved to the tile's first tap)
     if (LEAN && PM) lean_a = a.x + ((long long)pm_iy0 * a.W + pm_ix0) * a.ldx;
     const float* pa[AI];        // DENSE: running source pointer (or the zero block)
@@ -659,6 +667,12 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
             }
             if constexpr ((CG_ABL & 32) != 0) r &= 1023;      // ablation: the activation rows of every tile come from the same 1024 rows (L2-resident)
             va[j] = (unsigned)(((size_t)r * (PM ? (size_t)a.H * a.W : (size_t)1) * a.ldx + qa[j]) * 4);
+            if constexpr (LTSM) {
+                const int t = (mm / a.tsm_hw) % a.tsm_T;
+                const unsigned sh = (unsigned)((size_t)a.tsm_hw * a.ldx * 4);
+                vnx[j] = (ok && t < a.tsm_T - 1) ? va[j] + sh : 0x7ffffff0u;      // (out of range: the buffer form writes zeros)
+                vpv[j] = (ok && t > 0) ? va[j] - sh : 0x7ffffff0u;
+            }
         } else if (DENSE) {
             if (ok) { pa[j] = a.x + (size_t)mm * a.ldx + qa[j]; step_a[j] = 32; }
             if (a.tsm_T > 0) {
@@ -720,6 +734,8 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
 
     // per-slice wave-uniform state of the NEXT slice's DMA (set by prep)
     bool nx_tsm = false, nx_tail = false;
+    int ltsm_ty = -1;           // LTSM: kind of the slice whose offsets are in vcur (0 next frame, 1 previous frame, 2 own frame)
+    unsigned vcur[LTSM ? AI : 1];
     int nx_kt = 0, nx_tap = 0, nx_c0 = 0, nx_kh = 0, nx_kw = 0;
     int nx_koff = 0;            // PM: offset of the slice inside a filter row (taps are skipped, so it is not 32 * kt)
     long long nx_toff = 0;
@@ -728,6 +744,17 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         nx_tail = SPECIAL && DENSE && (kt + 1) * 32 > a.K;      // last, partial slice of a K that is not a multiple of 32
         if (DENSE) {
             nx_tsm = SPECIAL && a.tsm_T > 0 && kt * 32 < 2 * a.tsm_fold;
+            if (LTSM) {
+                // the slice's kind changes twice per tile (at the fold boundaries): the lane offsets in use are swapped there, under a real
+                // branch, so the K loop carries no select
+                const int ty = kt * 32 < a.tsm_fold ? 0 : nx_tsm ? 1 : 2;
+                if (ty != ltsm_ty) {
+                    asm volatile("");
+                    ltsm_ty = ty;
+#pragma unroll
+                    for (int j = 0; j < AI; ++j) vcur[j] = ty == 0 ? vnx[j] : ty == 1 ? vpv[j] : va[j];
+                }
+            }
         } else {
             // one filter tap per slice (cin % 32 == 0); prep() is called for kt = 0, 1, 2, ... so the
             // (tap, channel offset) pair is advanced incrementally -- scalar adds, no division
@@ -763,6 +790,17 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory", "m0");   // (m0 is named so that the compiler does not merge its own M0 initialisations across this block; the "reserved register" warning is expected)
     };
     auto issue_one = [&](int q, int buf) {
+        if (LTSM && q >= BI) {
+            // buffer_load_dwordx4 voffset, s[rsrc], soffset offen lds -- written out (the compiler's builtin for it makes the HOST pass drop
+            // every stub of this template without a diagnostic).  Descriptor: base, stride 0, num_records = the tensor's bytes, raw 32-bit format.
+            const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((buf * STAGE + (wave + (q - BI) * NW) * 8 * 32) * 4));
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(nx_kt * 128);
+            const unsigned long long b = (unsigned long long)a.x;
+            const u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu),
+                              (unsigned)__builtin_amdgcn_readfirstlane((unsigned)((size_t)a.M * a.ldx * 4)), 0x00020000u};
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(l), "v"(vcur[q - BI]), "s"(rs), "s"(soff) : "memory", "m0");
+            return;
+        }
         if (LEAN) {
             if (q < BI)     // (pre-split weights: a slice is 32 bf16 = 16 floats of a plane row)
                 lean_dma(BSP ? reinterpret_cast<const float*>(a.wsp) + (PM ? nx_koff >> 1 : nx_kt * 16) : a.w + (PM ? nx_koff : nx_kt * 32), vb[q],
@@ -1737,6 +1775,16 @@ void launch_glds(ConvArgs a, bool dense, hipStream_t s) {
                                 (size_t)a.H * a.W * a.ldx * (size_t)(a.OH * a.OW > 0 ? a.M / (a.OH * a.OW) : 0) * 4 < 0xffffff00ull;
         if ((dense || strided1x1) && !special && lean && conv_lean_enabled() == 1 && BM * BN > 64 * 64) {
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, false, 0, false, 0, false, true>), dim3(a.nblocks),
+                               dim3(64 * WGM * WGN), 0, s, a);
+            return;
+        }
+    }
+    if constexpr (PIPE == 1 && EMU == 0 && !BSP && BM * BN > 64 * 64) {
+        // a conv1 with the fused temporal shift on the lean K loop (round 6): whole 32-channel slices on either side of the fold boundaries, every
+        // row's frame neighbours inside the tensor (2 GB: the buffer form's offsets stay below the out-of-range marker)
+        if (dense && a.tsm_T > 0 && (a.K & 31) == 0 && (a.tsm_fold & 31) == 0 && a.stride == 1 && lean && adaf_options().tsm_lean &&
+            (size_t)a.M * a.ldx * 4 < 0x7fff0000ull) {
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WGM, WGN, true, 1, true, 0, false, 0, false, true>), dim3(a.nblocks),
                                dim3(64 * WGM * WGN), 0, s, a);
             return;
         }

@@ -76,7 +76,7 @@ int adaf_set_conv_pos_major(adaf_handle* h, int on);
  * signature.  The defaults are the plan every reported number is measured with; INTEGRATION.md lists them.  Keys:
  *   "conv_pool" 0|1, "mb_strip" 0|1 (strip-walking front kernels of the glancer), "mbv2_chunk", "latency_rows", "latency_linear_rows",
  *   "effnet_plan" (ADAF_EF_PLAN_* bits), "effnet_chunk", "gru_scan_slices" 1|2, "effnet_fused_blocks" (bit b = MBConv block b may use the fused
- *   expand + depthwise launch), "stem_rows" 0|1|2, "split_stage1_f32" 0|1 (see adaf_resnet50_set_math), "split_lean" 0|1 (the split tiles' lean K loop; bit-identical A/B), "gru_graph_persistent" 0|1 (1 = a
+ *   expand + depthwise launch), "stem_rows" 0|1|2, "split_stage1_f32" 0|1 (see adaf_resnet50_set_math), "split_lean" 0|1 (the split tiles' lean K loop; bit-identical A/B), "tsm_lean" 0|1 (a temporally shifted conv1 on the lean K loop; bit-identical A/B), "gru_graph_persistent" 0|1 (1 = a
  *   stream capture keeps the persistent GRU scan; default 0: captured scans take the launch-per-step form, which has no grid barrier).
  * adaf_set_global_option returns ADAF_E_BADARG for an unknown key or a value out of range; adaf_get_global_option returns the current value
  * (NaN for an unknown key).  Not thread-safe against concurrent launches: set options between forwards.

@@ -112,3 +112,27 @@ def test_split_tiles_lean_k_loop_bit_identical(dev, n, p):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert torch.equal(all_lean, all_ptr)
+
+
+@pytest.mark.parametrize("n,p,seg", [(16, 96, 8), (24, 144, 12), (160, 128, 8), (21, 128, 3)])
+def test_shifted_conv1_lean_k_loop_bit_identical(dev, n, p, seg):
+    """A conv1 with the fused temporal shift on the lean K loop (conv_gemm.hip LEAN + SPECIAL, option "tsm_lean"): the activations arrive through the
+    range-checked buffer form of the LDS DMA, which writes zeros for the rows at clip ends, instead of a per-lane source select -- the same bytes in
+    the same LDS image, so the trunk's features must be equal bit for bit to the select form's, for whole clips, ragged row tiles and clips of 3
+    frames (every frame a clip end for one of the two shifted folds).  STH/ops/temporal_shift.py:28-46, STH/models/tsn.py:215-241."""
+    from adafocus_amd.resnet import resnet50
+    net = resnet50(num_classes=200).eval()
+    net.load_state_dict(synth_sd("ACT", 1007, "focuser.net.", keep_prefix=False), strict=True)
+    net = net.to(dev)
+    net.tsm_segments = seg
+    x = rnd((n, 3, p, p), 700 + n).to(dev)
+    outs = []
+    with torch.no_grad():
+        for lean in (1, 0, 1):
+            with L.option("tsm_lean", lean):
+                outs.append(net.get_featvec(x).clone())
+        net.tsm_segments = 0
+        plain = net.get_featvec(x).clone()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not torch.equal(outs[0], plain)          # (the shift is really there)
