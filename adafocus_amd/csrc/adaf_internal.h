@@ -255,9 +255,10 @@ bool adaf_conv_tile_exists(int tile);   // is `tile` an id adaf_launch_conv_gemm
 void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s);
 // conv2 3x3 (64 -> 64) -> conv3 1x1 (+ identity, ReLU) [-> the next block's conv1 1x1] in one launch (stage 1 of the trunk);
 // returns 0 or < 0 when the shape is not eligible
+bool adaf_fused_tail_shift_ok(const ConvArgs& c2, int n3, int ldr, int tsm_T1, int tsm_fold1);
 int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3, const float* b3, const float* res, int ldr,
                            float* out, int n3, const float* w1n, const float* s1n, const float* b1n, float* out1, int n1,
-                           hipStream_t s);
+                           hipStream_t s, int tsm_T1 = 0, int tsm_fold1 = 0);
 
 // crop.hip
 hipError_t adaf_launch_crop(const float* frames, int nf, int C, int H, int W, const float* act, int fpa, int P,

@@ -723,15 +723,19 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
                 ConvArgs a2;
                 if ((rc = make_conv_args(h, &p, t1, L2.w, L2.scale, L2.bias, nullptr, t2, &a2))) return rc;
                 // the next block's conv1 rides along unless it carries a temporal shift or a tile override
-                const ConvLayer* Ln = (tsm_T == 0 && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;   // (either placement)
+                // ('block' placement: the next block reads a shifted COPY of this block's output, so its conv1 cannot ride; 'blockres': it rides
+                //  with the shift as a row offset inside the tile when clips divide the 128-image tiles -- the launcher says -2 otherwise)
+                const ConvLayer* Ln = ((tsm_T == 0 || (tsm_c1 > 0 && 128 % tsm_c1 == 0)) && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;
                 if (Ln && !(Ln->k == 1 && Ln->stride == 1 && Ln->cin == L3.cout && (Ln->cout == 64 || Ln->cout == 128))) Ln = nullptr;
+                const int tsm_n1 = (Ln && tsm_c1 > 0) ? tsm_c1 : 0, fold_n1 = Ln ? Ln->cin / (tsm_div > 0 ? tsm_div : 8) : 0;
+                if (tsm_n1 && !adaf_fused_tail_shift_ok(a2, L3.cout, L3.cout, tsm_n1, fold_n1)) Ln = nullptr;
                 const double M = (double)a2.M;
                 double macs = M * 64 * 9 * 64 + M * L3.cout * 64 + (Ln ? M * Ln->cout * L3.cout : 0.0);
                 double bytes = 4.0 * (M * 64 + 2.0 * M * L3.cout + (Ln ? M * Ln->cout : 0.0) + 64.0 * 576 + 64.0 * L3.cout +
                                       (Ln ? (double)Ln->cout * L3.cout : 0.0));
                 mark(2.0 * macs, bytes, Ln ? 92 : 91);
                 if (adaf_launch_fused_tail(a2, L3.w, L3.scale, L3.bias, identity, L3.cout, nxt, L3.cout, Ln ? Ln->w : nullptr,
-                                           Ln ? Ln->scale : nullptr, Ln ? Ln->bias : nullptr, t2, Ln ? Ln->cout : 0, st) < 0)
+                                           Ln ? Ln->scale : nullptr, Ln ? Ln->bias : nullptr, t2, Ln ? Ln->cout : 0, st, Ln ? tsm_n1 : 0, fold_n1) < 0)
                     return fail(h, ADAF_E_LAUNCH, "resnet50: fused bottleneck tail rejected the shape");
                 h3 = a2.OH; w3 = a2.OW;
                 if (Ln) { float* t = t1; t1 = t2; t2 = t; c1_done = true; }

@@ -1186,8 +1186,10 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
 // Every product keeps the k order of the unfused kernels, so the results are BIT-IDENTICAL to the three separate
 // launches (tests: test_resnet50_fused_launches_bit_identical).  Three blocks fit a CU for N1 = 0 / 64 (48 KB of LDS: the
 // phase-2 image is exactly the phase-1 ring, the epilogue's transposition slab lives in the dead half of the A2 image), two
-// for N1 = 128 (56 KB), so one block's HBM-heavy phase 2 overlaps the others' MFMA-heavy phase 1.  The next conv1 cannot ride
-// along when it carries a fused temporal shift (its rows come from other clips' frames): N1 = 0 then.
+// for N1 = 128 (56 KB), so one block's HBM-heavy phase 2 overlaps the others' MFMA-heavy phase 1.  A next conv1 that carries the fused
+// temporal shift rides along in the position-major form when clips divide the 128-image tiles (round 6): a tile's rows are the same pixel of 128
+// CONSECUTIVE frames, so the shifted channels of row r are rows r + 1 / r - 1 of the SAME chunk image (zeros at clip ends, which then include the
+// tile's first and last row) -- phase 3 reads them with a row offset.  Otherwise (other clip lengths, row-major tiles): N1 = 0.
 struct FusedTailArgs {
     ConvArgs c2;          // the 3x3 conv (x, w, scale, bias, geometry; N = 64, K = 9 * 64)
     const float* w3;      // [n3][64]
@@ -1201,6 +1203,8 @@ struct FusedTailArgs {
     const float* b1n;
     float* out1;          // [M][N1]
     int act1n;
+    int tsm_T1;           // > 0: the next conv1 carries the fused temporal shift over clips of tsm_T1 frames (PM tiles only, 128 % tsm_T1 == 0)
+    int tsm_np1;          // conv3 passes (32 channels each) per shifted fold: passes [0, np1) read the NEXT frame's rows, [np1, 2 np1) the previous frame's
 };
 
 // PM: position-major tiles (the 128 rows of a tile are one output pixel of 128 consecutive images): the 3x3 gather then has
@@ -1576,11 +1580,26 @@ __global__ __launch_bounds__(256, N1 == 128 ? 2 : 3) void conv_fused_tail_kernel
         if (!W3DB && np + 1 < npass) issue_w3(np + 1);
         if (N1) {
             // ---- next conv1: acc1 += chunk[128 x 32] x W1n[:, 32 np ..]^T, wave tile 64 x N1/2
+            const int tsm_dr = (PM && fa.tsm_T1 > 0) ? (np < fa.tsm_np1 ? 1 : np < 2 * fa.tsm_np1 ? -1 : 0) : 0;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 f32x4 af[TM], bf[TN1 ? TN1 : 1];
+                if (PM && tsm_dr != 0) {
+                    // shifted channels: the neighbouring frame's row of the chunk image (its own swizzle), zeros at a clip end
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(A2 + (wm * 64 + i * 32) * 32 + foff[kk]);
+                    for (int i = 0; i < TM; ++i) {
+                        const int arow = wm * 64 + i * 32 + (lane & 31);
+                        const int t = (m0 + arow) % fa.tsm_T1;
+                        const bool ok = tsm_dr > 0 ? t < fa.tsm_T1 - 1 : t > 0;
+                        const int nrow = ok ? arow + tsm_dr : arow;
+                        const int swn = (nrow >> 1) & 7;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(A2 + nrow * 32 + (((2 * kk + (lane >> 5)) ^ swn) << 2));
+                        af[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(A2 + (wm * 64 + i * 32) * 32 + foff[kk]);
+                }
 #pragma unroll
                 for (int j = 0; j < TN1; ++j) bf[j] = *reinterpret_cast<const f32x4*>(W1s + (wn * TN1 * 32 + j * 32) * 32 + foff[kk]);
 #pragma unroll
@@ -2003,9 +2022,29 @@ void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s) {
 }
 
 // Launcher of conv_fused_tail_kernel: c2 = the 3x3 conv's flattened description (64 -> 64, cin % 32 == 0, 16-byte epilogue legal).
+// position-major tiles when the images fill the 128-row groups (<= 6 % padding rows): no tap masks in the gather
+static bool fused_tail_pm(const ConvArgs& c2, int n3, int ldr, int* images_out, int* groups_out) {
+    const int ohw = c2.OH * c2.OW;
+    const int images = ohw > 0 ? c2.M / ohw : 0;
+    const int groups = (images + 127) / 128;
+    *images_out = images;
+    *groups_out = groups;
+    return c2.pm_allow == 1 && conv_lean_enabled() != 0 && images * ohw == c2.M && images >= 128 && ohw <= 4096 &&
+           (long long)groups * 128 * 100 <= (long long)images * 106 && (size_t)ohw * 8 * (size_t)(n3 > ldr ? n3 : ldr) * 4 < 0xffffff00ull;
+}
+
+// May the next block's conv1 ride in the fused tail although it carries the fused temporal shift (clips of tsm_T1 frames, fold of tsm_fold1
+// channels)?  Only in the position-major form, with clips dividing the 128-image tiles and whole 32-channel passes per fold.
+bool adaf_fused_tail_shift_ok(const ConvArgs& c2, int n3, int ldr, int tsm_T1, int tsm_fold1) {
+    int images, groups;
+    return adaf_options().tsm_lean && tsm_T1 > 0 && fused_tail_pm(c2, n3, ldr, &images, &groups) && 128 % tsm_T1 == 0 && images % tsm_T1 == 0 &&
+           tsm_fold1 > 0 && tsm_fold1 % 32 == 0 && 2 * tsm_fold1 <= n3;
+}
+
+// tsm_T1 > 0: the next conv1 (w1n) carries the fused temporal shift (adaf_fused_tail_shift_ok must hold: -2 otherwise, nothing launched).
 int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3, const float* b3, const float* res, int ldr,
                            float* out, int n3, const float* w1n, const float* s1n, const float* b1n, float* out1, int n1,
-                           hipStream_t s) {
+                           hipStream_t s, int tsm_T1, int tsm_fold1) {
     if (c2.N != 64 || c2.cin != 64 || (c2.K & 31) || c2.KH * c2.KW > 32 || n3 % 32 || (n1 != 0 && n1 != 64 && n1 != 128)) return -1;
     // scalar-base accesses: 32-bit lane offsets
     if ((size_t)c2.M * c2.ldx * 4 >= 0xffffff00ull || (size_t)c2.M * n3 * 4 >= 0x3fffffffull * 4 || (size_t)n3 * 128 * 4 >= 0xffffff00ull)
@@ -2017,12 +2056,15 @@ int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3,
     fa.c2.vec_epi = conv_lean_enabled() == 1 ? 2 : 1;       // the next block's conv1 tile goes out through the lean epilogue
     fa.w3 = w3; fa.s3 = s3; fa.b3 = b3; fa.res = res; fa.out = out; fa.n3 = n3; fa.ldr = ldr;
     fa.w1n = w1n; fa.s1n = s1n; fa.b1n = b1n; fa.out1 = out1; fa.act1n = ADAF_ACT_RELU;
-    // position-major tiles when the images fill the 128-row groups (<= 6 % padding rows): no tap masks in the gather
     const int ohw = c2.OH * c2.OW;
-    const int images = ohw > 0 ? c2.M / ohw : 0;
-    const int groups = (images + 127) / 128;
-    const bool pm = c2.pm_allow == 1 && conv_lean_enabled() != 0 && images * ohw == c2.M && images >= 128 && ohw <= 4096 &&
-                    (long long)groups * 128 * 100 <= (long long)images * 106 && (size_t)ohw * 8 * (size_t)(n3 > ldr ? n3 : ldr) * 4 < 0xffffff00ull;
+    int images, groups;
+    const bool pm = fused_tail_pm(c2, n3, ldr, &images, &groups);
+    fa.tsm_T1 = 0; fa.tsm_np1 = 0;
+    if (n1 != 0 && tsm_T1 > 0) {
+        if (!adaf_fused_tail_shift_ok(c2, n3, ldr, tsm_T1, tsm_fold1)) return -2;
+        fa.tsm_T1 = tsm_T1;
+        fa.tsm_np1 = tsm_fold1 / 32;
+    }
     if (pm) {
         fa.c2.pm_images = images;
         fa.c2.pm_groups = groups;
