@@ -724,8 +724,8 @@ int run_trunk(adaf_resnet50* net, const float* x4, int n, int P, int tsm_T, int 
                 if ((rc = make_conv_args(h, &p, t1, L2.w, L2.scale, L2.bias, nullptr, t2, &a2))) return rc;
                 // the next block's conv1 rides along unless it carries a temporal shift or a tile override
                 // ('block' placement: the next block reads a shifted COPY of this block's output, so its conv1 cannot ride; 'blockres': it rides
-                //  with the shift as a row offset inside the tile when clips divide the 128-image tiles -- the launcher says -2 otherwise)
-                const ConvLayer* Ln = ((tsm_T == 0 || (tsm_c1 > 0 && 128 % tsm_c1 == 0)) && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;
+                //  with the shift as a row offset inside the tile, whole clips per tile -- adaf_fused_tail_shift_ok)
+                const ConvLayer* Ln = ((tsm_T == 0 || tsm_c1 > 0) && i_next < (int)net->convs.size() && !net->tiles[i_next]) ? &net->convs[i_next] : nullptr;
                 if (Ln && !(Ln->k == 1 && Ln->stride == 1 && Ln->cin == L3.cout && (Ln->cout == 64 || Ln->cout == 128))) Ln = nullptr;
                 const int tsm_n1 = (Ln && tsm_c1 > 0) ? tsm_c1 : 0, fold_n1 = Ln ? Ln->cin / (tsm_div > 0 ? tsm_div : 8) : 0;
                 if (tsm_n1 && !adaf_fused_tail_shift_ok(a2, L3.cout, L3.cout, tsm_n1, fold_n1)) Ln = nullptr;

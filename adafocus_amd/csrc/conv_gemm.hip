@@ -1189,7 +1189,8 @@ void conv_gemm_glds_kernel(const ConvArgs a) {
 // for N1 = 128 (56 KB), so one block's HBM-heavy phase 2 overlaps the others' MFMA-heavy phase 1.  A next conv1 that carries the fused
 // temporal shift rides along in the position-major form when clips divide the 128-image tiles (round 6): a tile's rows are the same pixel of 128
 // CONSECUTIVE frames, so the shifted channels of row r are rows r + 1 / r - 1 of the SAME chunk image (zeros at clip ends, which then include the
-// tile's first and last row) -- phase 3 reads them with a row offset.  Otherwise (other clip lengths, row-major tiles): N1 = 0.
+// tile's first and last row) -- phase 3 reads them with a row offset.  Clip lengths that do not divide 128 take the largest multiple below it as
+// the tile group (120 images for T = 12: eight idle rows per tile).  Row-major tiles: N1 = 0.
 struct FusedTailArgs {
     ConvArgs c2;          // the 3x3 conv (x, w, scale, bias, geometry; N = 64, K = 9 * 64)
     const float* w3;      // [n3][64]
@@ -1204,6 +1205,7 @@ struct FusedTailArgs {
     float* out1;          // [M][N1]
     int act1n;
     int tsm_T1;           // > 0: the next conv1 carries the fused temporal shift over clips of tsm_T1 frames (PM tiles only, 128 % tsm_T1 == 0)
+    int pm_gstride;       // position-major form: images per tile group (128; fewer when a shifted next conv1 needs whole clips per tile: the rows above idle)
     int tsm_np1;          // conv3 passes (32 channels each) per shifted fold: passes [0, np1) read the NEXT frame's rows, [np1, 2 np1) the previous frame's
 };
 
@@ -1257,9 +1259,9 @@ __global__ __launch_bounds__(256, N1 == 128 ? 2 : 3) void conv_fused_tail_kernel
         const int ohw = a.OH * a.OW;
         const int g = bid / ohw;
         roff = bid - g * ohw;
-        m0 = g * BM;
+        m0 = g * fa.pm_gstride;                       // (128, or the largest multiple of the clip length below it: clips never straddle tiles)
         rstride = ohw;
-        rlimit = a.pm_images;
+        rlimit = a.pm_images < m0 + fa.pm_gstride ? a.pm_images : m0 + fa.pm_gstride;
         const int oy = roff / a.OW, ox = roff - oy * a.OW;
         pm_iy0 = oy * a.stride - a.pad;
         pm_ix0 = ox * a.stride - a.pad;
@@ -2023,22 +2025,26 @@ void adaf_launch_conv_naive(const ConvArgs& a, hipStream_t s) {
 
 // Launcher of conv_fused_tail_kernel: c2 = the 3x3 conv's flattened description (64 -> 64, cin % 32 == 0, 16-byte epilogue legal).
 // position-major tiles when the images fill the 128-row groups (<= 6 % padding rows): no tap masks in the gather
-static bool fused_tail_pm(const ConvArgs& c2, int n3, int ldr, int* images_out, int* groups_out) {
+static bool fused_tail_pm(const ConvArgs& c2, int n3, int ldr, int* images_out, int* groups_out, int gstride = 128) {
     const int ohw = c2.OH * c2.OW;
     const int images = ohw > 0 ? c2.M / ohw : 0;
-    const int groups = (images + 127) / 128;
+    const int groups = (images + gstride - 1) / gstride;
     *images_out = images;
     *groups_out = groups;
+    // (with a group stride below 128 the idle rows count as padding too: up to 8 %)
     return c2.pm_allow == 1 && conv_lean_enabled() != 0 && images * ohw == c2.M && images >= 128 && ohw <= 4096 &&
-           (long long)groups * 128 * 100 <= (long long)images * 106 && (size_t)ohw * 8 * (size_t)(n3 > ldr ? n3 : ldr) * 4 < 0xffffff00ull;
+           (long long)groups * 128 * 100 <= (long long)images * (gstride == 128 ? 106 : 108) && (size_t)ohw * 8 * (size_t)(n3 > ldr ? n3 : ldr) * 4 < 0xffffff00ull;
 }
+
+// images per tile group of the position-major tail whose next conv1 is shifted over clips of T frames: whole clips per tile
+static int fused_tail_gstride(int tsm_T1) { return tsm_T1 > 0 && tsm_T1 <= 128 ? (128 / tsm_T1) * tsm_T1 : 128; }
 
 // May the next block's conv1 ride in the fused tail although it carries the fused temporal shift (clips of tsm_T1 frames, fold of tsm_fold1
 // channels)?  Only in the position-major form, with clips dividing the 128-image tiles and whole 32-channel passes per fold.
 bool adaf_fused_tail_shift_ok(const ConvArgs& c2, int n3, int ldr, int tsm_T1, int tsm_fold1) {
     int images, groups;
-    return adaf_options().tsm_lean && tsm_T1 > 0 && fused_tail_pm(c2, n3, ldr, &images, &groups) && 128 % tsm_T1 == 0 && images % tsm_T1 == 0 &&
-           tsm_fold1 > 0 && tsm_fold1 % 32 == 0 && 2 * tsm_fold1 <= n3;
+    return adaf_options().tsm_lean && tsm_T1 > 0 && tsm_T1 <= 128 && fused_tail_pm(c2, n3, ldr, &images, &groups, fused_tail_gstride(tsm_T1)) &&
+           images % tsm_T1 == 0 && tsm_fold1 > 0 && tsm_fold1 % 32 == 0 && 2 * tsm_fold1 <= n3;
 }
 
 // tsm_T1 > 0: the next conv1 (w1n) carries the fused temporal shift (adaf_fused_tail_shift_ok must hold: -2 otherwise, nothing launched).
@@ -2058,13 +2064,14 @@ int adaf_launch_fused_tail(const ConvArgs& c2, const float* w3, const float* s3,
     fa.w1n = w1n; fa.s1n = s1n; fa.b1n = b1n; fa.out1 = out1; fa.act1n = ADAF_ACT_RELU;
     const int ohw = c2.OH * c2.OW;
     int images, groups;
-    const bool pm = fused_tail_pm(c2, n3, ldr, &images, &groups);
-    fa.tsm_T1 = 0; fa.tsm_np1 = 0;
+    fa.tsm_T1 = 0; fa.tsm_np1 = 0; fa.pm_gstride = 128;
     if (n1 != 0 && tsm_T1 > 0) {
         if (!adaf_fused_tail_shift_ok(c2, n3, ldr, tsm_T1, tsm_fold1)) return -2;
         fa.tsm_T1 = tsm_T1;
         fa.tsm_np1 = tsm_fold1 / 32;
+        fa.pm_gstride = fused_tail_gstride(tsm_T1);
     }
+    const bool pm = fused_tail_pm(c2, n3, ldr, &images, &groups, fa.pm_gstride);
     if (pm) {
         fa.c2.pm_images = images;
         fa.c2.pm_groups = groups;

@@ -385,7 +385,9 @@ def test_sth_stage3_classifier_training_forward(dev, O):
                                      (64, 257, 0), (96, 264, 12), (128, 256, 0),
                                      # round 6: a shifted next conv1 rides in the position-major fused tail when clips divide the 128-image tiles
                                      # (full groups, three groups, a ragged last group whose last valid frame ends a clip)
-                                     (96, 256, 16), (48, 384, 8), (32, 248, 8)])
+                                     (96, 256, 16), (48, 384, 8), (32, 248, 8),
+                                     # ... and with 120-image tile groups when clips of 12 frames do not divide 128
+                                     (48, 360, 12), (32, 240, 12)])
 def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
     """Stage-1 conv2 -> conv3 -> next conv1 in one launch and stem + max-pool in one launch (adaf_resnet50_set_fusion):
     same k order in every product, hence torch.equal with the one-launch-per-layer plan -- full tiles, ragged last tiles
@@ -411,10 +413,11 @@ def test_resnet50_fused_launches_bit_identical(dev, p, n, tsm):
     assert torch.isfinite(ref).all()
     assert torch.equal(got, ref)
     assert len(prof) < len(prof_ref)                       # the fused plan really ran (fewer launches)
-    if tsm and n >= 128 and 128 % tsm == 0:                # ... with the shifted next conv1 inside the tail (tile id 92), and without where clips do not fit
-        assert sum(e["tile"] == 92 for e in prof) == 3
-    elif tsm:
-        assert not any(e["tile"] == 92 for e in prof)
+    if tsm:                # ... with the shifted next conv1 inside the tail (tile id 92) where whole clips fill position-major tile groups, else without
+        gs = (128 // tsm) * tsm
+        groups = (n + gs - 1) // gs
+        rides = n >= 128 and groups * 128 * 100 <= n * (106 if gs == 128 else 108)
+        assert sum(e["tile"] == 92 for e in prof) == (3 if rides else 0), (rides, [e["tile"] for e in prof][:8])
     assert abs(sum(e["flops"] for e in prof) - sum(e["flops"] for e in prof_ref)) < 1e-6 * sum(e["flops"] for e in prof_ref)
 
 
