@@ -170,6 +170,10 @@ struct MbFuseArgs {
     const float* res;    // [n][OH][OW][cout] or nullptr
     float* out2;         // [n][OH][OW][cout]
     int cout;
+    // mb_expand_dw_s_kernel (mbstrip.hip: expand -> depthwise of the stride-1 blocks with 64 / 96 input channels): the temporal shift of the
+    // block's INPUT inside the pixel loads -- clips of tsm_T frames, the first tsm_fold channels from the next frame, the next tsm_fold from
+    // the previous one, zeros at clip ends (the buffer descriptor spans the clip: a neighbour frame outside it is out of range) -- 0 = no shift
+    int tsm_T, tsm_fold;
 };
 struct MbStemArgs {       // fused stem -> block 1 (t = 1: depthwise + project) of MobileNetV2
     const float* x;       // [n][S][S][4] pixel-major frames

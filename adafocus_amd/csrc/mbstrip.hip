@@ -746,8 +746,20 @@ __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs
     // ---- expand GEMM roles: A row p = lane & 31 = (er = p >> 4, ec = p & 15) is input pixel (2 s - 1 + er, ox0 - 1 + ec), k = 8 kk + 4 half ..
     const int half = lane >> 5, nl = lane & 31;
     const int er = nl >> 4, ec = nl & 15;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)img * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
-    const int voff0 = (((er - 1) * W + ox0 - 1 + ec) * CIN + 4 * half) * 4;
+    // (temporal shift of the block's input, MbFuseArgs::tsm_T: the descriptor spans the frame's CLIP, a lane's k group reads its own frame, the next or
+    //  the previous one, and a neighbour outside the clip is out of range = zeros.  Out-of-image pixels then land in a neighbouring frame instead of out
+    //  of range: every one of them is overwritten by the row / column masks below.)
+    const int tsmT = a.tsm_T, tfr = tsmT > 0 ? img % tsmT : 0, fbytes = H * W * CIN * 4;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)(img - tfr) * H * W * CIN), 0,
+                                                                     (tsmT > 0 ? tsmT : 1) * fbytes, 0x00020000);
+    const int voff0 = (((er - 1) * W + ox0 - 1 + ec) * CIN + 4 * half) * 4 + tfr * fbytes;
+    constexpr int KS = (KK + 3) / 4;         // the two shifted folds are the first CIN / 4 channels: only the first KK / 4 loads of a pixel carry an offset
+    int dsh[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int ch = 8 * kk + 4 * half;
+        dsh[kk] = tsmT > 0 ? (ch < a.tsm_fold ? fbytes : ch < 2 * a.tsm_fold ? -fbytes : 0) : 0;
+    }
     const int rstep = 2 * W * CIN * 4;
     float* ewr = Ew + (4 * half) * SW_EP + nl;              // natural channel order in the ring
 
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs
     auto fetch = [&](int s) {
         const int vo = voff0 + s * rstep;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) af[kk] = bload(rsrc, vo + 32 * kk);
+        for (int kk = 0; kk < KK; ++kk) af[kk] = bload(rsrc, kk < KS ? vo + 32 * kk + dsh[kk] : vo + 32 * kk);
     };
     load_bf(c_lo);
     fetch(0);

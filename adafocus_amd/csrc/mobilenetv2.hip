@@ -287,8 +287,13 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
                 const bool strip_xd = net->fuse && net->whole && !fused && adaf_mb_expand_dw_strip_ok(b.inp, hid, b.stride, hw, hw);
                 if (strip_xd) fused = true;
                 const float* ein = cur;
-                int fused_T = 0;
-                if (tsm) {
+                int fused_T = 0, strip_T = 0;
+                // the expand -> depthwise strip kernel, whose lanes load whole 4-channel groups of one shift kind (fold % 4 == 0: the 64- / 96-channel blocks):
+                // the shift rides in their pixel loads (MbFuseArgs::tsm_T), nothing is materialised and the identity rows are the input itself
+                // (the whole-block strip kernel of the 32-channel blocks has no register left for the frame offset: 252 of 256; its input stays materialised)
+                const bool strip_shift = tsm && strip_xd && (b.inp / tsm_div) % 4 == 0;
+                if (strip_shift) strip_T = tsm_segments;
+                else if (tsm) {
                     if (!fused && (b.inp / tsm_div) % 4 == 0) fused_T = tsm_segments;   // shift fused into the operand load
                     else {   // fold not a multiple of 4 channels (24-channel block), or the fused kernel: materialise the shift once
                         float* sh = fused ? bufE : bufD;
@@ -303,6 +308,7 @@ int adaf_mobilenetv2_forward(adaf_mobilenetv2* net, const float* frames_nhwc4, i
                     fa.we = E.w; fa.se = E.scale; fa.be = E.bias; fa.wd = D.w; fa.sd = D.scale; fa.bd = D.bias;
                     fa.out = bufD; fa.hid = hid; fa.OH = fa.OW = cdiv_out(hw, 3, b.stride, 1);
                     fa.zeros = net->h->zeros;
+                    fa.tsm_T = strip_T; fa.tsm_fold = strip_T ? b.inp / tsm_div : 0;
                     const MbConv& P = net->convs[b.project];
                     if (net->whole && adaf_mb_block_ok(b.inp, hid, b.oup, b.stride, hw) && P.cin_pad == hid) {
                         // the whole block in one launch: neither expanded map reaches HBM

@@ -69,7 +69,9 @@ def test_strip_kernels_run_to_run_and_batch_position(dev):
 
 def test_sth_glancer_with_temporal_shift_on_strips(dev):
     """The Something-Something glancer (temporal shift in front of the residual blocks' expand convs, STH/models/gfv_net.py:235-246) at 224^2:
-    the shifted input is materialised once and the strip kernels read it, the identity rows stay unshifted -- strips == tiles == unfused."""
+    the expand -> depthwise strips of the 64- / 96-channel blocks take the shift inside their pixel loads (a buffer descriptor over the clip: a
+    neighbour frame outside it reads as zeros), the whole-block strips read a shifted copy, the identity rows stay unshifted -- strips == tiles ==
+    unfused."""
     from adafocus_amd.gfv_net_sth import Glancer
     from tests.test_state_dict_compat import sth_args
     gl = Glancer(sth_args()).eval()
