@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void mb_block_s2_kernel(const MbFuseArgs a)
 // 1x1 conv (k slices of 32, a lane's 16-byte fragment) and dwconv3x3_kernel: bit-identical to the two launches.
 constexpr int XD_MAXCH = 18;                 // chunks (hid <= 576)
 
-template <int CIN>
+template <int CIN, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs a) {
     constexpr int KK = CIN / 8;
     __shared__ __attribute__((aligned(16))) float Eall[4][SW_RING];
@@ -764,11 +764,13 @@ __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs
     float* ewr = Ew + (4 * half) * SW_EP + nl;              // natural channel order in the ring
 
     // ---- depthwise roles: (output column n, channel octet cq)
+    // (STRIDE 2 -- block 14, 14 x 14 -> 7 x 7: output column n of the strip's seven reads ring positions 2 n .. 2 n + 2, one output row per step)
     const int n = lane & 15, cq = lane >> 4;
-    const float* erd = Ew + n * SW_EP + 8 * cq;
+    const float* erd = Ew + STRIDE * n * SW_EP + 8 * cq;
     const float* tw = Tall + cq * SW_TAPF;
-    float* const obase = a.out + ((size_t)img * H * W + ox0 + n) * hid + 8 * cq;       // output row 0 of this lane's column
-    const bool ostore = n < SW_OW;
+    const int OWs = STRIDE == 1 ? W : W / 2;
+    float* const obase = a.out + ((size_t)img * (STRIDE == 1 ? H : H / 2) * OWs + ox0 / STRIDE + n) * hid + 8 * cq;       // output row 0 of this lane's column
+    const bool ostore = n < SW_OW / STRIDE;
 
     f32x4 bf[KK], af[KK];
     float esc, ebi;
@@ -832,7 +834,41 @@ __global__ __launch_bounds__(256, 2) void mb_expand_dw_s_kernel(const MbFuseArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) ewr[(r < 8 ? SL0 : SL1) * SW_ROWF + ((r & 3) + 8 * ((r >> 2) & 1)) * SW_EP] = acc[r];
             __builtin_amdgcn_wave_barrier();
-            if (s > 0) {
+            if (s > 0 && STRIDE == 2) {
+                // output row s - 1 from expanded rows 2 s - 3, 2 s - 2 (the previous step's) and 2 s - 1 (this step's first)
+                constexpr int slot[3] = {par ? 3 : 1, par ? 0 : 2, SL0};
+                f32x2 s0[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s0[i] = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 ta = *reinterpret_cast<const f32x4*>(tc + (e * 3 + kx) * 8), tb = *reinterpret_cast<const f32x4*>(tc + (e * 3 + kx) * 8 + 4);
+                        const f32x2 t4[4] = {{ta.x, ta.y}, {ta.z, ta.w}, {tb.x, tb.y}, {tb.z, tb.w}};
+                        const float* p = erd + slot[e] * SW_ROWF + kx * SW_EP;
+                        const f32x4 va = ringr(p), vb = ringr(p + 4);
+                        const f32x2 v[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pkfma(s0[i], v[i], t4[i]);
+                    }
+                }
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(tc + 72), sb = *reinterpret_cast<const f32x4*>(tc + 76);
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(tc + 80), bb = *reinterpret_cast<const f32x4*>(tc + 84);
+                const f32x2 dsc[4] = {{sa.x, sa.y}, {sa.z, sa.w}, {sb.x, sb.y}, {sb.z, sb.w}}, dbi[4] = {{ba.x, ba.y}, {ba.z, ba.w}, {bb.x, bb.y}, {bb.z, bb.w}};
+                float d0[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 r0 = __builtin_elementwise_fma(s0[i], dsc[i], dbi[i]);
+                    d0[2 * i] = __builtin_amdgcn_fmed3f(r0.x, 0.f, 6.f); d0[2 * i + 1] = __builtin_amdgcn_fmed3f(r0.y, 0.f, 6.f);
+                }
+                if (ostore) {
+                    float* o = optr + (size_t)(s - 1) * OWs * hid;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{d0[0], d0[1], d0[2], d0[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{d0[4], d0[5], d0[6], d0[7]};
+                }
+            }
+            if (s > 0 && STRIDE == 1) {
                 constexpr int slot[4] = {par ? 3 : 1, par ? 0 : 2, SL0, SL1};
                 f32x2 s0[4], s1[4];
 #pragma unroll
@@ -933,10 +969,11 @@ void adaf_launch_mb_block_strip(MbFuseArgs a, hipStream_t s) {
     else hipLaunchKernelGGL((mb_block_s_kernel<32>), grid, block, 0, s, a);
 }
 
-// expand -> depthwise of the stride-1 blocks with 64 / 96 input channels on maps whose side is a multiple of 14 (b8-b13 at 224^2 frames)
+// expand -> depthwise of the stride-1 blocks with 64 / 96 input channels on maps whose side is a multiple of 14 (b8-b13 at 224^2 frames),
+// and of the stride-2 block with 96 (b14: 14 x 14 -> 7 x 7)
 bool adaf_mb_expand_dw_strip_ok(int cin, int hid, int stride, int h, int w) {
-    return adaf_options().mb_strip != 0 && stride == 1 && (cin == 64 || cin == 96) && hid % 32 == 0 && hid <= 32 * XD_MAXCH && h == w && w % SW_OW == 0 &&
-           h % 2 == 0;
+    return adaf_options().mb_strip != 0 && (stride == 1 || (stride == 2 && cin == 96)) && (cin == 64 || cin == 96) && hid % 32 == 0 && hid <= 32 * XD_MAXCH &&
+           h == w && w % SW_OW == 0 && h % 2 == 0;
 }
 
 void adaf_launch_mb_expand_dw_strip(MbFuseArgs a, hipStream_t s) {
@@ -953,6 +990,7 @@ void adaf_launch_mb_expand_dw_strip(MbFuseArgs a, hipStream_t s) {
     a.tiles_y = groups;
     const long long items = (long long)a.n * a.tiles_x * a.tiles_y;
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
-    if (a.cin == 64) hipLaunchKernelGGL((mb_expand_dw_s_kernel<64>), grid, block, 0, s, a);
+    if (a.OH != a.H) hipLaunchKernelGGL((mb_expand_dw_s_kernel<96, 2>), grid, block, 0, s, a);      // stride 2 (block 14)
+    else if (a.cin == 64) hipLaunchKernelGGL((mb_expand_dw_s_kernel<64>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((mb_expand_dw_s_kernel<96>), grid, block, 0, s, a);
 }
