@@ -112,6 +112,9 @@ def mobilenetv2_bytes_per_frame(size=224, fused=True, fused_tail=False, whole_bl
         # round 6: expand -> depthwise on strips for the stride-1 blocks with 64 / 96 input channels on maps whose side is a multiple of 14 (b8-b13 at 224^2)
         if fused and whole_blocks and strips and b["stride"] == 1 and b["inp"] in (64, 96) and b["hw"] % 14 == 0 and hid <= 576:
             pair_fused = True
+        # ... and for the stride-2 block with 96 (b14: 14^2 -> 7^2)
+        if fused and whole_blocks and strips and b["stride"] == 2 and b["inp"] == 96 and b["hw"] % 14 == 0 and hid <= 576:
+            pair_fused = True
         s2_whole = strips and b["stride"] == 2 and b["inp"] in (16, 24) and b["ohw"] % 14 == 0
         if pair_fused and whole_blocks and (b["stride"] == 1 or s2_whole) and b["oup"] <= 32 and hid <= 192:
             elems += hin * b["inp"] + hout * b["oup"] + (hout * b["oup"] if res else 0)

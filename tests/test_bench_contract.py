@@ -83,7 +83,7 @@ def test_workload_byte_and_flop_figures():
     strips = w.mobilenetv2_bytes_per_frame(224, strips=True)
     tiles = w.mobilenetv2_bytes_per_frame(224, strips=False)
     unfused = w.mobilenetv2_bytes_per_frame(224, fused=False)
-    assert block < strips < tiles < unfused and abs(block / 1e6 - 9.51) < 0.01 and abs(tiles / 1e6 - 22.18) < 0.01 and abs(strips / 1e6 - 14.66) < 0.01
+    assert block < strips < tiles < unfused and abs(block / 1e6 - 9.51) < 0.01 and abs(tiles / 1e6 - 22.18) < 0.01 and abs(strips / 1e6 - 13.75) < 0.01
     # frames whose maps are not multiples of 14 take no strip kernel: same bytes either way
     assert w.mobilenetv2_bytes_per_frame(200, strips=True) == w.mobilenetv2_bytes_per_frame(200, strips=False)
     # config 5: the structural floor of a squeeze-and-excite network sits between the block-level bytes and the launch plan's
