@@ -283,7 +283,8 @@ int adaf_resnet50_forward_profiled(adaf_resnet50* net, const float* patches_nhwc
 int adaf_resnet50_set_tiles(adaf_resnet50* net, const int* tile, int count);
 /* Layer fusion inside the trunk (default on; off = one launch per layer, for A/B and the bit-identity tests):
  *   - stage 1 (64 planes): conv2 3x3 -> conv3 1x1 + identity + ReLU -> the NEXT block's conv1 1x1 in one launch per
- *     128-pixel tile (csrc/conv_gemm.hip conv_fused_tail_kernel); the next conv1 is left out when it carries a temporal shift;
+ *     128-pixel tile (csrc/conv_gemm.hip conv_fused_tail_kernel); a next conv1 that carries a temporal shift rides along when whole clips fill
+ *     the position-major 128-image tiles (clip lengths dividing 128; round 6), else it stays a launch of its own;
  *   - stem conv 7x7/2 + BN + ReLU + max-pool 3x3/2 in one launch (csrc/stem.hip) at the patch sizes where that is the
  *     faster plan (on = 2: at every size, for tests); the stage-1 launches likewise only from ~1.5 row tiles of 128 pixels per CU
  *     upwards (below that the three separate launches are faster: small batches; on = 2: always);
